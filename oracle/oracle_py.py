@@ -1,0 +1,392 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (orb_slam2_map_amd) never imports this module.
+Parity status of the oracle itself: see oracle/orb_oracle.h ("parity unpinned").
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MAX_LEVELS = 16
+GRID_COLS, GRID_ROWS = 64, 48
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")])
+CORNER_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
+POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p), ("kp_octave", C.c_void_p),
+                ("kp_angle", C.c_void_p), ("u_right", C.c_void_p), ("desc", C.c_void_p),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("scale_factors", C.c_void_p),
+                ("nlevels", C.c_int), ("cell_start", C.c_void_p), ("cell_items", C.c_void_p)]
+
+
+class MapPointView(C.Structure):
+    _fields_ = [("m", C.c_int), ("in_view", C.c_void_p), ("bad", C.c_void_p), ("obs_pos", C.c_void_p),
+                ("level", C.c_void_p), ("view_cos", C.c_void_p), ("proj_x", C.c_void_p),
+                ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p), ("desc", C.c_void_p)]
+
+
+class LastFrameView(C.Structure):
+    _fields_ = [("n", C.c_int), ("has_mp", C.c_void_p), ("outlier", C.c_void_p), ("obs_pos", C.c_void_p),
+                ("world_pos", C.c_void_p), ("desc", C.c_void_p), ("kp_octave", C.c_void_p),
+                ("kp_angle", C.c_void_p), ("Tcw", C.c_void_p)]
+
+
+def build(out=None, extra_cflags=None):
+    """Compile the oracle with gcc (building the checker is not using it)."""
+    env = dict(os.environ)
+    args = ["make", "-C", _HERE]
+    if out:
+        args.append("OUT=%s" % out)
+    if extra_cflags:
+        args.append("CFLAGS=%s" % extra_cflags)
+    subprocess.run(args, check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return out or os.path.join(_HERE, "liborb_oracle.so")
+
+
+def lib(path=None):
+    global _LIB
+    if path is None and _LIB is not None:
+        return _LIB
+    p = path or os.path.join(_HERE, "liborb_oracle.so")
+    if not os.path.exists(p):
+        build()
+    L = C.CDLL(p)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.ora_extractor_create.restype = vp
+    L.ora_extractor_create.argtypes = [ci, cf, ci, ci, ci]
+    L.ora_extractor_destroy.argtypes = [vp]
+    for name in ("ora_get_scale_factors", "ora_get_inv_scale_factors", "ora_get_sigma2", "ora_get_inv_sigma2",
+                 "ora_get_quotas", "ora_get_umax"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
+    L.ora_get_pattern.restype = vp
+    L.ora_get_levels.argtypes = [vp]
+    L.ora_extract.argtypes = [vp, vp, ci, ci, C.c_size_t, vp, vp, ci]
+    L.ora_pyramid_level.restype = vp
+    L.ora_pyramid_level.argtypes = [vp, ci, vp, vp, vp]
+    L.ora_blurred_level.restype = vp
+    L.ora_blurred_level.argtypes = [vp, ci, vp, vp]
+    L.ora_level_candidates.argtypes = [vp, ci, vp]
+    L.ora_level_selected.argtypes = [vp, ci, vp]
+    L.ora_resize_linear_u8.argtypes = [vp, ci, ci, C.c_size_t, vp, ci, ci, C.c_size_t]
+    L.ora_border_reflect101_u8.argtypes = [vp, ci, ci, C.c_size_t, vp, C.c_size_t, ci]
+    L.ora_gauss7_u8.argtypes = [vp, ci, ci, C.c_size_t, vp, C.c_size_t]
+    L.ora_fast9_16.argtypes = [vp, ci, ci, C.c_size_t, ci, vp, ci]
+    L.ora_distribute_octtree.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci]
+    L.ora_ic_angle.restype = cf
+    L.ora_ic_angle.argtypes = [vp, ci, vp]
+    L.ora_fast_atan2.restype = cf
+    L.ora_fast_atan2.argtypes = [cf, cf]
+    L.ora_orb_descriptor.argtypes = [vp, ci, cf, vp]
+    L.ora_descriptor_distance.argtypes = [vp, vp]
+    L.ora_match_bf.argtypes = [vp, vp, vp, ci, vp, vp, ci, ci, cf, ci, vp]
+    L.ora_assign_features_to_grid.argtypes = [ci, vp, vp, cf, cf, cf, cf, vp, vp]
+    L.ora_get_features_in_area.argtypes = [vp, cf, cf, cf, ci, ci, vp]
+    L.ora_search_by_projection.argtypes = [vp, vp, cf, cf, vp]
+    L.ora_search_by_projection_last.argtypes = [vp, vp, cf, cf, cf, cf, cf, cf, vp, cf, ci, ci, vp]
+    L.ora_is_in_frustum.argtypes = [vp, cf, cf, cf, cf, cf, cf, cf, cf, cf, vp, vp, cf, cf, cf, ci, cf,
+                                    vp, vp, vp, vp, vp]
+    L.ora_compute_stereo_from_rgbd.argtypes = [ci, vp, vp, vp, vp, C.c_size_t, cf, vp, vp]
+    L.ora_backproject.argtypes = [vp, C.c_size_t, vp, C.c_size_t, ci, ci, cf, cf, cf, cf, vp]
+    L.ora_pose_inverse.argtypes = [vp, vp, vp]
+    L.ora_transform_points.argtypes = [vp, ci, vp, vp, vp]
+    L.ora_voxel_filter.argtypes = [vp, ci, cf, vp, vp]
+    if path is None:
+        _LIB = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class Extractor:
+    """Oracle ORBextractor (reference include/ORBextractor.h:46-110)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, libpath=None):
+        self.L = lib(libpath)
+        self.h = self.L.ora_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("bad extractor parameters")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ora_extractor_destroy(self.h)
+            self.h = None
+
+    def scale_factors(self):
+        return _arr(self.L.ora_get_scale_factors(self.h), self.nlevels, "<f4")
+
+    def inv_scale_factors(self):
+        return _arr(self.L.ora_get_inv_scale_factors(self.h), self.nlevels, "<f4")
+
+    def sigma2(self):
+        return _arr(self.L.ora_get_sigma2(self.h), self.nlevels, "<f4")
+
+    def inv_sigma2(self):
+        return _arr(self.L.ora_get_inv_sigma2(self.h), self.nlevels, "<f4")
+
+    def quotas(self):
+        return _arr(self.L.ora_get_quotas(self.h), self.nlevels, "<i4")
+
+    def umax(self):
+        return _arr(self.L.ora_get_umax(self.h), 16, "<i4")
+
+    def extract(self, gray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        h, w = gray.shape
+        cap = self.nfeatures + 4 * self.nlevels + 64
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.ora_extract(self.h, _p(gray), w, h, gray.strides[0], _p(kps), _p(desc), cap)
+        if n < 0:
+            raise RuntimeError("oracle capacity exceeded")
+        return kps[:n].copy(), desc[:n].copy()
+
+    def pyramid_level(self, level):
+        w, h, pitch = C.c_int(), C.c_int(), C.c_int()
+        ptr = self.L.ora_pyramid_level(self.h, level, C.byref(w), C.byref(h), C.byref(pitch))
+        a = _arr(ptr, pitch.value * (h.value + 38), np.uint8)
+        return a.reshape(h.value + 38, pitch.value)
+
+    def blurred_level(self, level):
+        w, h = C.c_int(), C.c_int()
+        ptr = self.L.ora_blurred_level(self.h, level, C.byref(w), C.byref(h))
+        if not ptr:
+            return None
+        return _arr(ptr, w.value * h.value, np.uint8).reshape(h.value, w.value)
+
+    def level_candidates(self, level):
+        out = C.c_void_p()
+        n = self.L.ora_level_candidates(self.h, level, C.byref(out))
+        return _arr(out.value, n, CORNER_DTYPE)
+
+    def level_selected(self, level):
+        out = C.c_void_p()
+        n = self.L.ora_level_selected(self.h, level, C.byref(out))
+        return _arr(out.value, n, CORNER_DTYPE)
+
+
+def pattern():
+    return _arr(lib().ora_get_pattern(), 1024, np.int8)
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().ora_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    return dst
+
+
+def border101(src, border):
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape
+    dst = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    lib().ora_border_reflect101_u8(_p(src), w, h, src.strides[0], _p(dst), dst.strides[0], border)
+    return dst
+
+
+def gauss7(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().ora_gauss7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+    return dst
+
+
+def fast(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = max(1, w * h)
+    out = np.zeros(cap, CORNER_DTYPE)
+    n = lib().ora_fast9_16(_p(img), w, h, img.strides[0], threshold, _p(out), cap)
+    return out[:n].copy()
+
+
+def distribute(keys, min_x, max_x, min_y, max_y, n):
+    keys = np.ascontiguousarray(keys, CORNER_DTYPE)
+    cap = max(1, len(keys))
+    out = np.zeros(cap, CORNER_DTYPE)
+    r = lib().ora_distribute_octtree(_p(keys), len(keys), min_x, max_x, min_y, max_y, n, _p(out), cap)
+    if r < 0:
+        raise ValueError("invalid region")
+    return out[:r].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().ora_descriptor_distance(_p(a), _p(b))
+
+
+def match_bf(desc_a, angle_a, desc_b, angle_b, valid_a=None, th_low=50, nnratio=0.7, check_orientation=True):
+    desc_a = np.ascontiguousarray(desc_a, np.uint8)
+    desc_b = np.ascontiguousarray(desc_b, np.uint8)
+    angle_a = np.ascontiguousarray(angle_a, np.float32)
+    angle_b = np.ascontiguousarray(angle_b, np.float32)
+    va = None if valid_a is None else np.ascontiguousarray(valid_a, np.uint8)
+    out = np.zeros(max(1, len(desc_b)), np.int32)
+    n = lib().ora_match_bf(_p(desc_a), _p(angle_a), _p(va), len(desc_a), _p(desc_b), _p(angle_b), len(desc_b),
+                           th_low, nnratio, int(check_orientation), _p(out))
+    return n, out[:len(desc_b)].copy()
+
+
+def assign_grid(kp_x, kp_y, min_x, min_y, inv_w, inv_h):
+    kp_x = np.ascontiguousarray(kp_x, np.float32)
+    kp_y = np.ascontiguousarray(kp_y, np.float32)
+    cs = np.zeros(GRID_COLS * GRID_ROWS + 1, np.int32)
+    items = np.zeros(max(1, len(kp_x)), np.int32)
+    lib().ora_assign_features_to_grid(len(kp_x), _p(kp_x), _p(kp_y), min_x, min_y, inv_w, inv_h, _p(cs), _p(items))
+    return cs, items[:cs[-1]].copy()
+
+
+class Frame:
+    """SoA view of the Frame members the matcher reads (reference include/Frame.h)."""
+
+    def __init__(self, kp_x, kp_y, octave, angle, u_right, desc, width, height, scale_factors):
+        f32 = np.float32
+        self.kp_x = np.ascontiguousarray(kp_x, f32)
+        self.kp_y = np.ascontiguousarray(kp_y, f32)
+        self.octave = np.ascontiguousarray(octave, np.int32)
+        self.angle = np.ascontiguousarray(angle, f32)
+        self.u_right = np.ascontiguousarray(u_right, f32)
+        self.desc = np.ascontiguousarray(desc, np.uint8)
+        self.n = len(self.kp_x)
+        self.min_x, self.max_x, self.min_y, self.max_y = f32(0), f32(width), f32(0), f32(height)
+        # Frame.cc:155-156
+        self.inv_w = f32(f32(GRID_COLS) / f32(self.max_x - self.min_x))
+        self.inv_h = f32(f32(GRID_ROWS) / f32(self.max_y - self.min_y))
+        self.scale_factors = np.ascontiguousarray(scale_factors, f32)
+        self.cell_start, self.cell_items = assign_grid(self.kp_x, self.kp_y, self.min_x, self.min_y, self.inv_w,
+                                                       self.inv_h)
+        if len(self.cell_items) == 0:
+            self.cell_items = np.zeros(1, np.int32)
+
+    def view(self):
+        v = FrameView()
+        v.n = self.n
+        v.kp_x, v.kp_y, v.kp_octave, v.kp_angle = _p(self.kp_x), _p(self.kp_y), _p(self.octave), _p(self.angle)
+        v.u_right, v.desc = _p(self.u_right), _p(self.desc)
+        v.min_x, v.max_x, v.min_y, v.max_y = self.min_x, self.max_x, self.min_y, self.max_y
+        v.grid_inv_w, v.grid_inv_h = self.inv_w, self.inv_h
+        v.scale_factors, v.nlevels = _p(self.scale_factors), len(self.scale_factors)
+        v.cell_start, v.cell_items = _p(self.cell_start), _p(self.cell_items)
+        return v
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
+        out = np.zeros(max(1, self.n), np.int32)
+        v = self.view()
+        n = lib().ora_get_features_in_area(C.byref(v), x, y, r, min_level, max_level, _p(out))
+        return out[:n].copy()
+
+
+def search_by_projection(frame, mp, th, nnratio, kp_to_mp):
+    """mp: dict of arrays in_view,bad,obs_pos,level,view_cos,proj_x,proj_y,proj_xr,desc."""
+    keep = {k: np.ascontiguousarray(mp[k], dt) for k, dt in
+            (("in_view", np.uint8), ("bad", np.uint8), ("obs_pos", np.uint8), ("level", np.int32),
+             ("view_cos", np.float32), ("proj_x", np.float32), ("proj_y", np.float32), ("proj_xr", np.float32),
+             ("desc", np.uint8))}
+    v = MapPointView()
+    v.m = len(keep["level"])
+    for k in keep:
+        setattr(v, k, _p(keep[k]))
+    fv = frame.view()
+    out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
+    n = lib().ora_search_by_projection(C.byref(fv), C.byref(v), th, nnratio, _p(out))
+    return n, out
+
+
+def search_by_projection_last(cur, cur_Tcw, fx, fy, cx, cy, mbf, mb, last, th, mono, check_ori, kp_to_mp):
+    """last: dict of arrays has_mp,outlier,obs_pos,world_pos,desc,kp_octave,kp_angle,Tcw."""
+    keep = {k: np.ascontiguousarray(last[k], dt) for k, dt in
+            (("has_mp", np.uint8), ("outlier", np.uint8), ("obs_pos", np.uint8), ("world_pos", np.float32),
+             ("desc", np.uint8), ("kp_octave", np.int32), ("kp_angle", np.float32), ("Tcw", np.float32))}
+    v = LastFrameView()
+    v.n = len(keep["kp_octave"])
+    for k in keep:
+        setattr(v, k, _p(keep[k]))
+    fv = cur.view()
+    T = np.ascontiguousarray(cur_Tcw, np.float32)
+    out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
+    n = lib().ora_search_by_projection_last(C.byref(fv), _p(T), fx, fy, cx, cy, mbf, mb, C.byref(v), th, int(mono),
+                                            int(check_ori), _p(out))
+    return n, out
+
+
+def is_in_frustum(Tcw, fx, fy, cx, cy, mbf, width, height, P, normal, min_dist, max_dist, log_sf, cos_limit=0.5):
+    T = np.ascontiguousarray(Tcw, np.float32)
+    P = np.ascontiguousarray(P, np.float32)
+    nrm = np.ascontiguousarray(normal, np.float32)
+    px, py, pxr, vc = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    lvl = C.c_int32()
+    ok = lib().ora_is_in_frustum(_p(T), fx, fy, cx, cy, mbf, 0.0, float(width), 0.0, float(height), _p(P), _p(nrm),
+                                 min_dist, max_dist, log_sf, 0, cos_limit, C.byref(px), C.byref(py), C.byref(pxr),
+                                 C.byref(lvl), C.byref(vc))
+    return bool(ok), px.value, py.value, pxr.value, lvl.value, vc.value
+
+
+def compute_stereo_from_rgbd(kp_x, kp_y, kpun_x, depth, mbf):
+    kp_x = np.ascontiguousarray(kp_x, np.float32)
+    kp_y = np.ascontiguousarray(kp_y, np.float32)
+    kpun_x = np.ascontiguousarray(kpun_x, np.float32)
+    depth = np.ascontiguousarray(depth, np.float32)
+    n = len(kp_x)
+    ur = np.zeros(max(1, n), np.float32)
+    d = np.zeros(max(1, n), np.float32)
+    lib().ora_compute_stereo_from_rgbd(n, _p(kp_x), _p(kp_y), _p(kpun_x), _p(depth), depth.strides[0] // 4, mbf,
+                                       _p(ur), _p(d))
+    return ur[:n], d[:n]
+
+
+def backproject(depth, rgb, fx, fy, cx, cy):
+    depth = np.ascontiguousarray(depth, np.float32)
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = depth.shape
+    cap = ((h + 2) // 3) * ((w + 2) // 3)
+    out = np.zeros(max(1, cap), POINT_DTYPE)
+    n = lib().ora_backproject(_p(depth), depth.strides[0] // 4, _p(rgb), rgb.strides[0], w, h, fx, fy, cx, cy, _p(out))
+    return out[:n].copy()
+
+
+def pose_inverse(Tcw):
+    T = np.ascontiguousarray(Tcw, np.float32)
+    R = np.zeros(9, np.float64)
+    t = np.zeros(3, np.float64)
+    lib().ora_pose_inverse(_p(T), _p(R), _p(t))
+    return R, t
+
+
+def transform_points(pts, R, t):
+    pts = np.ascontiguousarray(pts, POINT_DTYPE)
+    out = np.zeros(max(1, len(pts)), POINT_DTYPE)
+    R = np.ascontiguousarray(R, np.float64)
+    t = np.ascontiguousarray(t, np.float64)
+    lib().ora_transform_points(_p(pts), len(pts), _p(R), _p(t), _p(out))
+    return out[:len(pts)].copy()
+
+
+def voxel_filter(pts, leaf):
+    pts = np.ascontiguousarray(pts, POINT_DTYPE)
+    out = np.zeros(max(1, len(pts)), POINT_DTYPE)
+    ov = C.c_int(0)
+    n = lib().ora_voxel_filter(_p(pts), len(pts), leaf, _p(out), C.byref(ov))
+    return out[:n].copy(), bool(ov.value)

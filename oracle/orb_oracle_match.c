@@ -1,0 +1,457 @@
+/*
+ * orb_oracle_match.c -- CPU ORACLE (test infrastructure, NOT product code; see orb_oracle.h).
+ *
+ * Restates ORB_SLAM2::ORBmatcher (reference src/ORBmatcher.cc) and the Frame helpers it reads
+ * (reference src/Frame.cc).  Compile with -ffp-contract=off.
+ */
+#include "orb_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ M0 */
+/* ORBmatcher::DescriptorDistance, ORBmatcher.cc:1647-1663 (bit-twiddling popcount) */
+int ora_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+    }
+    return dist;
+}
+
+/* ORBmatcher::ComputeThreeMaxima, ORBmatcher.cc:1601-1642 (on bin sizes) */
+static void three_maxima(const int *histo, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    *ind1 = *ind2 = *ind3 = -1;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2;
+            max2 = max1;
+            max1 = s;
+            *ind3 = *ind2;
+            *ind2 = *ind1;
+            *ind1 = i;
+        } else if (s > max2) {
+            max3 = max2;
+            max2 = s;
+            *ind3 = *ind2;
+            *ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            *ind3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) {
+        *ind2 = -1;
+        *ind3 = -1;
+    } else if ((float)max3 < 0.1f * (float)max1) {
+        *ind3 = -1;
+    }
+}
+
+/* rotation bin, ORBmatcher.cc:238-243 / 1433-1438 */
+static int rot_bin(float angle_a, float angle_b)
+{
+    const float factor = 1.0f / ORA_HISTO_LENGTH;
+    float rot = angle_a - angle_b;
+    if (rot < 0.0)
+        rot += 360.0f;
+    int bin = (int)roundf(rot * factor);
+    if (bin == ORA_HISTO_LENGTH)
+        bin = 0;
+    return bin;
+}
+
+/* ------------------------------------------------------------------ M4 */
+int ora_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *valid_a, int na,
+                 const uint8_t *desc_b, const float *angle_b, int nb, int th_low, float nnratio,
+                 int check_orientation, int32_t *match_b)
+{
+    int nmatches = 0;
+    int *bin_of = (int *)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));
+    int histo[ORA_HISTO_LENGTH];
+    memset(histo, 0, sizeof(histo));
+    for (int j = 0; j < nb; j++) {
+        match_b[j] = -1;
+        bin_of[j] = -1;
+    }
+    for (int i = 0; i < na; i++) {
+        if (valid_a && !valid_a[i])
+            continue; /* :195-199 pMP NULL or bad */
+        const uint8_t *da = desc_a + (size_t)i * 32;
+        int best1 = 256, bestIdx = -1, best2 = 256;
+        for (int j = 0; j < nb; j++) {
+            if (match_b[j] >= 0)
+                continue; /* :209-210 */
+            int dist = ora_descriptor_distance(da, desc_b + (size_t)j * 32);
+            if (dist < best1) {
+                best2 = best1;
+                best1 = dist;
+                bestIdx = j;
+            } else if (dist < best2) {
+                best2 = dist;
+            }
+        }
+        if (best1 <= th_low) {
+            if ((float)best1 < nnratio * (float)best2) {
+                match_b[bestIdx] = i;
+                if (check_orientation) {
+                    int bin = rot_bin(angle_a[i], angle_b[bestIdx]);
+                    bin_of[bestIdx] = bin;
+                    histo[bin]++;
+                }
+                nmatches++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        three_maxima(histo, ORA_HISTO_LENGTH, &i1, &i2, &i3);
+        for (int j = 0; j < nb; j++) {
+            int b = bin_of[j];
+            if (b < 0 || b == i1 || b == i2 || b == i3)
+                continue;
+            match_b[j] = -1;
+            nmatches--;
+        }
+    }
+    free(bin_of);
+    return nmatches;
+}
+
+/* ------------------------------------------------------------------ M7 */
+/* Frame::PosInGrid Frame.cc:382-392 + AssignFeaturesToGrid :230-245 */
+void ora_assign_features_to_grid(int n, const float *kp_x, const float *kp_y, float min_x, float min_y,
+                                 float inv_w, float inv_h, int32_t *cell_start, int32_t *cell_items)
+{
+    const int NC = ORA_GRID_COLS * ORA_GRID_ROWS;
+    int *cell_of = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    memset(cell_start, 0, sizeof(int32_t) * (size_t)(NC + 1));
+    for (int i = 0; i < n; i++) {
+        int px = (int)roundf((kp_x[i] - min_x) * inv_w);
+        int py = (int)roundf((kp_y[i] - min_y) * inv_h);
+        if (px < 0 || px >= ORA_GRID_COLS || py < 0 || py >= ORA_GRID_ROWS) {
+            cell_of[i] = -1;
+            continue;
+        }
+        cell_of[i] = px * ORA_GRID_ROWS + py;
+        cell_start[cell_of[i] + 1]++;
+    }
+    for (int c = 0; c < NC; c++)
+        cell_start[c + 1] += cell_start[c];
+    int *pos = (int *)malloc(sizeof(int) * (size_t)NC);
+    for (int c = 0; c < NC; c++)
+        pos[c] = cell_start[c];
+    for (int i = 0; i < n; i++)
+        if (cell_of[i] >= 0)
+            cell_items[pos[cell_of[i]]++] = i;
+    free(pos);
+    free(cell_of);
+}
+
+/* Frame::GetFeaturesInArea, Frame.cc:327-380 */
+int ora_get_features_in_area(const ora_frame_view *f, float x, float y, float r, int min_level, int max_level,
+                             int32_t *out)
+{
+    int n = 0;
+    int c0 = (int)floorf((x - f->min_x - r) * f->grid_inv_w);
+    const int nMinCellX = c0 > 0 ? c0 : 0;
+    if (nMinCellX >= ORA_GRID_COLS)
+        return 0;
+    int c1 = (int)ceilf((x - f->min_x + r) * f->grid_inv_w);
+    const int nMaxCellX = c1 < ORA_GRID_COLS - 1 ? c1 : ORA_GRID_COLS - 1;
+    if (nMaxCellX < 0)
+        return 0;
+    int r0 = (int)floorf((y - f->min_y - r) * f->grid_inv_h);
+    const int nMinCellY = r0 > 0 ? r0 : 0;
+    if (nMinCellY >= ORA_GRID_ROWS)
+        return 0;
+    int r1 = (int)ceilf((y - f->min_y + r) * f->grid_inv_h);
+    const int nMaxCellY = r1 < ORA_GRID_ROWS - 1 ? r1 : ORA_GRID_ROWS - 1;
+    if (nMaxCellY < 0)
+        return 0;
+
+    const int bCheckLevels = (min_level > 0) || (max_level >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            int c = ix * ORA_GRID_ROWS + iy;
+            for (int j = f->cell_start[c]; j < f->cell_start[c + 1]; j++) {
+                int idx = f->cell_items[j];
+                if (bCheckLevels) {
+                    if (f->kp_octave[idx] < min_level)
+                        continue;
+                    if (max_level >= 0)
+                        if (f->kp_octave[idx] > max_level)
+                            continue;
+                }
+                const float distx = f->kp_x[idx] - x;
+                const float disty = f->kp_y[idx] - y;
+                if (fabsf(distx) < r && fabsf(disty) < r)
+                    out[n++] = idx;
+            }
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ M2 */
+static int kp_is_claimed(const int32_t *kp_to_mp, int idx, const uint8_t *obs_pos)
+{
+    int v = kp_to_mp[idx];
+    if (v == -1)
+        return 0;
+    if (v == -2)
+        return 1;
+    return obs_pos ? obs_pos[v] != 0 : 1;
+}
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), ORBmatcher.cc:45-129 */
+int ora_search_by_projection(const ora_frame_view *f, const ora_mappoint_view *mp, float th, float nnratio,
+                             int32_t *kp_to_mp)
+{
+    int nmatches = 0;
+    const int bFactor = th != 1.0;
+    int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(f->n > 0 ? f->n : 1));
+    for (int i = 0; i < mp->m; i++) {
+        if (!mp->in_view[i])
+            continue;
+        if (mp->bad && mp->bad[i])
+            continue;
+        const int lvl = mp->level[i];
+        if (lvl < 0 || lvl >= f->nlevels) {
+            free(vIndices);
+            return -1; /* H5: the reference would index mvScaleFactors out of range */
+        }
+        float r = mp->view_cos[i] > 0.998 ? 2.5f : 4.0f; /* RadiusByViewingCos :131-137 */
+        if (bFactor)
+            r *= th;
+        const float rs = r * f->scale_factors[lvl];
+        int nc = ora_get_features_in_area(f, mp->proj_x[i], mp->proj_y[i], rs, lvl - 1, lvl, vIndices);
+        if (nc == 0)
+            continue;
+        const uint8_t *dmp = mp->desc + (size_t)i * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = vIndices[c];
+            if (kp_is_claimed(kp_to_mp, idx, mp->obs_pos))
+                continue;
+            if (f->u_right[idx] > 0) {
+                const float er = fabsf(mp->proj_xr[i] - f->u_right[idx]);
+                if (er > rs)
+                    continue;
+            }
+            const int dist = ora_descriptor_distance(dmp, f->desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = f->kp_octave[idx];
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = f->kp_octave[idx];
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= ORA_TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)
+                continue;
+            kp_to_mp[bestIdx] = i;
+            nmatches++;
+        }
+    }
+    free(vIndices);
+    return nmatches;
+}
+
+/* ------------------------------------------------------------------ M3 */
+/* cv::Mat 3x3 * 3x1 + 3x1 for CV_32F takes cv::gemm's small-matrix path (OpenCV 2.4
+ * matmul.cpp): float products summed left to right, then one add of the C term.  Adopted. */
+static void rt_apply(const float *T /*4x4 row-major*/, const float *p, float *out)
+{
+    for (int i = 0; i < 3; i++) {
+        float t0 = T[4 * i + 0] * p[0] + T[4 * i + 1] * p[1] + T[4 * i + 2] * p[2];
+        out[i] = t0 + T[4 * i + 3];
+    }
+}
+/* -R^T * t : general gemm path with double accumulators, alpha = -1. */
+static void minus_rt_t(const float *T, float *out)
+{
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++)
+            s += (double)T[4 * k + i] * (double)T[4 * k + 3];
+        out[i] = (float)(s * -1.0);
+    }
+}
+
+int ora_search_by_projection_last(const ora_frame_view *cur, const float *cur_Tcw, float fx, float fy, float cx,
+                                  float cy, float mbf, float mb, const ora_lastframe_view *last, float th,
+                                  int mono, int check_orientation, int32_t *kp_to_mp)
+{
+    int nmatches = 0;
+    int histo[ORA_HISTO_LENGTH];
+    memset(histo, 0, sizeof(histo));
+    /* rotHist[bin].push_back(bestIdx2) replayed as a flat push list (a keypoint can be pushed
+     * more than once when an earlier claimant has Observations()==0, e.g. the RGB-D temporal
+     * points of Tracking::UpdateLastFrame) */
+    int *push_idx = (int *)malloc(sizeof(int) * (size_t)(last->n > 0 ? last->n : 1));
+    int *push_bin = (int *)malloc(sizeof(int) * (size_t)(last->n > 0 ? last->n : 1));
+    int npush = 0;
+    int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cur->n > 0 ? cur->n : 1));
+
+    float twc[3], tlc[3];
+    minus_rt_t(cur_Tcw, twc);
+    rt_apply(last->Tcw, twc, tlc);
+    const int bForward = tlc[2] > mb && !mono;
+    const int bBackward = -tlc[2] > mb && !mono;
+
+    for (int i = 0; i < last->n; i++) {
+        if (!last->has_mp[i])
+            continue;
+        if (last->outlier && last->outlier[i])
+            continue;
+        float xc3[3];
+        rt_apply(cur_Tcw, last->world_pos + 3 * (size_t)i, xc3);
+        const float xc = xc3[0], yc = xc3[1];
+        const float invzc = (float)(1.0 / (double)xc3[2]);
+        if (invzc < 0)
+            continue;
+        float u = fx * xc * invzc + cx;
+        float v = fy * yc * invzc + cy;
+        if (u < cur->min_x || u > cur->max_x)
+            continue;
+        if (v < cur->min_y || v > cur->max_y)
+            continue;
+        int nLastOctave = last->kp_octave[i];
+        if (nLastOctave < 0 || nLastOctave >= cur->nlevels) {
+            nmatches = -1;
+            goto done;
+        }
+        float radius = th * cur->scale_factors[nLastOctave];
+        int nc;
+        if (bForward)
+            nc = ora_get_features_in_area(cur, u, v, radius, nLastOctave, -1, vIndices);
+        else if (bBackward)
+            nc = ora_get_features_in_area(cur, u, v, radius, 0, nLastOctave, vIndices);
+        else
+            nc = ora_get_features_in_area(cur, u, v, radius, nLastOctave - 1, nLastOctave + 1, vIndices);
+        if (nc == 0)
+            continue;
+        const uint8_t *dmp = last->desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = vIndices[c];
+            if (kp_is_claimed(kp_to_mp, i2, last->obs_pos))
+                continue;
+            if (cur->u_right[i2] > 0) {
+                const float ur = u - mbf * invzc;
+                const float er = fabsf(ur - cur->u_right[i2]);
+                if (er > radius)
+                    continue;
+            }
+            const int dist = ora_descriptor_distance(dmp, cur->desc + (size_t)i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= ORA_TH_HIGH) {
+            kp_to_mp[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                int bin = rot_bin(last->kp_angle[i], cur->kp_angle[bestIdx2]);
+                push_idx[npush] = bestIdx2;
+                push_bin[npush++] = bin;
+                histo[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        three_maxima(histo, ORA_HISTO_LENGTH, &i1, &i2, &i3);
+        for (int k = 0; k < npush; k++) {
+            int b = push_bin[k];
+            if (b == i1 || b == i2 || b == i3)
+                continue;
+            kp_to_mp[push_idx[k]] = -1;
+            nmatches--;
+        }
+    }
+done:
+    free(vIndices);
+    free(push_idx);
+    free(push_bin);
+    return nmatches;
+}
+
+/* ------------------------------------------------------------------ M8 */
+/* Frame::isInFrustum, Frame.cc:269-325; MapPoint::PredictScale, MapPoint.cc:385-394 */
+int ora_is_in_frustum(const float *Tcw, float fx, float fy, float cx, float cy, float mbf, float min_x,
+                      float max_x, float min_y, float max_y, const float *P, const float *normal, float min_dist,
+                      float max_dist, float log_scale_factor, int nlevels_unused, float cos_limit, float *proj_x,
+                      float *proj_y, float *proj_xr, int32_t *level, float *view_cos)
+{
+    (void)nlevels_unused;
+    float Pc[3];
+    rt_apply(Tcw, P, Pc);
+    if (Pc[2] < 0.0f)
+        return 0;
+    const float invz = 1.0f / Pc[2];
+    const float u = fx * Pc[0] * invz + cx;
+    const float v = fy * Pc[1] * invz + cy;
+    if (u < min_x || u > max_x)
+        return 0;
+    if (v < min_y || v > max_y)
+        return 0;
+    /* GetMax/MinDistanceInvariance (MapPoint.cc:373-383) */
+    const float maxDistance = 1.2f * max_dist;
+    const float minDistance = 0.8f * min_dist;
+    float Ow[3];
+    minus_rt_t(Tcw, Ow);
+    float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+    /* cv::norm (double accumulation) */
+    const float dist = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+    if (dist < minDistance || dist > maxDistance)
+        return 0;
+    /* Mat::dot (double accumulation) */
+    double dot = (double)PO[0] * normal[0] + (double)PO[1] * normal[1] + (double)PO[2] * normal[2];
+    const float viewCos = (float)(dot / (double)dist);
+    if (viewCos < cos_limit)
+        return 0;
+    float ratio = max_dist / dist;
+    const int nPredictedLevel = (int)ceilf(logf(ratio) / log_scale_factor);
+    *proj_x = u;
+    *proj_xr = u - mbf * invz;
+    *proj_y = v;
+    *level = nPredictedLevel;
+    *view_cos = viewCos;
+    return 1;
+}
+
+/* Frame::ComputeStereoFromRGBD, Frame.cc:641-662 */
+void ora_compute_stereo_from_rgbd(int n, const float *kp_x, const float *kp_y, const float *kpun_x,
+                                  const float *depth, size_t depth_stride_elems, float mbf, float *u_right,
+                                  float *kp_depth)
+{
+    for (int i = 0; i < n; i++) {
+        u_right[i] = -1;
+        kp_depth[i] = -1;
+        /* imDepth.at<float>(v,u): float -> int conversion truncates */
+        const int vi = (int)kp_y[i], ui = (int)kp_x[i];
+        const float d = depth[(size_t)vi * depth_stride_elems + (size_t)ui];
+        if (d > 0) {
+            kp_depth[i] = d;
+            u_right[i] = kpun_x[i] - mbf / d;
+        }
+    }
+}
