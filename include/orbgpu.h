@@ -1,0 +1,292 @@
+/*
+ * orbgpu.h -- C ABI of liborbgpu.so: MI355X (gfx950) implementation of the per-frame hot path
+ * of carry4985/ORB_SLAM2_MAP (ORBextractor + ORBmatcher + PointCloudMapping arithmetic).
+ *
+ * The reference has no FFI/plugin layer: its boundary is three C++ classes compiled into
+ * libORB_SLAM2.so (reference CMakeLists.txt:63-84).  Every entry point below names the
+ * reference interface (file:line, relative to the reference tree) it replaces; the C++ shims
+ * that re-create those classes on top of this ABI are in orb_slam2_map_amd/shim/ and the binding a
+ * maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types; never throws across the ABI;
+ *  - every function returns an orbgpu_status (0 = OK, <0 = error); orbgpu_last_error_string()
+ *    gives a thread-local message;
+ *  - "host" entry points take host pointers and synchronise before returning;
+ *    "*_device" entry points take device pointers plus a hipStream_t (passed as void*), enqueue
+ *    work on that stream and return without synchronising;
+ *  - a handle must not be used from two threads at once; distinct handles are independent.
+ *  - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *    ORBGPU_EHIP.
+ */
+#ifndef ORBGPU_H
+#define ORBGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBGPU_ABI_VERSION 1
+#define ORBGPU_MAX_LEVELS 16
+
+typedef enum {
+    ORBGPU_OK = 0,
+    ORBGPU_EINVAL = -1,    /* bad argument */
+    ORBGPU_ENOMEM = -2,    /* host or device allocation failed */
+    ORBGPU_EHIP = -3,      /* HIP runtime error / no device */
+    ORBGPU_ECAPACITY = -4, /* caller-provided output capacity too small */
+    ORBGPU_ELEVEL = -5     /* predicted pyramid level outside [0,nlevels) (UB in the reference:
+                              ORBmatcher.cc:69 indexes mvScaleFactors with an unclamped
+                              MapPoint::PredictScale, MapPoint.cc:385-394) */
+} orbgpu_status;
+
+const char *orbgpu_last_error_string(void);
+int orbgpu_abi_version(void);
+/* Number of visible HIP devices (0 if none); never fails. */
+int orbgpu_device_count(void);
+
+/* ======================================================================================
+ * ORBextractor  (reference include/ORBextractor.h:46-110, src/ORBextractor.cc)
+ * ====================================================================================== */
+
+/* cv::KeyPoint layout (28 B): pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbgpu_keypoint;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (ORBextractor.h:51-52; values come from the YAML keys read at Tracking.cc:193-197). */
+typedef struct {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t device_id; /* HIP device ordinal */
+    int32_t max_batch; /* frames per batched launch the handle pre-sizes for (>=1) */
+} orbgpu_extractor_params;
+
+typedef struct orbgpu_extractor orbgpu_extractor;
+
+/* replaces `new ORBextractor(...)` (Tracking.cc:201-213) */
+int orbgpu_extractor_create(const orbgpu_extractor_params *params, orbgpu_extractor **out);
+int orbgpu_extractor_destroy(orbgpu_extractor *h);
+
+/* GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (ORBextractor.h:63-83). Arrays receive nlevels floats. */
+int orbgpu_extractor_get_levels(const orbgpu_extractor *h, int32_t *nlevels);
+int orbgpu_extractor_get_scale_factor(const orbgpu_extractor *h, float *scale_factor);
+int orbgpu_extractor_get_scale_factors(const orbgpu_extractor *h, float *out);
+int orbgpu_extractor_get_inv_scale_factors(const orbgpu_extractor *h, float *out);
+int orbgpu_extractor_get_sigma2(const orbgpu_extractor *h, float *out);
+int orbgpu_extractor_get_inv_sigma2(const orbgpu_extractor *h, float *out);
+/* mnFeaturesPerLevel (ORBextractor.h:102) */
+int orbgpu_extractor_get_quotas(const orbgpu_extractor *h, int32_t *out);
+/* Upper bound of keypoints one frame can produce (SURVEY.md E3': a level may return up to
+ * max(4*nIni, quota+2) keypoints) -- the `cap` every extract call needs. */
+int orbgpu_extractor_max_keypoints(const orbgpu_extractor *h, int32_t width, int32_t height, int32_t *cap);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors) (ORBextractor.h:59-61,
+ * ORBextractor.cc:1043-1105; called from Frame::ExtractORB, Frame.cc:247-253).  The mask is
+ * ignored by the reference (ORBextractor.h:58) and has no parameter here.
+ * gray: 8-bit single channel, `stride` bytes per row.  kps[cap], desc[cap*32].  An empty image
+ * (width or height 0) returns OK with *n_out = 0 (ORBextractor.cc:1046). */
+int orbgpu_extract(orbgpu_extractor *h, const uint8_t *gray, int32_t width, int32_t height, size_t stride,
+                   orbgpu_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out);
+
+/* `batch` independent frames of one size in one launch sequence (frames x levels as grid
+ * dimensions).  gray: batch images, `frame_stride` bytes apart.  Outputs are [batch][cap]. */
+int orbgpu_extract_batch(orbgpu_extractor *h, const uint8_t *gray, int32_t batch, int32_t width, int32_t height,
+                         size_t stride, size_t frame_stride, orbgpu_keypoint *kps, uint8_t *desc, int32_t cap,
+                         int32_t *n_out);
+
+/* Device-resident variant: all pointers are device pointers, nothing is copied or synchronised;
+ * d_n_out[batch] receives the per-frame keypoint counts.  If a frame would exceed `cap` its
+ * count is reported as -1 - (required count) and its outputs are unspecified. */
+int orbgpu_extract_batch_device(orbgpu_extractor *h, const uint8_t *d_gray, int32_t batch, int32_t width,
+                                int32_t height, size_t stride, size_t frame_stride, orbgpu_keypoint *d_kps,
+                                uint8_t *d_desc, int32_t cap, int32_t *d_n_out, void *hip_stream);
+
+/* mvImagePyramid[level] (public member, ORBextractor.h:85; read by Frame::ComputeStereoMatches,
+ * Frame.cc:471,561,578).  Copies level `level` of frame `frame` of the LAST call (without the
+ * 19 px border) to host memory, dst_stride bytes per row. */
+int orbgpu_extractor_get_pyramid_level(orbgpu_extractor *h, int32_t frame, int32_t level, uint8_t *dst,
+                                       size_t dst_stride, int32_t *width, int32_t *height);
+
+/* Stage introspection of the last call, for stage-by-stage parity tests (not part of the
+ * drop-in surface).  what: */
+enum {
+    ORBGPU_DBG_PYRAMID_PADDED = 0, /* u8, (h+38) rows of `pitch` bytes; *n = bytes, aux = pitch   */
+    ORBGPU_DBG_BLURRED_PADDED = 1, /* same geometry, only the w x h interior is defined           */
+    ORBGPU_DBG_CANDIDATES = 2,     /* int32 triples (x,y,response), vToDistributeKeys order       */
+    ORBGPU_DBG_SELECTED = 3        /* int32 triples (x,y,response), DistributeOctTree list order  */
+};
+int orbgpu_extractor_debug_read(orbgpu_extractor *h, int32_t what, int32_t frame, int32_t level, void *dst,
+                                size_t dst_bytes, size_t *n, int32_t *aux);
+
+/* Per-kernel device time (ms) of the stages of the last *_device/_batch call, measured with HIP
+ * events on the call's stream when profiling is enabled. Names are returned by
+ * orbgpu_extractor_stage_name(i); count by orbgpu_extractor_stage_count(). */
+int orbgpu_extractor_set_profiling(orbgpu_extractor *h, int32_t enable);
+int orbgpu_extractor_stage_count(void);
+const char *orbgpu_extractor_stage_name(int32_t i);
+/* Synchronises the profiling events of the last call and returns the elapsed ms per stage. */
+int orbgpu_extractor_stage_times(orbgpu_extractor *h, float *ms_out);
+
+/* ======================================================================================
+ * ORBmatcher  (reference include/ORBmatcher.h:41-106, src/ORBmatcher.cc)
+ * ====================================================================================== */
+
+#define ORBGPU_TH_HIGH 100     /* ORBmatcher::TH_HIGH  ORBmatcher.cc:37 */
+#define ORBGPU_TH_LOW 50       /* ORBmatcher::TH_LOW   ORBmatcher.cc:38 */
+#define ORBGPU_HISTO_LENGTH 30 /* ORBmatcher::HISTO_LENGTH ORBmatcher.cc:39 */
+#define ORBGPU_GRID_COLS 64    /* FRAME_GRID_COLS Frame.h:38 */
+#define ORBGPU_GRID_ROWS 48    /* FRAME_GRID_ROWS Frame.h:37 */
+
+/* ORBmatcher::DescriptorDistance (ORBmatcher.h:44, ORBmatcher.cc:1647-1663) for n pairs:
+ * out[i] = Hamming(a[i], b[i]) over 256 bits. Host pointers. */
+int orbgpu_hamming256(const uint8_t *a, const uint8_t *b, int32_t n, int32_t *out, int32_t device_id);
+
+/* Brute-force 256-bit Hamming matcher with the acceptance rule, greedy claim order and rotation
+ * consistency of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:159-288) when all
+ * features share one vocabulary node (the reference has no other brute-force matcher).
+ * For each valid A row in index order: best/second-best over B rows not yet claimed; accept iff
+ * best <= th_low and (float)best < nnratio*(float)second; claim.  match_b[j] = A index or -1.
+ * valid_a may be NULL.  angle_* are cv::KeyPoint::angle (degrees), used iff check_orientation. */
+int orbgpu_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *valid_a, int32_t na,
+                    const uint8_t *desc_b, const float *angle_b, int32_t nb, int32_t th_low, float nnratio,
+                    int32_t check_orientation, int32_t *match_b, int32_t *nmatches, int32_t device_id);
+
+/* Batched device-resident variant: `pairs` independent (A,B) problems.  Row p of every array is
+ * `cap` elements apart; na[p]/nb[p] are device int32 counts (e.g. d_n_out of the extractor).
+ * d_desc: [pairs][cap][32]; d_angle_stride_bytes lets the angle be read in place from an
+ * orbgpu_keypoint array (stride 28) or from a packed float array (stride 4).
+ * d_match_b: [pairs][cap]; d_nmatches: [pairs].  d_valid_a may be NULL. */
+typedef struct orbgpu_matcher orbgpu_matcher;
+int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orbgpu_matcher **out);
+int orbgpu_matcher_destroy(orbgpu_matcher *m);
+int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, const uint8_t *d_desc_a,
+                                 const void *d_angle_a, const uint8_t *d_valid_a, const int32_t *d_na,
+                                 const uint8_t *d_desc_b, const void *d_angle_b, const int32_t *d_nb,
+                                 size_t angle_stride_bytes, int32_t th_low, float nnratio,
+                                 int32_t check_orientation, int32_t *d_match_b, int32_t *d_nmatches,
+                                 void *hip_stream);
+/* Fixpoint sweeps the last batched call needed (diagnostic). */
+int orbgpu_matcher_last_sweeps(orbgpu_matcher *m, int32_t *sweeps);
+
+/* SoA view of the Frame members the projection matchers read (Frame.h:100-190):
+ * mvKeysUn (pt, octave, angle), mvuRight, mDescriptors, image bounds, grid metrics, the
+ * extractor's scale factors, and mGrid flattened to CSR in (ix*ROWS+iy) order with items in
+ * insertion order (Frame::AssignFeaturesToGrid, Frame.cc:230-245). Host pointers. */
+typedef struct {
+    int32_t n;
+    const float *kp_x, *kp_y;
+    const int32_t *kp_octave;
+    const float *kp_angle;
+    const float *u_right;
+    const uint8_t *desc;
+    float min_x, max_x, min_y, max_y;
+    float grid_inv_w, grid_inv_h;
+    const float *scale_factors;
+    int32_t nlevels;
+    const int32_t *cell_start; /* COLS*ROWS+1 */
+    const int32_t *cell_items; /* cell_start[COLS*ROWS] entries */
+} orbgpu_frame_view;
+
+/* Frame::AssignFeaturesToGrid + PosInGrid (Frame.cc:230-245, 382-392): fills the CSR arrays. */
+int orbgpu_assign_features_to_grid(int32_t n, const float *kp_x, const float *kp_y, float min_x, float min_y,
+                                   float grid_inv_w, float grid_inv_h, int32_t *cell_start, int32_t *cell_items);
+
+/* MapPoint tracking scratch filled by Frame::isInFrustum (MapPoint.h:91-96, Frame.cc:317-322)
+ * plus the flags and descriptor the matcher reads per point (ORBmatcher.cc:53-63, 77, 88). */
+typedef struct {
+    int32_t m;
+    const uint8_t *in_view;  /* mbTrackInView */
+    const uint8_t *bad;      /* isBad(); may be NULL */
+    const uint8_t *obs_pos;  /* Observations()>0; may be NULL (= all true) */
+    const int32_t *level;    /* mnTrackScaleLevel */
+    const float *view_cos;   /* mTrackViewCos */
+    const float *proj_x, *proj_y, *proj_xr;
+    const uint8_t *desc;     /* GetDescriptor(), m x 32 */
+} orbgpu_mappoint_view;
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORBmatcher.h:48,
+ * ORBmatcher.cc:45-129; called from Tracking::SearchLocalPoints, Tracking.cc:1495).
+ * kp_to_mp[f->n] in/out: in  >=0 existing association (index into mp), -1 free, -2 held by a map
+ * point outside `mp` with Observations()>0; out: as F.mvpMapPoints after the call. */
+int orbgpu_search_by_projection(const orbgpu_frame_view *f, const orbgpu_mappoint_view *mp, float th,
+                                float nnratio, int32_t *kp_to_mp, int32_t *nmatches, int32_t device_id);
+
+/* LastFrame members read by SearchByProjection(CurrentFrame, LastFrame, th, bMono). */
+typedef struct {
+    int32_t n;
+    const uint8_t *has_mp;    /* mvpMapPoints[i] != NULL */
+    const uint8_t *outlier;   /* mvbOutlier[i]; may be NULL */
+    const uint8_t *obs_pos;   /* pMP->Observations()>0; may be NULL (= all true) */
+    const float *world_pos;   /* n x 3 */
+    const uint8_t *desc;      /* pMP->GetDescriptor(), n x 32 */
+    const int32_t *kp_octave; /* LastFrame.mvKeys[i].octave */
+    const float *kp_angle;    /* LastFrame.mvKeysUn[i].angle */
+    const float *Tcw;         /* LastFrame.mTcw, 4x4 row-major */
+} orbgpu_lastframe_view;
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
+ * (ORBmatcher.h:52, ORBmatcher.cc:1328-1470; Tracking::TrackWithMotionModel, Tracking.cc:1169). */
+int orbgpu_search_by_projection_last(const orbgpu_frame_view *cur, const float *cur_Tcw, float fx, float fy,
+                                     float cx, float cy, float mbf, float mb, const orbgpu_lastframe_view *last,
+                                     float th, int32_t mono, int32_t check_orientation, int32_t *kp_to_mp,
+                                     int32_t *nmatches, int32_t device_id);
+
+/* ======================================================================================
+ * PointCloudMapping  (reference include/PointCloudMap.h:41-88, src/PointCloudMap.cc)
+ * ====================================================================================== */
+
+/* pcl::PointXYZRGBA payload: xyz + packed colour (b | g<<8 | r<<16 | a<<24). 16 B. */
+typedef struct {
+    float x, y, z;
+    uint32_t rgba;
+} orbgpu_point_xyzrgba;
+
+typedef struct orbgpu_cloud orbgpu_cloud;
+
+/* PointCloudMapping::PointCloudMapping(resolution, loopCloser) (PointCloudMap.h:46,
+ * PointCloudMap.cc:36-57): voxel leaf = (float)resolution on all axes. */
+int orbgpu_cloud_create(double resolution, int32_t device_id, orbgpu_cloud **out);
+int orbgpu_cloud_destroy(orbgpu_cloud *h);
+
+/* One key-frame step of PointCloudMapping::viewer (PointCloudMap.cc:204-262, no-loop branch):
+ * convertToPointCloud(kf) -> transformPointCloud(Twc) -> globalMap += -> voxel.filter(globalMap).
+ * depth: float32 metres (after DepthMapFactor), rgb: 8UC3 in the byte order of KeyFrame::mImRGB,
+ * Tcw: kf->GetPose() 4x4 row-major float.  depth_stride in floats, rgb_stride in bytes. */
+int orbgpu_cloud_insert(orbgpu_cloud *h, const float *depth, size_t depth_stride, const uint8_t *rgb,
+                        size_t rgb_stride, int32_t width, int32_t height, float fx, float fy, float cx, float cy,
+                        const float *Tcw);
+/* Loop-closure branch (PointCloudMap.cc:217-243): drop the map, re-generate every key-frame cloud
+ * with its (new) pose, filter once. Arrays of n key-frames of one size. */
+int orbgpu_cloud_rebuild(orbgpu_cloud *h, int32_t n, const float *const *depth, size_t depth_stride,
+                         const uint8_t *const *rgb, size_t rgb_stride, int32_t width, int32_t height, float fx,
+                         float fy, float cx, float cy, const float *const *Tcw);
+int orbgpu_cloud_size(orbgpu_cloud *h, int64_t *n);
+/* Global map in ascending voxel-index order (pcl::VoxelGrid output order). */
+int orbgpu_cloud_download(orbgpu_cloud *h, orbgpu_point_xyzrgba *out, int64_t cap, int64_t *n);
+/* 1 if the last filter hit PCL's int32 voxel-index overflow and returned its input unfiltered. */
+int orbgpu_cloud_last_overflow(orbgpu_cloud *h, int32_t *overflow);
+
+/* Stateless stages (host pointers), for parity tests and other callers:
+ * convertToPointCloud (PointCloudMap.cc:112-138) with optional pose transform (Tcw != NULL:
+ * generatePointCloud, :78-110).  out cap >= ceil(h/3)*ceil(w/3). */
+int orbgpu_backproject(const float *depth, size_t depth_stride, const uint8_t *rgb, size_t rgb_stride,
+                       int32_t width, int32_t height, float fx, float fy, float cx, float cy, const float *Tcw,
+                       orbgpu_point_xyzrgba *out, int64_t cap, int64_t *n, int32_t device_id);
+/* pcl::VoxelGrid<PointXYZRGBA>::filter with leaf = (float)resolution (PointCloudMap.cc:41, 240-243). */
+int orbgpu_voxel_filter(const orbgpu_point_xyzrgba *in, int64_t n, double resolution, orbgpu_point_xyzrgba *out,
+                        int64_t cap, int64_t *n_out, int32_t *overflow, int32_t device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBGPU_H */

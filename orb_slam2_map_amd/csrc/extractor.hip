@@ -1,0 +1,1491 @@
+// ORB extraction pipeline for MI355X (gfx950): image pyramid, per-cell FAST-9/16 with NMS and
+// threshold fallback, quadtree distribution, intensity-centroid orientation, 7x7 Gaussian blur and
+// 256-bit steered BRIEF -- one launch per stage over (cells | tiles | keypoints) x frames.
+//
+// Replaces ORB_SLAM2::ORBextractor::operator() (reference src/ORBextractor.cc:1043-1105) and the
+// OpenCV 2.4 calls it makes.  Integer stages are bit-exact by
+// construction; float stages are written without contraction (see common.h).
+#include "common.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace orbgpu {
+
+constexpr int EDGE = 19;           // EDGE_THRESHOLD, ORBextractor.cc:74
+constexpr int BORDER0 = EDGE - 3;  // minBorderX/Y, ORBextractor.cc:775-776
+constexpr int HALF_PATCH = 15;     // HALF_PATCH_SIZE, ORBextractor.cc:73
+constexpr int PATCH = 31;          // PATCH_SIZE
+constexpr float CELL_W = 30.f;     // W, ORBextractor.cc:769
+
+// ---------------------------------------------------------------------------------------------
+// Geometry tables (host-built, device-read)
+// ---------------------------------------------------------------------------------------------
+struct LevelGeom {
+    int w, h, pitch;     // level size; padded row pitch in bytes (multiple of 64)
+    int plane_off;       // byte offset of the padded plane inside one frame's pyramid block
+    int max_bx, max_by;  // maxBorderX/Y = w-16, h-16
+    int ncols, nrows, wcell, hcell;
+    int cell_first, ncells;  // this level's (non-skipped) cells in the cell table
+    int slot_off, slot_cnt;  // this level's key slots inside one frame's slot block (u32 units)
+    int quota, sel_cap, sel_off;
+    int n_ini;
+    float hx;
+    float scale;
+    int patch;
+    int xtab_off, ytab_off;  // resize tables (levels >= 1)
+    int tile_first, ntiles_x, ntiles_y;  // blur tiles
+};
+
+struct CellDesc {
+    short level;
+    short x0, y0, x1, y1;  // sub-image [x0,x1) x [y0,y1) in level coordinates (FAST apron included)
+    short addx, addy;      // j*wCell, i*hCell  (ORBextractor.cc:822-823)
+    short cap;             // slot capacity
+    int slot_off;          // offset of this cell's slots inside one frame's slot block
+};
+
+struct XTab {  // cv::resize horizontal table entry (A2)
+    uint16_t sx, sx1, a0, a1;
+};
+struct YTab {
+    uint16_t sy0, sy1;
+    int16_t b0, b1;
+};
+
+struct BlurTile {
+    short level, tx, ty, pad;
+};
+
+// packed FAST key: y[31:20] x[19:8] response[7:0]; x,y relative to (minBorderX,minBorderY)
+__host__ __device__ __forceinline__ uint32_t pack_key(int x, int y, int resp)
+{
+    return ((uint32_t)y << 20) | ((uint32_t)x << 8) | (uint32_t)resp;
+}
+__host__ __device__ __forceinline__ int key_x(uint32_t k) { return (int)((k >> 8) & 0xFFF); }
+__host__ __device__ __forceinline__ int key_y(uint32_t k) { return (int)(k >> 20); }
+__host__ __device__ __forceinline__ int key_resp(uint32_t k) { return (int)(k & 0xFF); }
+
+__host__ __device__ __forceinline__ int reflect101(int p, int len)
+{
+    // single bounce is enough: every level is >= 62 px and the border is 19 px
+    if (p < 0)
+        p = -p;
+    else if (p >= len)
+        p = 2 * (len - 1) - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1a: level 0 = copyMakeBorder(image, REFLECT_101)           (ORBextractor.cc:1125-1129, A6)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src, size_t stride,
+                                                 size_t frame_stride, uint8_t *__restrict__ pyr,
+                                                 size_t frame_pyr, const LevelGeom *__restrict__ geom)
+{
+    const LevelGeom g = geom[0];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int py = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x4 >= g.pitch)
+        return;
+    const int sy = reflect101(py - EDGE, g.h);
+    const uint8_t *s = src + (size_t)f * frame_stride + (size_t)sy * stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int px = min(x4 + k, g.w + 2 * EDGE - 1);
+        int sx = reflect101(px - EDGE, g.w);
+        v |= (uint32_t)s[sx] << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + x4) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1b: level l = resize(level l-1, INTER_LINEAR) + copyMakeBorder(REFLECT_101|ISOLATED)
+//      (ORBextractor.cc:1118-1124; OpenCV 2.4 8-bit fixed-point bilinear, A2).  Border pixels are
+//      produced by evaluating the resize at the reflected coordinate, so one pass writes the
+//      whole padded plane.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr, size_t frame_pyr,
+                                                      const LevelGeom *__restrict__ geom, int level,
+                                                      const XTab *__restrict__ xtab,
+                                                      const YTab *__restrict__ ytab)
+{
+    const LevelGeom g = geom[level];
+    const LevelGeom gs = geom[level - 1];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int py = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x4 >= g.pitch)
+        return;
+    const int dy = reflect101(py - EDGE, g.h);
+    const YTab yt = ytab[g.ytab_off + dy];
+    const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + (size_t)EDGE * gs.pitch + EDGE;
+    const uint8_t *S0 = base + (size_t)yt.sy0 * gs.pitch;
+    const uint8_t *S1 = base + (size_t)yt.sy1 * gs.pitch;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int px = min(x4 + k, g.w + 2 * EDGE - 1);
+        int dx = reflect101(px - EDGE, g.w);
+        const XTab xt = xtab[g.xtab_off + dx];
+        int t0 = S0[xt.sx] * xt.a0 + S0[xt.sx1] * xt.a1;
+        int t1 = S1[xt.sx] * xt.a0 + S1[xt.sx1] * xt.a1;
+        int o = ((((int)yt.b0 * (t0 >> 4)) >> 16) + (((int)yt.b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        v |= (uint32_t)(o & 0xFF) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + x4) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: per-cell FAST-9/16 + 3x3 NMS + per-cell threshold fallback
+//     (ORBextractor.cc:789-829 calling cv::FAST(sub, kps, th, true), A4)
+//
+// One 256-thread workgroup per (cell, frame).  The (cell+6)^2 sub-image is staged in LDS; phase A
+// tests the 9-of-16 arc condition at the lower threshold with bit masks; phase B computes the exact
+// corner score s (largest t such that the pixel is a corner for every threshold < s) only for the
+// compacted corner list; phase C applies the strict 3x3 NMS of cv::FAST restricted to the cell's
+// interior at iniThFAST and, if that leaves nothing, at minThFAST; survivors are written in
+// row-major order (cv::FAST's output order) with a ballot-based ordered compaction.
+// ---------------------------------------------------------------------------------------------
+constexpr int TP = 72;        // LDS tile pitch  (cell + 6 <= 72)
+constexpr int TROWS = 72;     // LDS tile rows
+constexpr int SP = 68;        // score map pitch (cell + 2)
+constexpr int MAX_CELL = 66;  // max cell interior edge
+
+__device__ __forceinline__ bool has_arc9(uint32_t m16)
+{
+    uint32_t x = m16 | (m16 << 16);
+    x &= x >> 1;
+    x &= x >> 2;
+    x &= x >> 4;
+    x &= x >> 1;
+    return (x & 0xFFFFu) != 0;
+}
+
+// ring offsets (dx,dy), A4
+#define ORBGPU_RING(F)                                                                                       \
+    F(0, 0, 3) F(1, 1, 3) F(2, 2, 2) F(3, 3, 1) F(4, 3, 0) F(5, 3, -1) F(6, 2, -2) F(7, 1, -3) F(8, 0, -3)    \
+        F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
+
+__device__ __forceinline__ int fast_score(const uint8_t *c)
+{
+    const int v = c[0];
+    int d[16];
+#define LD(i, dx, dy) d[i] = v - (int)c[(dy) * TP + (dx)];
+    ORBGPU_RING(LD)
+#undef LD
+    int m2[16], m4[16], m8[16];
+    int best_dark = -256, best_bright = -256;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m8[k] = min(m4[k], m4[(k + 4) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        best_dark = max(best_dark, min(m8[k], d[(k + 8) & 15]));
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m2[k] = max(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m4[k] = max(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m8[k] = max(m4[k], m4[(k + 4) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        best_bright = max(best_bright, -max(m8[k], d[(k + 8) & 15]));
+    return max(best_dark, best_bright);
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_pyr,
+                                                    const LevelGeom *__restrict__ geom,
+                                                    const CellDesc *__restrict__ cells, int ncells_total,
+                                                    uint32_t *__restrict__ slots, size_t frame_slots,
+                                                    int *__restrict__ cell_cnt, int ini_th, int min_th)
+{
+    __shared__ uint8_t tile[TP * TROWS];
+    __shared__ uint8_t smap[SP * SP];
+    __shared__ uint16_t clist[MAX_CELL * MAX_CELL];
+    __shared__ int s_ccount;
+    __shared__ int s_wave_cnt[4];
+    __shared__ int s_base;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const CellDesc cd = cells[blockIdx.x];
+    const int f = blockIdx.y;
+    const LevelGeom g = geom[cd.level];
+    const int tw = cd.x1 - cd.x0, th = cd.y1 - cd.y0;
+    const int iw = tw - 6, ih = th - 6;
+    int *out_cnt = cell_cnt + (size_t)f * ncells_total + blockIdx.x;
+    if (iw <= 0 || ih <= 0) {
+        if (tid == 0)
+            *out_cnt = 0;
+        return;
+    }
+    const uint8_t *src =
+        pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)(cd.y0 + EDGE) * g.pitch + (cd.x0 + EDGE);
+    for (int i = tid; i < tw * th; i += 256) {
+        int ty = i / tw, tx = i - ty * tw;
+        tile[ty * TP + tx] = src[(size_t)ty * g.pitch + tx];
+    }
+    for (int i = tid; i < (ih + 2) * SP; i += 256)
+        smap[i] = 0;
+    if (tid == 0) {
+        s_ccount = 0;
+        s_base = 0;
+    }
+    __syncthreads();
+
+    // ---- phase A: arc test at the lower of the two thresholds
+    const int tlow = min(ini_th, min_th);
+    const int npix = iw * ih;
+    for (int p = tid; p < npix; p += 256) {
+        int iy = p / iw, ix = p - iy * iw;
+        const uint8_t *c = &tile[(iy + 3) * TP + ix + 3];
+        const int v = c[0];
+        const int hi = v + tlow, lo = v - tlow;
+        uint32_t mb = 0, md = 0;
+#define TST(i, dx, dy)                                                                                       \
+    {                                                                                                        \
+        int q = c[(dy) * TP + (dx)];                                                                         \
+        mb |= (uint32_t)(q > hi) << i;                                                                       \
+        md |= (uint32_t)(q < lo) << i;                                                                       \
+    }
+        ORBGPU_RING(TST)
+#undef TST
+        if (has_arc9(mb) || has_arc9(md)) {
+            int slot = atomicAdd(&s_ccount, 1);
+            clist[slot] = (uint16_t)p;
+        }
+    }
+    __syncthreads();
+    // ---- phase B: exact score for the corner list
+    const int ccount = s_ccount;
+    for (int i = tid; i < ccount; i += 256) {
+        int p = clist[i];
+        int iy = p / iw, ix = p - iy * iw;
+        int s = fast_score(&tile[(iy + 3) * TP + ix + 3]);
+        smap[(iy + 1) * SP + ix + 1] = (uint8_t)s;
+    }
+    __syncthreads();
+
+    // ---- phase C: NMS + ordered compaction, iniThFAST first, minThFAST if the cell stays empty
+    uint32_t *out = slots + (size_t)f * frame_slots + cd.slot_off;
+    int total = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int thr = pass == 0 ? ini_th : min_th;
+        for (int chunk = 0; chunk < npix; chunk += 256) {
+            const int p = chunk + tid;
+            bool keep = false;
+            int ix = 0, iy = 0, s = 0;
+            if (p < npix) {
+                iy = p / iw;
+                ix = p - iy * iw;
+                const uint8_t *sm = &smap[(iy + 1) * SP + ix + 1];
+                s = sm[0];
+                if (s > thr) {
+                    const int r = s - 1;
+                    keep = true;
+#define NB(off)                                                                                              \
+    {                                                                                                        \
+        int sn = sm[off];                                                                                    \
+        int vn = sn > thr ? sn - 1 : 0;                                                                      \
+        keep = keep && (r > vn);                                                                             \
+    }
+                    NB(-SP - 1) NB(-SP) NB(-SP + 1) NB(-1) NB(1) NB(SP - 1) NB(SP) NB(SP + 1)
+#undef NB
+                }
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (lane == 0)
+                s_wave_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int off = s_base, chunk_total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int c = s_wave_cnt[w];
+                off += w < wave ? c : 0;
+                chunk_total += c;
+            }
+            off += __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && off < cd.cap)
+                out[off] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, s - 1);
+            __syncthreads();  // everyone has read s_base / s_wave_cnt
+            if (tid == 0)
+                s_base += chunk_total;
+        }
+        __syncthreads();
+        total = s_base;
+        if (total > 0)
+            break;
+    }
+    if (tid == 0)
+        *out_cnt = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: quadtree distribution                       (DistributeOctTree, ORBextractor.cc:539-763)
+//
+// One workgroup per (level, frame).  The std::list of the reference is kept as arrays in list
+// order in LDS (ping-pong A/B); keys live in HBM (L2-resident) with their node id.  A pass
+// expands a set E of nodes in a processing order:
+//   phase 1 (:591-667): E = every node with >1 keys, processed front-to-back;
+//   phase 2 (:674-736): nodes with >1 keys sorted by (size, creation) descending, E = the shortest
+//            prefix that brings the list to >= N nodes (the reference's `break`).
+// Children are created in processing order (n1..n4, empty ones skipped) and push_front'ed, so the
+// new list is reverse(creation order) followed by the untouched nodes in their old order.
+// Tie-break of the (size, pointer) sort at :684: the node created later compares greater (the
+// reference compares heap addresses, which is not deterministic; the oracle uses the same rule).
+// ---------------------------------------------------------------------------------------------
+struct QtShared {
+    int *ccnt;          // [ncap*4] child key counts (also: cell scan, best-key scratch)
+    int *sa, *sb;       // scan scratch
+    uint16_t *cpos;     // [ncap*4] new list position of child q
+    uint16_t *opos;     // new list position of an untouched node
+    uint16_t *order;    // processing order (node ids)
+    uint8_t *inE;       // node is expanded in this pass
+};
+
+__device__ __forceinline__ int quadrant_of(uint32_t key, short4 b)
+{
+    // ExtractorNode::DivideNode, ORBextractor.cc:481-484, 513-526
+    const int halfx = (int)ceilf((float)(b.z - b.x) / 2);
+    const int halfy = (int)ceilf((float)(b.w - b.y) / 2);
+    const int x = key_x(key), y = key_y(key);
+    return (x < b.x + halfx) ? ((y < b.y + halfy) ? 0 : 2) : ((y < b.y + halfy) ? 1 : 3);
+}
+
+// In-place exclusive scan of an LDS int array by the whole workgroup; returns the total.
+__device__ int block_excl_scan(int *a, int n, int *s_tmp /*>= 8 ints*/)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int ipt = (n + nt - 1) / nt;
+    const int beg = min(tid * ipt, n), end = min(beg + ipt, n);
+    int sum = 0;
+    for (int i = beg; i < end; i++)
+        sum += a[i];
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off, 64);
+        if (lane >= off)
+            inc += t;
+    }
+    if (lane == 63)
+        s_tmp[wave] = inc;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < nw; w++) {
+        int t = s_tmp[w];
+        if (w < wave)
+            woff += t;
+        total += t;
+    }
+    int run = woff + inc - sum;
+    for (int i = beg; i < end; i++) {
+        int t = a[i];
+        a[i] = run;
+        run += t;
+    }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(const LevelGeom *__restrict__ geom,
+                                                  const CellDesc *__restrict__ cells, int ncells_total,
+                                                  const uint32_t *__restrict__ slots, size_t frame_slots,
+                                                  const int *__restrict__ cell_cnt,
+                                                  uint32_t *__restrict__ dense_key,
+                                                  uint16_t *__restrict__ dense_node,
+                                                  uint32_t *__restrict__ sel, int sel_cap_total,
+                                                  int *__restrict__ nsel, int *__restrict__ ncand, int nlevels,
+                                                  int ncap)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ int s_tmp[8];
+    __shared__ int s_n, s_phase, s_done, s_nexp, s_nE, s_cut;
+
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelGeom g = geom[level];
+    const int N = g.quota;
+
+    QtShared S;
+    // list-ordered node arrays, ping-pong A (current) / B (next): bounds (ulx,uly,brx,bry), key
+    // count, creation index inside the pass that created the node
+    short4 *bndA, *bndB;
+    int *cntA, *cntB;
+    uint16_t *creA, *creB;
+    {
+        uint8_t *p = smem;
+        bndA = (short4 *)p; p += sizeof(short4) * ncap;
+        bndB = (short4 *)p; p += sizeof(short4) * ncap;
+        cntA = (int *)p; p += sizeof(int) * ncap;
+        cntB = (int *)p; p += sizeof(int) * ncap;
+        S.ccnt = (int *)p; p += sizeof(int) * ncap * 4;
+        S.sa = (int *)p; p += sizeof(int) * ncap;
+        S.sb = (int *)p; p += sizeof(int) * ncap;
+        S.cpos = (uint16_t *)p; p += sizeof(uint16_t) * ncap * 4;
+        creA = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
+        creB = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
+        S.opos = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
+        S.order = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
+        S.inE = (uint8_t *)p;
+    }
+
+    const uint32_t *fslots = slots + (size_t)f * frame_slots;
+    uint32_t *dkey = dense_key + (size_t)f * frame_slots + g.slot_off;
+    uint16_t *dnode = dense_node + (size_t)f * frame_slots + g.slot_off;
+    const int *ccounts = cell_cnt + (size_t)f * ncells_total + g.cell_first;
+
+    // ---- step 0: compact this level's cell slots into vToDistributeKeys order
+    for (int c = tid; c < g.ncells; c += nt)
+        S.ccnt[c] = ccounts[c];
+    __syncthreads();
+    const int nkeys = block_excl_scan(S.ccnt, g.ncells, s_tmp);
+    {
+        const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+        for (int c = wave; c < g.ncells; c += nw) {
+            const int cnt = ccounts[c];
+            const int off = S.ccnt[c];
+            const uint32_t *srcp = fslots + cells[g.cell_first + c].slot_off;
+            for (int k = lane; k < cnt; k += 64)
+                dkey[off + k] = srcp[k];
+        }
+    }
+    __syncthreads();  // dkey written by this workgroup only; visible after the barrier (same CU)
+    if (tid == 0)
+        ncand[(size_t)f * nlevels + level] = nkeys;
+
+    // ---- step 1: initial nodes (:542-585)
+    const int n_ini = g.n_ini;
+    const float hx = g.hx;
+    for (int b = tid; b < n_ini; b += nt)
+        S.ccnt[b] = 0;
+    __syncthreads();
+    for (int i = tid; i < nkeys; i += nt) {
+        int b = (int)((float)key_x(dkey[i]) / hx);
+        b = min(max(b, 0), n_ini - 1);
+        atomicAdd(&S.ccnt[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        for (int b = 0; b < n_ini; b++) {
+            int c = S.ccnt[b];
+            S.sa[b] = n;  // bin -> list position
+            if (c > 0) {
+                bndA[n] = make_short4((short)(int)(hx * (float)b), 0, (short)(int)(hx * (float)(b + 1)),
+                                          (short)(g.max_by - BORDER0));
+                cntA[n] = c;
+                creA[n] = (uint16_t)n;
+                n++;
+            }
+        }
+        s_n = n;
+        s_phase = 1;
+        s_done = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < nkeys; i += nt) {
+        int b = (int)((float)key_x(dkey[i]) / hx);
+        b = min(max(b, 0), n_ini - 1);
+        dnode[i] = (uint16_t)S.sa[b];
+    }
+    __syncthreads();
+
+    // ---- passes
+    for (int iter = 0; iter < 64; iter++) {
+        const int n = s_n;
+        const int phase = s_phase;
+        if (s_done || n == 0)
+            break;
+        // (1) child key counts of every node with >1 keys
+        for (int i = tid; i < n * 4; i += nt)
+            S.ccnt[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < nkeys; i += nt) {
+            const int nd = dnode[i];
+            if (cntA[nd] > 1)
+                atomicAdd(&S.ccnt[nd * 4 + quadrant_of(dkey[i], bndA[nd])], 1);
+        }
+        __syncthreads();
+
+        // (2) processing order of the expandable nodes
+        for (int p = tid; p < n; p += nt)
+            S.sa[p] = cntA[p] > 1 ? 1 : 0;
+        __syncthreads();
+        const int nv = block_excl_scan(S.sa, n, s_tmp);  // sa[p] = rank among expandable (list order)
+        if (phase == 1) {
+            for (int p = tid; p < n; p += nt)
+                if (cntA[p] > 1)
+                    S.order[S.sa[p]] = (uint16_t)p;
+        } else {
+            // sort by (cnt, creation) descending: rank by counting (keys are unique)
+            for (int p = tid; p < n; p += nt)
+                if (cntA[p] > 1)
+                    S.opos[S.sa[p]] = (uint16_t)p;  // opos as temporary list of expandable nodes
+            __syncthreads();
+            for (int a = tid; a < nv; a += nt) {
+                const int p = S.opos[a];
+                const uint32_t ka = ((uint32_t)cntA[p] << 16) | creA[p];
+                int rank = 0;
+                for (int b = 0; b < nv; b++) {
+                    const int q = S.opos[b];
+                    const uint32_t kb = ((uint32_t)cntA[q] << 16) | creA[q];
+                    rank += kb > ka;
+                }
+                S.order[rank] = (uint16_t)p;
+            }
+        }
+        __syncthreads();
+
+        // (3) children per expandable node in processing order; find the cut for phase 2
+        for (int j = tid; j < nv; j += nt) {
+            const int p = S.order[j];
+            const int *cc = &S.ccnt[p * 4];
+            S.sb[j] = (cc[0] > 0) + (cc[1] > 0) + (cc[2] > 0) + (cc[3] > 0);
+        }
+        if (tid == 0)
+            s_cut = nv;  // number of nodes to expand
+        __syncthreads();
+        const int call = block_excl_scan(S.sb, nv, s_tmp);  // sb[j] = creation index of first child
+        if (phase == 2) {
+            // list size after expanding j+1 nodes = n + (children so far) - (j+1) >= N ?  (:730-731)
+            for (int j = tid; j < nv; j += nt) {
+                const int kids_incl = (j + 1 < nv) ? S.sb[j + 1] : call;
+                if (n + kids_incl - (j + 1) >= N)
+                    atomicMin(&s_cut, j + 1);
+            }
+            __syncthreads();
+        }
+        const int nE = s_cut;
+        const int C = (nE < nv) ? S.sb[nE] : call;  // children created in this pass
+
+        // (4) untouched nodes keep their order behind the children
+        for (int p = tid; p < n; p += nt)
+            S.inE[p] = 0;
+        __syncthreads();
+        for (int j = tid; j < nE; j += nt)
+            S.inE[S.order[j]] = 1;
+        __syncthreads();
+        for (int p = tid; p < n; p += nt)
+            S.sa[p] = S.inE[p] ? 0 : 1;
+        __syncthreads();
+        const int nkept = block_excl_scan(S.sa, n, s_tmp);
+        const int n2 = C + nkept;
+        if (n2 > ncap) {  // cannot happen for validated geometry; fail safe
+            if (tid == 0)
+                s_done = 2;
+            __syncthreads();
+            break;
+        }
+        if (tid == 0)
+            s_nexp = 0;
+        __syncthreads();
+
+        // (5) build the new list
+        for (int p = tid; p < n; p += nt) {
+            if (!S.inE[p]) {
+                const int pos = C + S.sa[p];
+                bndB[pos] = bndA[p];
+                cntB[pos] = cntA[p];
+                creB[pos] = creA[p];
+                S.opos[p] = (uint16_t)pos;
+            }
+        }
+        int my_exp = 0;
+        for (int j = tid; j < nE; j += nt) {
+            const int p = S.order[j];
+            const short4 b = bndA[p];
+            const int halfx = (int)ceilf((float)(b.z - b.x) / 2);
+            const int halfy = (int)ceilf((float)(b.w - b.y) / 2);
+            const short mx = (short)(b.x + halfx), my = (short)(b.y + halfy);
+            int k = S.sb[j];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = S.ccnt[p * 4 + q];
+                if (c == 0)
+                    continue;
+                const int pos = C - 1 - k;
+                short4 cb;
+                cb.x = (q & 1) ? mx : b.x;
+                cb.z = (q & 1) ? b.z : mx;
+                cb.y = (q & 2) ? my : b.y;
+                cb.w = (q & 2) ? b.w : my;
+                bndB[pos] = cb;
+                cntB[pos] = c;
+                creB[pos] = (uint16_t)k;
+                S.cpos[p * 4 + q] = (uint16_t)pos;
+                my_exp += c > 1;
+                k++;
+            }
+        }
+        if (my_exp)
+            atomicAdd(&s_nexp, my_exp);
+        __syncthreads();
+
+        // (6) re-label the keys
+        for (int i = tid; i < nkeys; i += nt) {
+            const int nd = dnode[i];
+            dnode[i] = S.inE[nd] ? S.cpos[nd * 4 + quadrant_of(dkey[i], bndA[nd])] : S.opos[nd];
+        }
+        __syncthreads();
+
+        // (7) termination / phase switch (:669-673, :733-734)
+        if (tid == 0) {
+            s_n = n2;
+            if (n2 >= N || n2 == n)
+                s_done = 1;
+            else if (phase == 1 && n2 + 3 * s_nexp > N)
+                s_phase = 2;
+        }
+        {
+            short4 *tb = bndA; bndA = bndB; bndB = tb;
+            int *tc = cntA; cntA = cntB; cntB = tc;
+            uint16_t *tr = creA; creA = creB; creB = tr;
+        }
+        __syncthreads();
+    }
+
+    // ---- step 3: best response per node, first maximum in key order (:741-760)
+    const int n = s_n;
+    int *best = S.ccnt;
+    for (int p = tid; p < n; p += nt)
+        best[p] = 0;
+    __syncthreads();
+    for (int i = tid; i < nkeys; i += nt)
+        atomicMax(&best[dnode[i]], (int)(((uint32_t)key_resp(dkey[i]) << 23) | (uint32_t)(0x7FFFFF - i)));
+    __syncthreads();
+    uint32_t *osel = sel + (size_t)f * sel_cap_total + g.sel_off;
+    const bool ok = s_done != 2 && n <= g.sel_cap;
+    for (int p = tid; p < n && ok; p += nt) {
+        const int i = 0x7FFFFF - (best[p] & 0x7FFFFF);
+        osel[p] = dkey[i];
+    }
+    if (tid == 0)
+        nsel[(size_t)f * nlevels + level] = ok ? n : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: orientation + key-point assembly
+//     (IC_Angle :77-104, fastAtan2 A5, fix-up :837-847, scaling :1095-1101)
+// One wave per selected key point: lanes cover two rows of the radius-15 disc per step.
+// ---------------------------------------------------------------------------------------------
+struct KpAux {
+    int x, y, level;
+    float angle;
+};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float s = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s;
+    const float p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0)
+        a = 180.f - a;
+    if (y < 0)
+        a = 360.f - a;
+    return a;
+}
+
+struct UMax {
+    int v[16];
+};
+
+__global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, size_t frame_pyr,
+                                                const LevelGeom *__restrict__ geom, int nlevels,
+                                                const uint32_t *__restrict__ sel, int sel_cap_total,
+                                                const int *__restrict__ nsel, UMax um,
+                                                orbgpu_keypoint *__restrict__ kps, KpAux *__restrict__ aux,
+                                                int cap, int *__restrict__ n_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int f = blockIdx.y;
+    const int *ns = nsel + (size_t)f * nlevels;
+    // locate (level, j) of this slot and the output offset
+    int level = -1, j = 0, out_off = 0, total = 0;
+    bool bad = false;
+    for (int l = 0; l < nlevels; l++) {
+        const int c = ns[l];
+        if (c < 0)
+            bad = true;
+        const int so = geom[l].sel_off;
+        if (slot >= so && slot < so + geom[l].sel_cap) {
+            level = l;
+            j = slot - so;
+            out_off = total;
+        }
+        total += max(c, 0);
+    }
+    if (slot == 0 && lane == 0)
+        n_out[f] = bad ? -1 - total : (total > cap ? -1 - total : total);
+    if (level < 0 || bad || total > cap || j >= ns[level])
+        return;
+    const LevelGeom g = geom[level];
+    const uint32_t key = sel[(size_t)f * sel_cap_total + g.sel_off + j];
+    const int x = key_x(key) + BORDER0, y = key_y(key) + BORDER0;
+    const uint8_t *center = pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)(y + EDGE) * g.pitch + (x + EDGE);
+
+    int m10 = 0, m01 = 0;
+    const int u = (lane & 31) - HALF_PATCH;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int v = 2 * r + (lane >> 5) - HALF_PATCH;
+        if (v <= HALF_PATCH && (lane & 31) < 31) {
+            const int av = v < 0 ? -v : v;
+            const int au = u < 0 ? -u : u;
+            if (au <= um.v[av]) {
+                const int val = center[v * g.pitch + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+    }
+    m10 = wave_reduce_add(m10);
+    m01 = wave_reduce_add(m01);
+    if (lane == 0) {
+        const float angle = fast_atan2_deg((float)m01, (float)m10);
+        orbgpu_keypoint kp;
+        kp.x = (float)x;
+        kp.y = (float)y;
+        if (level != 0) {
+            kp.x *= g.scale;
+            kp.y *= g.scale;
+        }
+        kp.size = (float)g.patch;
+        kp.angle = angle;
+        kp.response = (float)key_resp(key);
+        kp.octave = level;
+        kp.class_id = -1;
+        kps[(size_t)f * cap + out_off + j] = kp;
+        KpAux a;
+        a.x = x;
+        a.y = y;
+        a.level = level;
+        a.angle = angle;
+        aux[(size_t)f * cap + out_off + j] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: GaussianBlur(7x7, sigma 2, REFLECT_101), OpenCV 2.4 8-bit fixed-point path (A3).
+// Separable, taps x256 = [18,34,49,55,49,34,18]; dst = sat_u8((sum + 32768) >> 16).  The border
+// the reference gets from REFLECT_101 on the cloned level equals the pyramid's own 19-px
+// reflect-101 border, so the kernel simply reads the padded plane.  Tile 64x32 per workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int BT_W = 64, BT_H = 32;
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                              size_t frame_pyr, const LevelGeom *__restrict__ geom,
+                                              const BlurTile *__restrict__ tiles)
+{
+    __shared__ uint8_t in[(BT_H + 6) * (BT_W + 8)];
+    __shared__ uint16_t hz[(BT_H + 6) * BT_W];
+    const int tid = threadIdx.x;
+    const BlurTile t = tiles[blockIdx.x];
+    const int f = blockIdx.y;
+    const LevelGeom g = geom[t.level];
+    const int x0 = t.tx * BT_W, y0 = t.ty * BT_H;
+    const uint8_t *src = pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)(y0 + EDGE - 3) * g.pitch + (x0 + EDGE - 3);
+    // rows beyond the padded plane are never needed for valid outputs; clamp the row to stay in bounds
+    const int max_row = g.h + 2 * EDGE - 1 - (y0 + EDGE - 3);
+    const int max_col = g.pitch - 1 - (x0 + EDGE - 3);
+    for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+        int r = i / (BT_W + 6), c = i - r * (BT_W + 6);
+        in[r * (BT_W + 8) + c] = src[(size_t)min(r, max_row) * g.pitch + min(c, max_col)];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
+        int r = i / BT_W, c = i - r * BT_W;
+        const uint8_t *p = &in[r * (BT_W + 8) + c];
+        hz[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    }
+    __syncthreads();
+    const int c = tid & 63, rg = tid >> 6;
+    uint8_t *dst = blur + (size_t)f * frame_pyr + g.plane_off + (size_t)(y0 + EDGE) * g.pitch + (x0 + EDGE);
+#pragma unroll
+    for (int k = 0; k < BT_H / 4; k++) {
+        const int r = rg * (BT_H / 4) + k;
+        const uint16_t *p = &hz[r * BT_W + c];
+        int s = 18 * (p[0] + p[6 * BT_W]) + 34 * (p[BT_W] + p[5 * BT_W]) + 49 * (p[2 * BT_W] + p[4 * BT_W]) +
+                55 * p[3 * BT_W];
+        int v = (s + 32768) >> 16;
+        v = v > 255 ? 255 : v;
+        if (x0 + c < g.w && y0 + r < g.h)
+            dst[(size_t)r * g.pitch + c] = (uint8_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: steered BRIEF, 256 bits                         (computeOrbDescriptor, :108-147)
+// 32 lanes per key point, one descriptor byte (8 tests, 16 samples) per lane.
+// ---------------------------------------------------------------------------------------------
+struct Pattern {
+    int8_t v[1024];
+};
+
+__global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, size_t frame_pyr,
+                                                  const LevelGeom *__restrict__ geom,
+                                                  const KpAux *__restrict__ aux, const int *__restrict__ n_out,
+                                                  int cap, const int8_t *__restrict__ pattern,
+                                                  uint8_t *__restrict__ desc)
+{
+    __shared__ __align__(16) int8_t pat[1024];
+    for (int i = threadIdx.x; i < 256; i += 256)
+        reinterpret_cast<uint32_t *>(pat)[i] = reinterpret_cast<const uint32_t *>(pattern)[i];
+    __syncthreads();
+    const int f = blockIdx.y;
+    const int n = n_out[f];
+    const int kpi = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (kpi >= n)
+        return;
+    const int byte = threadIdx.x & 31;
+    const KpAux a = aux[(size_t)f * cap + kpi];
+    const LevelGeom g = geom[a.level];
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float angle = a.angle * factorPI;
+    const float ca = (float)cos((double)angle), sb = (float)sin((double)angle);
+    const uint8_t *center = blur + (size_t)f * frame_pyr + g.plane_off + (size_t)(a.y + EDGE) * g.pitch + (a.x + EDGE);
+    const int8_t *p = &pat[byte * 32];
+    int val = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float x0 = (float)p[4 * k], y0 = (float)p[4 * k + 1];
+        const float x1 = (float)p[4 * k + 2], y1 = (float)p[4 * k + 3];
+        const int r0 = __float2int_rn(x0 * sb + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sb);
+        const int r1 = __float2int_rn(x1 * sb + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sb);
+        const int t0 = center[r0 * g.pitch + c0];
+        const int t1 = center[r1 * g.pitch + c1];
+        val |= (t0 < t1) << k;
+    }
+    desc[((size_t)f * cap + kpi) * 32 + byte] = (uint8_t)val;
+}
+
+// small helper kernels for the debug API
+__global__ void k_unpack_keys(const uint32_t *__restrict__ keys, int n, int *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint32_t k = keys[i];
+        out[3 * i] = key_x(k);
+        out[3 * i + 1] = key_y(k);
+        out[3 * i + 2] = key_resp(k);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------
+static const int8_t k_pattern_host[1024] = {
+#include "orbgpu_pattern.inc"
+};
+
+enum Stage { ST_PYRAMID = 0, ST_FAST, ST_QUADTREE, ST_ORIENT, ST_BLUR, ST_DESCRIBE, ST_COUNT };
+static const char *k_stage_names[ST_COUNT] = {"pyramid", "fast", "quadtree", "orient", "blur", "describe"};
+
+static inline int cv_round_host(double v) { return (int)lrint(v); }
+
+} // namespace orbgpu
+
+using namespace orbgpu;
+
+struct orbgpu_extractor {
+    orbgpu_extractor_params prm;
+    double scale_factor_d;
+    int nlevels;
+    float scale[ORBGPU_MAX_LEVELS], inv_scale[ORBGPU_MAX_LEVELS], sigma2[ORBGPU_MAX_LEVELS],
+        inv_sigma2[ORBGPU_MAX_LEVELS];
+    int quota[ORBGPU_MAX_LEVELS];
+    UMax umax;
+    // geometry of the configured image size
+    int cfg_w = 0, cfg_h = 0, cfg_batch = 0;
+    std::vector<LevelGeom> geom;
+    std::vector<CellDesc> cells;
+    std::vector<BlurTile> tiles;
+    size_t frame_pyr = 0, frame_slots = 0;
+    int sel_cap_total = 0, ncap = 0, max_kp = 0;
+    size_t qt_lds = 0;
+    // device state
+    DevBuf d_geom, d_cells, d_tiles, d_xtab, d_ytab, d_pattern;
+    DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
+    DevBuf d_in, d_kps, d_desc, d_nout;  // staging for the host entry points
+    DevBuf d_dbg;
+    hipStream_t stream = nullptr;
+    int last_batch = 0, last_cap = 0;
+    bool profiling = false;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    bool ev_valid = false;
+};
+
+namespace orbgpu {
+
+// E0: constructor tables, ORBextractor.cc:410-470
+static void build_tables(orbgpu_extractor *e)
+{
+    const int nl = e->nlevels;
+    e->scale_factor_d = (double)e->prm.scale_factor;  // ORBextractor.h:98 keeps a double
+    e->scale[0] = 1.0f;
+    e->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) {
+        e->scale[i] = (float)((double)e->scale[i - 1] * e->scale_factor_d);
+        e->sigma2[i] = e->scale[i] * e->scale[i];
+    }
+    for (int i = 0; i < nl; i++) {
+        e->inv_scale[i] = 1.0f / e->scale[i];
+        e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+    }
+    const float factor = (float)(1.0 / e->scale_factor_d);
+    float desired = (float)e->prm.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; l++) {
+        e->quota[l] = cv_round_host(desired);
+        sum += e->quota[l];
+        desired *= factor;
+    }
+    e->quota[nl - 1] = std::max(e->prm.nfeatures - sum, 0);
+
+    int *um = e->umax.v;
+    const int vmax = (int)floor(HALF_PATCH * sqrtf(2.f) / 2 + 1);
+    const int vmin = (int)ceil(HALF_PATCH * sqrtf(2.f) / 2);
+    const double hp2 = HALF_PATCH * HALF_PATCH;
+    for (int v = 0; v <= vmax; ++v)
+        um[v] = cv_round_host(sqrt(hp2 - v * v));
+    for (int v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+        while (um[v0] == um[v0 + 1])
+            ++v0;
+        um[v] = v0;
+        ++v0;
+    }
+}
+
+static inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+// Level sizes, FAST cell grid, resize tables, slot layout for one image size.
+static int configure(orbgpu_extractor *e, int w, int h, int batch)
+{
+    if (e->cfg_w == w && e->cfg_h == h && batch <= e->cfg_batch)
+        return ORBGPU_OK;
+    const int nl = e->nlevels;
+    std::vector<LevelGeom> geom(nl);
+    std::vector<CellDesc> cells;
+    std::vector<BlurTile> tiles;
+    std::vector<XTab> xtab;
+    std::vector<YTab> ytab;
+    size_t plane_off = 0;
+    int slot_off = 0, sel_off = 0, max_cells_level = 0, ncap = 0;
+    for (int l = 0; l < nl; l++) {
+        LevelGeom &g = geom[l];
+        memset(&g, 0, sizeof(g));
+        g.w = cv_round_host((float)w * e->inv_scale[l]);  // :1112
+        g.h = cv_round_host((float)h * e->inv_scale[l]);
+        g.max_bx = g.w - EDGE + 3;
+        g.max_by = g.h - EDGE + 3;
+        const float width = (float)(g.max_bx - BORDER0), height = (float)(g.max_by - BORDER0);
+        g.ncols = (int)(width / CELL_W);
+        g.nrows = (int)(height / CELL_W);
+        ORBGPU_REQUIRE(g.ncols >= 1 && g.nrows >= 1 && g.w < 4096 + BORDER0 && g.h < 4096 + BORDER0,
+                       "image %dx%d: pyramid level %d (%dx%d) is outside the supported range "
+                       "(each level needs >= 62 px per side and < 4112 px)",
+                       w, h, l, g.w, g.h);
+        g.wcell = (int)ceilf(width / g.ncols);
+        g.hcell = (int)ceilf(height / g.nrows);
+        ORBGPU_REQUIRE(g.wcell <= MAX_CELL && g.hcell <= MAX_CELL, "FAST cell %dx%d too large", g.wcell, g.hcell);
+        g.pitch = ((g.w + 2 * EDGE + 63) / 64) * 64;
+        g.plane_off = (int)plane_off;
+        plane_off += (((size_t)g.pitch * (g.h + 2 * EDGE) + 255) / 256) * 256;
+        g.quota = e->quota[l];
+        g.scale = e->scale[l];
+        g.patch = (int)(PATCH * e->scale[l]);  // :837
+        // DistributeOctTree initial nodes, :542-544
+        g.n_ini = (int)roundf(width / height);
+        ORBGPU_REQUIRE(g.n_ini >= 1, "level %d aspect ratio unsupported (nIni = 0 divides by zero in the reference)", l);
+        g.hx = width / (float)g.n_ini;
+        // cells, :789-808
+        g.cell_first = (int)cells.size();
+        g.slot_off = slot_off;
+        for (int i = 0; i < g.nrows; i++) {
+            const float iniY = (float)(BORDER0 + i * g.hcell);
+            float maxY = iniY + g.hcell + 6;
+            if (iniY >= g.max_by - 3)
+                continue;
+            if (maxY > g.max_by)
+                maxY = (float)g.max_by;
+            for (int j = 0; j < g.ncols; j++) {
+                const float iniX = (float)(BORDER0 + j * g.wcell);
+                float maxX = iniX + g.wcell + 6;
+                if (iniX >= g.max_bx - 6)
+                    continue;
+                if (maxX > g.max_bx)
+                    maxX = (float)g.max_bx;
+                CellDesc c;
+                c.level = (short)l;
+                c.x0 = (short)iniX;
+                c.x1 = (short)maxX;
+                c.y0 = (short)iniY;
+                c.y1 = (short)maxY;
+                c.addx = (short)(j * g.wcell);
+                c.addy = (short)(i * g.hcell);
+                const int iw = std::max(c.x1 - c.x0 - 6, 0), ih = std::max(c.y1 - c.y0 - 6, 0);
+                // strict 3x3 NMS: no two survivors are 8-neighbours
+                c.cap = (short)(((iw + 1) / 2) * ((ih + 1) / 2));
+                c.slot_off = slot_off;
+                slot_off += c.cap;
+                cells.push_back(c);
+            }
+        }
+        g.ncells = (int)cells.size() - g.cell_first;
+        g.slot_cnt = slot_off - g.slot_off;
+        max_cells_level = std::max(max_cells_level, g.ncells);
+        // E3': a level yields at most max(4*nIni, quota+2) key points
+        g.sel_cap = std::max(4 * g.n_ini, g.quota + 3) + 1;
+        g.sel_off = sel_off;
+        sel_off += g.sel_cap;
+        ncap = std::max(ncap, g.sel_cap);
+        // blur tiles
+        g.tile_first = (int)tiles.size();
+        g.ntiles_x = (g.w + BT_W - 1) / BT_W;
+        g.ntiles_y = (g.h + BT_H - 1) / BT_H;
+        for (int ty = 0; ty < g.ntiles_y; ty++)
+            for (int tx = 0; tx < g.ntiles_x; tx++)
+                tiles.push_back(BlurTile{(short)l, (short)tx, (short)ty, 0});
+        // resize tables (cv::resize INTER_LINEAR 8U, A2)
+        g.xtab_off = (int)xtab.size();
+        g.ytab_off = (int)ytab.size();
+        if (l > 0) {
+            const int sw = geom[l - 1].w, sh = geom[l - 1].h;
+            const double scale_x = 1. / ((double)g.w / sw), scale_y = 1. / ((double)g.h / sh);
+            for (int dx = 0; dx < g.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = (int)floor(fx);
+                fx -= sx;
+                if (sx < 0) {
+                    fx = 0;
+                    sx = 0;
+                }
+                if (sx >= sw - 1) {
+                    fx = 0;
+                    sx = sw - 1;
+                }
+                XTab t;
+                t.sx = (uint16_t)sx;
+                t.sx1 = (uint16_t)std::min(sx + 1, sw - 1);
+                t.a0 = (uint16_t)sat_short(cv_round_host((1.f - fx) * 2048));
+                t.a1 = (uint16_t)sat_short(cv_round_host(fx * 2048));
+                xtab.push_back(t);
+            }
+            for (int dy = 0; dy < g.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = (int)floor(fy);
+                fy -= sy;
+                YTab t;
+                t.sy0 = (uint16_t)std::min(std::max(sy, 0), sh - 1);
+                t.sy1 = (uint16_t)std::min(std::max(sy + 1, 0), sh - 1);
+                t.b0 = sat_short(cv_round_host((1.f - fy) * 2048));
+                t.b1 = sat_short(cv_round_host(fy * 2048));
+                ytab.push_back(t);
+            }
+        }
+    }
+    ncap = std::max(ncap, (max_cells_level + 3) / 4);  // the cell scan reuses the [ncap*4] child-count array
+    ncap = ((ncap + 7) / 8) * 8;
+    const size_t qt_lds = (size_t)ncap * (2 * sizeof(short4) + 2 * sizeof(int) + 4 * sizeof(int) + 2 * sizeof(int) +
+                                          4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1) + 64;
+    ORBGPU_REQUIRE(qt_lds <= 160 * 1024 - 1024, "nfeatures too large for the quadtree kernel (needs %zu B of LDS)", qt_lds);
+    ORBGPU_REQUIRE((size_t)slot_off < (1u << 23), "too many FAST key slots per frame");
+
+    e->geom = geom;
+    e->cells = cells;
+    e->tiles = tiles;
+    e->frame_pyr = plane_off;
+    e->frame_slots = (size_t)slot_off;
+    e->sel_cap_total = sel_off;
+    e->ncap = ncap;
+    e->qt_lds = qt_lds;
+    int max_kp = 0;
+    for (int l = 0; l < nl; l++)
+        max_kp += geom[l].sel_cap - 1;
+    e->max_kp = max_kp;
+
+    int rc;
+#define RSV(buf, n) if ((rc = (buf).reserve(n)) != ORBGPU_OK) return rc
+    RSV(e->d_geom, sizeof(LevelGeom) * nl);
+    RSV(e->d_cells, sizeof(CellDesc) * cells.size());
+    RSV(e->d_tiles, sizeof(BlurTile) * tiles.size());
+    RSV(e->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1));
+    RSV(e->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1));
+    RSV(e->d_pattern, 1024);
+    const size_t B = (size_t)batch;
+    RSV(e->d_pyr, e->frame_pyr * B);
+    RSV(e->d_blur, e->frame_pyr * B);
+    RSV(e->d_slots, sizeof(uint32_t) * e->frame_slots * B);
+    RSV(e->d_cellcnt, sizeof(int) * cells.size() * B);
+    RSV(e->d_dkey, sizeof(uint32_t) * e->frame_slots * B);
+    RSV(e->d_dnode, sizeof(uint16_t) * e->frame_slots * B);
+    RSV(e->d_sel, sizeof(uint32_t) * (size_t)sel_off * B);
+    RSV(e->d_nsel, sizeof(int) * nl * B);
+    RSV(e->d_ncand, sizeof(int) * nl * B);
+#undef RSV
+    ORBGPU_HIP_TRY(hipMemcpy(e->d_geom.p, geom.data(), sizeof(LevelGeom) * nl, hipMemcpyHostToDevice));
+    ORBGPU_HIP_TRY(hipMemcpy(e->d_cells.p, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
+    ORBGPU_HIP_TRY(hipMemcpy(e->d_tiles.p, tiles.data(), sizeof(BlurTile) * tiles.size(), hipMemcpyHostToDevice));
+    if (!xtab.empty()) {
+        ORBGPU_HIP_TRY(hipMemcpy(e->d_xtab.p, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpy(e->d_ytab.p, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice));
+    }
+    ORBGPU_HIP_TRY(hipMemcpy(e->d_pattern.p, k_pattern_host, 1024, hipMemcpyHostToDevice));
+    // the blurred planes are only written inside the image; define the rest once
+    ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
+    ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)qt_lds));
+    e->cfg_w = w;
+    e->cfg_h = h;
+    e->cfg_batch = batch;
+    return ORBGPU_OK;
+}
+
+static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch, int w, int h, size_t stride,
+                           size_t frame_stride, orbgpu_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n_out,
+                           hipStream_t st)
+{
+    const int nl = e->nlevels;
+    const LevelGeom *dg = e->d_geom.as<LevelGeom>();
+    uint8_t *pyr = e->d_pyr.as<uint8_t>();
+    uint8_t *blur = e->d_blur.as<uint8_t>();
+    int rc = e->d_aux.reserve(sizeof(KpAux) * (size_t)cap * batch);
+    if (rc != ORBGPU_OK)
+        return rc;
+    const bool prof = e->profiling;
+    if (prof && !e->ev[0])
+        for (int i = 0; i <= ST_COUNT; i++)
+            ORBGPU_HIP_TRY(hipEventCreate(&e->ev[i]));
+#define MARK(i) if (prof) ORBGPU_HIP_TRY(hipEventRecord(e->ev[i], st))
+    MARK(0);
+    {
+        const LevelGeom &g = e->geom[0];
+        dim3 grid((g.pitch / 4 + 255) / 256, g.h + 2 * EDGE, batch);
+        hipLaunchKernelGGL(k_border0, grid, dim3(256), 0, st, d_gray, stride, frame_stride, pyr, e->frame_pyr, dg);
+        for (int l = 1; l < nl; l++) {
+            const LevelGeom &gl = e->geom[l];
+            dim3 gr((gl.pitch / 4 + 255) / 256, gl.h + 2 * EDGE, batch);
+            hipLaunchKernelGGL(k_resize_level, gr, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
+                               e->d_xtab.as<XTab>(), e->d_ytab.as<YTab>());
+        }
+    }
+    MARK(1);
+    hipLaunchKernelGGL(k_fast_cells, dim3((unsigned)e->cells.size(), batch), dim3(256), 0, st, pyr, e->frame_pyr, dg,
+                       e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
+                       e->d_cellcnt.as<int>(), e->prm.ini_th_fast, e->prm.min_th_fast);
+    MARK(2);
+    hipLaunchKernelGGL(k_quadtree, dim3(nl, batch), dim3(256), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
+                       (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
+                       e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(), e->d_sel.as<uint32_t>(),
+                       e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
+    MARK(3);
+    hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 3) / 4, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
+                       e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
+                       e->d_aux.as<KpAux>(), cap, d_n_out);
+    MARK(4);
+    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, st, pyr, blur, e->frame_pyr, dg,
+                       e->d_tiles.as<BlurTile>());
+    MARK(5);
+    hipLaunchKernelGGL(k_describe, dim3((std::min(cap, e->max_kp) + 7) / 8, batch), dim3(256), 0, st, blur,
+                       e->frame_pyr, dg, e->d_aux.as<KpAux>(), d_n_out, cap, e->d_pattern.as<int8_t>(), d_desc);
+    MARK(6);
+#undef MARK
+    ORBGPU_HIP_TRY(hipGetLastError());
+    e->ev_valid = prof;
+    e->last_batch = batch;
+    e->last_cap = cap;
+    (void)w;
+    (void)h;
+    return ORBGPU_OK;
+}
+
+} // namespace orbgpu
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor **out)
+{
+    ORBGPU_REQUIRE(p && out, "null argument");
+    ORBGPU_REQUIRE(p->nlevels >= 1 && p->nlevels <= ORBGPU_MAX_LEVELS, "nlevels must be in [1,%d]", ORBGPU_MAX_LEVELS);
+    ORBGPU_REQUIRE(p->nfeatures >= 1, "nfeatures must be positive");
+    ORBGPU_REQUIRE(p->scale_factor > 1.0f, "scale_factor must be > 1");
+    ORBGPU_REQUIRE(p->ini_th_fast >= 0 && p->ini_th_fast <= 255 && p->min_th_fast >= 0 && p->min_th_fast <= 255,
+                   "FAST thresholds must be in [0,255]");
+    int rc = select_device(p->device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    orbgpu_extractor *e = new (std::nothrow) orbgpu_extractor();
+    if (!e) {
+        set_error("out of host memory");
+        return ORBGPU_ENOMEM;
+    }
+    e->prm = *p;
+    if (e->prm.max_batch < 1)
+        e->prm.max_batch = 1;
+    e->nlevels = p->nlevels;
+    build_tables(e);
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+        set_error("hipStreamCreate: %s", hipGetErrorString(he));
+        delete e;
+        return ORBGPU_EHIP;
+    }
+    *out = e;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_destroy(orbgpu_extractor *e)
+{
+    if (!e)
+        return ORBGPU_OK;
+    (void)hipSetDevice(e->prm.device_id);
+    (void)hipDeviceSynchronize();
+    DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_tiles, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_pyr,
+                      &e->d_blur, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
+                      &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
+    for (DevBuf *b : bufs)
+        b->release();
+    for (int i = 0; i <= ST_COUNT; i++)
+        if (e->ev[i])
+            (void)hipEventDestroy(e->ev[i]);
+    if (e->stream)
+        (void)hipStreamDestroy(e->stream);
+    delete e;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_get_levels(const orbgpu_extractor *e, int32_t *n)
+{
+    ORBGPU_REQUIRE(e && n, "null argument");
+    *n = e->nlevels;
+    return ORBGPU_OK;
+}
+int orbgpu_extractor_get_scale_factor(const orbgpu_extractor *e, float *s)
+{
+    ORBGPU_REQUIRE(e && s, "null argument");
+    *s = (float)e->scale_factor_d;
+    return ORBGPU_OK;
+}
+#define ORBGPU_GETTER(name, field, T)                                                                        \
+    int name(const orbgpu_extractor *e, T *out)                                                              \
+    {                                                                                                        \
+        ORBGPU_REQUIRE(e && out, "null argument");                                                           \
+        for (int i = 0; i < e->nlevels; i++)                                                                 \
+            out[i] = e->field[i];                                                                            \
+        return ORBGPU_OK;                                                                                    \
+    }
+ORBGPU_GETTER(orbgpu_extractor_get_scale_factors, scale, float)
+ORBGPU_GETTER(orbgpu_extractor_get_inv_scale_factors, inv_scale, float)
+ORBGPU_GETTER(orbgpu_extractor_get_sigma2, sigma2, float)
+ORBGPU_GETTER(orbgpu_extractor_get_inv_sigma2, inv_sigma2, float)
+ORBGPU_GETTER(orbgpu_extractor_get_quotas, quota, int32_t)
+#undef ORBGPU_GETTER
+
+int orbgpu_extractor_max_keypoints(const orbgpu_extractor *e, int32_t w, int32_t h, int32_t *cap)
+{
+    ORBGPU_REQUIRE(e && cap, "null argument");
+    ORBGPU_REQUIRE(w > 0 && h > 0, "empty image");
+    int total = 0;
+    for (int l = 0; l < e->nlevels; l++) {
+        const int lw = cv_round_host((float)w * e->inv_scale[l]), lh = cv_round_host((float)h * e->inv_scale[l]);
+        const float width = (float)(lw - 2 * BORDER0), height = (float)(lh - 2 * BORDER0);
+        ORBGPU_REQUIRE(width >= 30 && height >= 30, "pyramid level %d too small", l);
+        const int n_ini = (int)roundf(width / height);
+        total += std::max(4 * n_ini, e->quota[l] + 3);
+    }
+    *cap = total;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_gray, int32_t batch, int32_t w, int32_t h,
+                                size_t stride, size_t frame_stride, orbgpu_keypoint *d_kps, uint8_t *d_desc,
+                                int32_t cap, int32_t *d_n_out, void *hip_stream)
+{
+    ORBGPU_REQUIRE(e && d_gray && d_kps && d_desc && d_n_out, "null argument");
+    ORBGPU_REQUIRE(batch >= 1 && w > 0 && h > 0 && cap >= 1, "bad batch/size/cap");
+    ORBGPU_REQUIRE(stride >= (size_t)w && frame_stride >= stride * (size_t)(h - 1) + (size_t)w, "bad strides");
+    int rc = select_device(e->prm.device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    rc = configure(e, w, h, std::max(batch, e->prm.max_batch));
+    if (rc != ORBGPU_OK)
+        return rc;
+    return launch_pipeline(e, d_gray, batch, w, h, stride, frame_stride, d_kps, d_desc, cap, d_n_out,
+                           (hipStream_t)hip_stream);
+}
+
+int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch, int32_t w, int32_t h,
+                         size_t stride, size_t frame_stride, orbgpu_keypoint *kps, uint8_t *desc, int32_t cap,
+                         int32_t *n_out)
+{
+    ORBGPU_REQUIRE(e && n_out, "null argument");
+    ORBGPU_REQUIRE(batch >= 1, "bad batch");
+    if (w <= 0 || h <= 0 || !gray) {  // ORBextractor.cc:1046: empty image -> silent return
+        for (int i = 0; i < batch; i++)
+            n_out[i] = 0;
+        return ORBGPU_OK;
+    }
+    ORBGPU_REQUIRE(kps && desc && cap >= 1, "null output / bad cap");
+    ORBGPU_REQUIRE(stride >= (size_t)w, "bad stride");
+    int rc = select_device(e->prm.device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    const size_t img = (size_t)w * h;
+    if ((rc = e->d_in.reserve(img * batch)) != ORBGPU_OK)
+        return rc;
+    if ((rc = e->d_kps.reserve(sizeof(orbgpu_keypoint) * (size_t)cap * batch)) != ORBGPU_OK)
+        return rc;
+    if ((rc = e->d_desc.reserve((size_t)32 * cap * batch)) != ORBGPU_OK)
+        return rc;
+    if ((rc = e->d_nout.reserve(sizeof(int) * batch)) != ORBGPU_OK)
+        return rc;
+    for (int f = 0; f < batch; f++)
+        ORBGPU_HIP_TRY(hipMemcpy2DAsync(e->d_in.as<uint8_t>() + img * f, (size_t)w, gray + frame_stride * f, stride,
+                                        (size_t)w, (size_t)h, hipMemcpyHostToDevice, e->stream));
+    rc = orbgpu_extract_batch_device(e, e->d_in.as<uint8_t>(), batch, w, h, (size_t)w, img,
+                                     e->d_kps.as<orbgpu_keypoint>(), e->d_desc.as<uint8_t>(), cap,
+                                     e->d_nout.as<int32_t>(), e->stream);
+    if (rc != ORBGPU_OK)
+        return rc;
+    ORBGPU_HIP_TRY(hipMemcpyAsync(n_out, e->d_nout.p, sizeof(int) * batch, hipMemcpyDeviceToHost, e->stream));
+    ORBGPU_HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int f = 0; f < batch; f++) {
+        if (n_out[f] < 0) {
+            set_error("frame %d needs %d key points but cap is %d", f, -1 - n_out[f], cap);
+            return ORBGPU_ECAPACITY;
+        }
+    }
+    for (int f = 0; f < batch; f++) {
+        if (n_out[f] == 0)
+            continue;
+        ORBGPU_HIP_TRY(hipMemcpyAsync(kps + (size_t)cap * f, e->d_kps.as<orbgpu_keypoint>() + (size_t)cap * f,
+                                      sizeof(orbgpu_keypoint) * n_out[f], hipMemcpyDeviceToHost, e->stream));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(desc + (size_t)32 * cap * f, e->d_desc.as<uint8_t>() + (size_t)32 * cap * f,
+                                      (size_t)32 * n_out[f], hipMemcpyDeviceToHost, e->stream));
+    }
+    ORBGPU_HIP_TRY(hipStreamSynchronize(e->stream));
+    return ORBGPU_OK;
+}
+
+int orbgpu_extract(orbgpu_extractor *e, const uint8_t *gray, int32_t w, int32_t h, size_t stride,
+                   orbgpu_keypoint *kps, uint8_t *desc, int32_t cap, int32_t *n_out)
+{
+    return orbgpu_extract_batch(e, gray, 1, w, h, stride, stride * (size_t)(h > 0 ? h : 0), kps, desc, cap, n_out);
+}
+
+int orbgpu_extractor_get_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, uint8_t *dst,
+                                       size_t dst_stride, int32_t *width, int32_t *height)
+{
+    ORBGPU_REQUIRE(e && dst, "null argument");
+    ORBGPU_REQUIRE(e->last_batch > 0 && frame >= 0 && frame < e->last_batch && level >= 0 && level < e->nlevels,
+                   "no such frame/level in the last call");
+    const LevelGeom &g = e->geom[level];
+    ORBGPU_REQUIRE(dst_stride >= (size_t)g.w, "bad dst_stride");
+    int rc = select_device(e->prm.device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    const uint8_t *src = e->d_pyr.as<uint8_t>() + e->frame_pyr * frame + g.plane_off + (size_t)EDGE * g.pitch + EDGE;
+    ORBGPU_HIP_TRY(hipDeviceSynchronize());
+    ORBGPU_HIP_TRY(hipMemcpy2D(dst, dst_stride, src, (size_t)g.pitch, (size_t)g.w, (size_t)g.h, hipMemcpyDeviceToHost));
+    if (width)
+        *width = g.w;
+    if (height)
+        *height = g.h;
+    return ORBGPU_OK;
+}
+
+int orbgpu_extractor_debug_read(orbgpu_extractor *e, int32_t what, int32_t frame, int32_t level, void *dst,
+                                size_t dst_bytes, size_t *n, int32_t *aux)
+{
+    ORBGPU_REQUIRE(e && dst && n, "null argument");
+    ORBGPU_REQUIRE(e->last_batch > 0 && frame >= 0 && frame < e->last_batch && level >= 0 && level < e->nlevels,
+                   "no such frame/level in the last call");
+    int rc = select_device(e->prm.device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    ORBGPU_HIP_TRY(hipDeviceSynchronize());
+    const LevelGeom &g = e->geom[level];
+    if (what == ORBGPU_DBG_PYRAMID_PADDED || what == ORBGPU_DBG_BLURRED_PADDED) {
+        const size_t bytes = (size_t)g.pitch * (g.h + 2 * EDGE);
+        ORBGPU_REQUIRE(dst_bytes >= bytes, "dst too small (%zu needed)", bytes);
+        const uint8_t *base = (what == ORBGPU_DBG_PYRAMID_PADDED ? e->d_pyr : e->d_blur).as<uint8_t>();
+        ORBGPU_HIP_TRY(hipMemcpy(dst, base + e->frame_pyr * frame + g.plane_off, bytes, hipMemcpyDeviceToHost));
+        *n = bytes;
+        if (aux)
+            *aux = g.pitch;
+        return ORBGPU_OK;
+    }
+    if (what == ORBGPU_DBG_CANDIDATES || what == ORBGPU_DBG_SELECTED) {
+        int cnt = 0;
+        const int *cp = (what == ORBGPU_DBG_CANDIDATES ? e->d_ncand : e->d_nsel).as<int>() + (size_t)frame * e->nlevels + level;
+        ORBGPU_HIP_TRY(hipMemcpy(&cnt, cp, sizeof(int), hipMemcpyDeviceToHost));
+        ORBGPU_REQUIRE(cnt >= 0, "stage reported failure (%d)", cnt);
+        ORBGPU_REQUIRE(dst_bytes >= (size_t)cnt * 12, "dst too small (%zu needed)", (size_t)cnt * 12);
+        const uint32_t *keys = what == ORBGPU_DBG_CANDIDATES
+                                   ? e->d_dkey.as<uint32_t>() + e->frame_slots * frame + g.slot_off
+                                   : e->d_sel.as<uint32_t>() + (size_t)e->sel_cap_total * frame + g.sel_off;
+        if (cnt > 0) {
+            if ((rc = e->d_dbg.reserve((size_t)cnt * 12)) != ORBGPU_OK)
+                return rc;
+            hipLaunchKernelGGL(k_unpack_keys, dim3((cnt + 255) / 256), dim3(256), 0, 0, keys, cnt, e->d_dbg.as<int>());
+            ORBGPU_HIP_TRY(hipMemcpy(dst, e->d_dbg.p, (size_t)cnt * 12, hipMemcpyDeviceToHost));
+        }
+        *n = (size_t)cnt;
+        if (aux)
+            *aux = 0;
+        return ORBGPU_OK;
+    }
+    set_error("unknown debug selector %d", what);
+    return ORBGPU_EINVAL;
+}
+
+int orbgpu_extractor_set_profiling(orbgpu_extractor *e, int32_t enable)
+{
+    ORBGPU_REQUIRE(e, "null argument");
+    e->profiling = enable != 0;
+    return ORBGPU_OK;
+}
+int orbgpu_extractor_stage_count(void) { return ST_COUNT; }
+const char *orbgpu_extractor_stage_name(int32_t i) { return (i >= 0 && i < ST_COUNT) ? k_stage_names[i] : ""; }
+int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms)
+{
+    ORBGPU_REQUIRE(e && ms, "null argument");
+    ORBGPU_REQUIRE(e->ev_valid, "no profiled call recorded");
+    ORBGPU_HIP_TRY(hipEventSynchronize(e->ev[ST_COUNT]));
+    for (int i = 0; i < ST_COUNT; i++)
+        ORBGPU_HIP_TRY(hipEventElapsedTime(&ms[i], e->ev[i], e->ev[i + 1]));
+    return ORBGPU_OK;
+}
+
+} // extern "C"

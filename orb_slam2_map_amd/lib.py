@@ -1,0 +1,486 @@
+"""ctypes binding of liborbgpu.so (include/orbgpu.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared object is missing,
+or no HIP device is visible, calls fail loudly (OrbGpuError / OSError).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liborbgpu.so")
+
+OK, EINVAL, ENOMEM, EHIP, ECAPACITY, ELEVEL = 0, -1, -2, -3, -4, -5
+MAX_LEVELS = 16
+GRID_COLS, GRID_ROWS = 64, 48
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+KEYPOINT_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+     ("octave", "<i4"), ("class_id", "<i4")])
+POINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("rgba", "<u4")])
+
+DBG_PYRAMID_PADDED, DBG_BLURRED_PADDED, DBG_CANDIDATES, DBG_SELECTED = 0, 1, 2, 3
+
+
+class OrbGpuError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("orbgpu status %d: %s" % (status, msg))
+        self.status = status
+
+
+class ExtractorParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("device_id", C.c_int32),
+                ("max_batch", C.c_int32)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("kp_x", C.c_void_p), ("kp_y", C.c_void_p), ("kp_octave", C.c_void_p),
+                ("kp_angle", C.c_void_p), ("u_right", C.c_void_p), ("desc", C.c_void_p),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float),
+                ("grid_inv_w", C.c_float), ("grid_inv_h", C.c_float), ("scale_factors", C.c_void_p),
+                ("nlevels", C.c_int32), ("cell_start", C.c_void_p), ("cell_items", C.c_void_p)]
+
+
+class MapPointView(C.Structure):
+    _fields_ = [("m", C.c_int32), ("in_view", C.c_void_p), ("bad", C.c_void_p), ("obs_pos", C.c_void_p),
+                ("level", C.c_void_p), ("view_cos", C.c_void_p), ("proj_x", C.c_void_p),
+                ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p), ("desc", C.c_void_p)]
+
+
+class LastFrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("has_mp", C.c_void_p), ("outlier", C.c_void_p), ("obs_pos", C.c_void_p),
+                ("world_pos", C.c_void_p), ("desc", C.c_void_p), ("kp_octave", C.c_void_p),
+                ("kp_angle", C.c_void_p), ("Tcw", C.c_void_p)]
+
+
+_LIB = None
+
+# every symbol include/orbgpu.h declares (checked by tests/test_abi.py against the header text)
+ABI_SYMBOLS = [
+    "orbgpu_last_error_string", "orbgpu_abi_version", "orbgpu_device_count",
+    "orbgpu_extractor_create", "orbgpu_extractor_destroy", "orbgpu_extractor_get_levels",
+    "orbgpu_extractor_get_scale_factor", "orbgpu_extractor_get_scale_factors",
+    "orbgpu_extractor_get_inv_scale_factors", "orbgpu_extractor_get_sigma2", "orbgpu_extractor_get_inv_sigma2",
+    "orbgpu_extractor_get_quotas", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
+    "orbgpu_extract_batch_device", "orbgpu_extractor_get_pyramid_level", "orbgpu_extractor_debug_read",
+    "orbgpu_extractor_set_profiling", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
+    "orbgpu_extractor_stage_times",
+    "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
+    "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
+    "orbgpu_search_by_projection", "orbgpu_search_by_projection_last",
+    "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
+    "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
+    "orbgpu_voxel_filter",
+]
+
+
+def lib():
+    """Loads liborbgpu.so. Raises OSError if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(the HIP extension is the product; there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+    L.orbgpu_last_error_string.restype = C.c_char_p
+    L.orbgpu_extractor_stage_name.restype = C.c_char_p
+    L.orbgpu_extractor_stage_name.argtypes = [i32]
+    sigs = {
+        "orbgpu_extractor_create": [vp, vp],
+        "orbgpu_extractor_destroy": [vp],
+        "orbgpu_extractor_get_levels": [vp, vp],
+        "orbgpu_extractor_get_scale_factor": [vp, vp],
+        "orbgpu_extractor_get_scale_factors": [vp, vp],
+        "orbgpu_extractor_get_inv_scale_factors": [vp, vp],
+        "orbgpu_extractor_get_sigma2": [vp, vp],
+        "orbgpu_extractor_get_inv_sigma2": [vp, vp],
+        "orbgpu_extractor_get_quotas": [vp, vp],
+        "orbgpu_extractor_max_keypoints": [vp, i32, i32, vp],
+        "orbgpu_extract": [vp, vp, i32, i32, sz, vp, vp, i32, vp],
+        "orbgpu_extract_batch": [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp],
+        "orbgpu_extract_batch_device": [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp, vp],
+        "orbgpu_extractor_get_pyramid_level": [vp, i32, i32, vp, sz, vp, vp],
+        "orbgpu_extractor_debug_read": [vp, i32, i32, i32, vp, sz, vp, vp],
+        "orbgpu_extractor_set_profiling": [vp, i32],
+        "orbgpu_extractor_stage_times": [vp, vp],
+        "orbgpu_hamming256": [vp, vp, i32, vp, i32],
+        "orbgpu_match_bf": [vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, i32],
+        "orbgpu_matcher_create": [i32, i32, i32, vp],
+        "orbgpu_matcher_destroy": [vp],
+        "orbgpu_match_bf_batch_device": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, i32, f32, i32, vp, vp, vp],
+        "orbgpu_matcher_last_sweeps": [vp, vp],
+        "orbgpu_assign_features_to_grid": [i32, vp, vp, f32, f32, f32, f32, vp, vp],
+        "orbgpu_search_by_projection": [vp, vp, f32, f32, vp, vp, i32],
+        "orbgpu_search_by_projection_last": [vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
+        "orbgpu_cloud_create": [C.c_double, i32, vp],
+        "orbgpu_cloud_destroy": [vp],
+        "orbgpu_cloud_insert": [vp, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
+        "orbgpu_cloud_rebuild": [vp, i32, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
+        "orbgpu_cloud_size": [vp, vp],
+        "orbgpu_cloud_download": [vp, vp, C.c_int64, vp],
+        "orbgpu_cloud_last_overflow": [vp, vp],
+        "orbgpu_backproject": [vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp, vp, C.c_int64, vp, i32],
+        "orbgpu_voxel_filter": [vp, C.c_int64, C.c_double, vp, C.c_int64, vp, vp, i32],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.argtypes = args
+            fn.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def check(status):
+    if status != OK:
+        raise OrbGpuError(status, lib().orbgpu_last_error_string().decode("utf-8", "replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    return lib().orbgpu_device_count()
+
+
+# --------------------------------------------------------------------------------------------
+# ORBextractor (reference include/ORBextractor.h:46-110)
+# --------------------------------------------------------------------------------------------
+class ORBextractor:
+    """Mirror of ORB_SLAM2::ORBextractor; __call__ mirrors operator() (ORBextractor.h:59-61)."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device_id=0,
+                 max_batch=1):
+        self.L = lib()
+        self.params = ExtractorParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id, max_batch)
+        h = C.c_void_p()
+        check(self.L.orbgpu_extractor_create(C.byref(self.params), C.byref(h)))
+        self.h = h
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbgpu_extractor_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def GetLevels(self):
+        n = C.c_int32()
+        check(self.L.orbgpu_extractor_get_levels(self.h, C.byref(n)))
+        return n.value
+
+    def GetScaleFactor(self):
+        s = C.c_float()
+        check(self.L.orbgpu_extractor_get_scale_factor(self.h, C.byref(s)))
+        return s.value
+
+    def _vec(self, fn, dtype):
+        out = np.zeros(self.nlevels, dtype)
+        check(fn(self.h, _p(out)))
+        return out
+
+    def GetScaleFactors(self):
+        return self._vec(self.L.orbgpu_extractor_get_scale_factors, np.float32)
+
+    def GetInverseScaleFactors(self):
+        return self._vec(self.L.orbgpu_extractor_get_inv_scale_factors, np.float32)
+
+    def GetScaleSigmaSquares(self):
+        return self._vec(self.L.orbgpu_extractor_get_sigma2, np.float32)
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._vec(self.L.orbgpu_extractor_get_inv_sigma2, np.float32)
+
+    def quotas(self):
+        return self._vec(self.L.orbgpu_extractor_get_quotas, np.int32)
+
+    def max_keypoints(self, width, height):
+        cap = C.c_int32()
+        check(self.L.orbgpu_extractor_max_keypoints(self.h, width, height, C.byref(cap)))
+        return cap.value
+
+    def __call__(self, image, mask=None):
+        """(keypoints, descriptors) of one 8-bit gray image; mask is ignored as in the reference."""
+        k, d = self.extract_batch(np.asarray(image)[None])
+        return k[0], d[0]
+
+    def extract_batch(self, images):
+        images = np.ascontiguousarray(images, np.uint8)
+        if images.ndim != 3:
+            raise ValueError("images must be [batch, h, w] uint8")
+        b, h, w = images.shape
+        if h == 0 or w == 0:
+            return [np.zeros(0, KEYPOINT_DTYPE)] * b, [np.zeros((0, 32), np.uint8)] * b
+        cap = self.max_keypoints(w, h)
+        kps = np.zeros((b, cap), KEYPOINT_DTYPE)
+        desc = np.zeros((b, cap, 32), np.uint8)
+        n = np.zeros(b, np.int32)
+        check(self.L.orbgpu_extract_batch(self.h, _p(images), b, w, h, images.strides[1], images.strides[0], _p(kps),
+                                          _p(desc), cap, _p(n)))
+        return [kps[i, :n[i]].copy() for i in range(b)], [desc[i, :n[i]].copy() for i in range(b)]
+
+    def extract_batch_device(self, d_gray_ptr, batch, width, height, stride, frame_stride, d_kps_ptr, d_desc_ptr, cap,
+                             d_nout_ptr, stream=0):
+        check(self.L.orbgpu_extract_batch_device(self.h, d_gray_ptr, batch, width, height, stride, frame_stride,
+                                                 d_kps_ptr, d_desc_ptr, cap, d_nout_ptr, stream))
+
+    def pyramid_level(self, frame, level):
+        """mvImagePyramid[level] of `frame` of the last call (ORBextractor.h:85)."""
+        w, h = C.c_int32(), C.c_int32()
+        buf = np.zeros((8192, 8192), np.uint8) if False else None
+        # query the size first with a generous scratch row
+        probe = np.zeros(1, np.uint8)
+        del probe, buf
+        raw, pitch = self.debug_read(DBG_PYRAMID_PADDED, frame, level)
+        img = raw.reshape(-1, pitch)
+        return img
+
+    def debug_read(self, what, frame, level):
+        cap = 64 << 20
+        buf = np.zeros(cap, np.uint8)
+        n = C.c_size_t()
+        aux = C.c_int32()
+        check(self.L.orbgpu_extractor_debug_read(self.h, what, frame, level, _p(buf), cap, C.byref(n), C.byref(aux)))
+        if what in (DBG_PYRAMID_PADDED, DBG_BLURRED_PADDED):
+            return buf[:n.value].copy(), aux.value
+        return buf[:n.value * 12].view(np.int32).reshape(-1, 3).copy(), 0
+
+    def set_profiling(self, on):
+        check(self.L.orbgpu_extractor_set_profiling(self.h, int(on)))
+
+    def stage_times(self):
+        n = self.L.orbgpu_extractor_stage_count()
+        ms = np.zeros(n, np.float32)
+        check(self.L.orbgpu_extractor_stage_times(self.h, _p(ms)))
+        return {self.L.orbgpu_extractor_stage_name(i).decode(): float(ms[i]) for i in range(n)}
+
+
+# --------------------------------------------------------------------------------------------
+# ORBmatcher (reference include/ORBmatcher.h:41-106)
+# --------------------------------------------------------------------------------------------
+def assign_features_to_grid(kp_x, kp_y, min_x, min_y, inv_w, inv_h):
+    kp_x = np.ascontiguousarray(kp_x, np.float32)
+    kp_y = np.ascontiguousarray(kp_y, np.float32)
+    cs = np.zeros(GRID_COLS * GRID_ROWS + 1, np.int32)
+    items = np.zeros(max(1, len(kp_x)), np.int32)
+    check(lib().orbgpu_assign_features_to_grid(len(kp_x), _p(kp_x), _p(kp_y), min_x, min_y, inv_w, inv_h, _p(cs),
+                                               _p(items)))
+    return cs, items[:cs[-1]].copy()
+
+
+class Frame:
+    """SoA view of the Frame members the matcher reads (reference include/Frame.h:100-190)."""
+
+    def __init__(self, kp_x, kp_y, octave, angle, u_right, desc, width, height, scale_factors):
+        f32 = np.float32
+        self.kp_x = np.ascontiguousarray(kp_x, f32)
+        self.kp_y = np.ascontiguousarray(kp_y, f32)
+        self.octave = np.ascontiguousarray(octave, np.int32)
+        self.angle = np.ascontiguousarray(angle, f32)
+        self.u_right = np.ascontiguousarray(u_right, f32)
+        self.desc = np.ascontiguousarray(desc, np.uint8)
+        self.n = len(self.kp_x)
+        self.min_x, self.max_x, self.min_y, self.max_y = f32(0), f32(width), f32(0), f32(height)
+        self.inv_w = f32(f32(GRID_COLS) / f32(self.max_x - self.min_x))  # Frame.cc:155
+        self.inv_h = f32(f32(GRID_ROWS) / f32(self.max_y - self.min_y))  # Frame.cc:156
+        self.scale_factors = np.ascontiguousarray(scale_factors, f32)
+        self.cell_start, self.cell_items = assign_features_to_grid(self.kp_x, self.kp_y, self.min_x, self.min_y,
+                                                                   self.inv_w, self.inv_h)
+        if len(self.cell_items) == 0:
+            self.cell_items = np.zeros(1, np.int32)
+
+    def view(self):
+        v = FrameView()
+        v.n = self.n
+        v.kp_x, v.kp_y, v.kp_octave, v.kp_angle = _p(self.kp_x), _p(self.kp_y), _p(self.octave), _p(self.angle)
+        v.u_right, v.desc = _p(self.u_right), _p(self.desc)
+        v.min_x, v.max_x, v.min_y, v.max_y = self.min_x, self.max_x, self.min_y, self.max_y
+        v.grid_inv_w, v.grid_inv_h = self.inv_w, self.inv_h
+        v.scale_factors, v.nlevels = _p(self.scale_factors), len(self.scale_factors)
+        v.cell_start, v.cell_items = _p(self.cell_start), _p(self.cell_items)
+        return v
+
+
+class ORBmatcher:
+    """Mirror of ORB_SLAM2::ORBmatcher(nnratio, checkOri) (ORBmatcher.h:41-106)."""
+
+    TH_HIGH, TH_LOW, HISTO_LENGTH = TH_HIGH, TH_LOW, HISTO_LENGTH
+
+    def __init__(self, nnratio=0.6, checkOri=True, device_id=0):
+        self.L = lib()
+        self.nnratio, self.check_ori, self.device_id = float(nnratio), bool(checkOri), device_id
+
+    @staticmethod
+    def DescriptorDistance(a, b, device_id=0):
+        """ORBmatcher::DescriptorDistance (ORBmatcher.h:44); a, b: [n,32] or [32] uint8."""
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(a), np.int32)
+        check(lib().orbgpu_hamming256(_p(a), _p(b), len(a), _p(out), device_id))
+        return out
+
+    def MatchBruteForce(self, desc_a, angle_a, desc_b, angle_b, valid_a=None, th_low=TH_LOW):
+        """SearchByBoW(KF,F) with one vocabulary node (ORBmatcher.cc:159-288)."""
+        desc_a = np.ascontiguousarray(desc_a, np.uint8).reshape(-1, 32)
+        desc_b = np.ascontiguousarray(desc_b, np.uint8).reshape(-1, 32)
+        angle_a = np.ascontiguousarray(angle_a, np.float32)
+        angle_b = np.ascontiguousarray(angle_b, np.float32)
+        va = None if valid_a is None else np.ascontiguousarray(valid_a, np.uint8)
+        out = np.zeros(max(1, len(desc_b)), np.int32)
+        n = C.c_int32()
+        check(self.L.orbgpu_match_bf(_p(desc_a), _p(angle_a), _p(va), len(desc_a), _p(desc_b), _p(angle_b), len(desc_b),
+                                     th_low, self.nnratio, int(self.check_ori), _p(out), C.byref(n), self.device_id))
+        return n.value, out[:len(desc_b)].copy()
+
+    def SearchByProjection(self, frame, mp, th, kp_to_mp):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:45-129).
+        mp: dict of arrays in_view,bad,obs_pos,level,view_cos,proj_x,proj_y,proj_xr,desc."""
+        keep = {k: np.ascontiguousarray(mp[k], dt) for k, dt in
+                (("in_view", np.uint8), ("bad", np.uint8), ("obs_pos", np.uint8), ("level", np.int32),
+                 ("view_cos", np.float32), ("proj_x", np.float32), ("proj_y", np.float32),
+                 ("proj_xr", np.float32), ("desc", np.uint8))}
+        v = MapPointView()
+        v.m = len(keep["level"])
+        for k in keep:
+            setattr(v, k, _p(keep[k]))
+        fv = frame.view()
+        out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
+        n = C.c_int32()
+        check(self.L.orbgpu_search_by_projection(C.byref(fv), C.byref(v), th, self.nnratio, _p(out), C.byref(n),
+                                                 self.device_id))
+        return n.value, out
+
+    def SearchByProjectionLast(self, cur, cur_Tcw, fx, fy, cx, cy, mbf, mb, last, th, mono, kp_to_mp):
+        """SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1328-1470)."""
+        keep = {k: np.ascontiguousarray(last[k], dt) for k, dt in
+                (("has_mp", np.uint8), ("outlier", np.uint8), ("obs_pos", np.uint8), ("world_pos", np.float32),
+                 ("desc", np.uint8), ("kp_octave", np.int32), ("kp_angle", np.float32), ("Tcw", np.float32))}
+        v = LastFrameView()
+        v.n = len(keep["kp_octave"])
+        for k in keep:
+            setattr(v, k, _p(keep[k]))
+        fv = cur.view()
+        T = np.ascontiguousarray(cur_Tcw, np.float32)
+        out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
+        n = C.c_int32()
+        check(self.L.orbgpu_search_by_projection_last(C.byref(fv), _p(T), fx, fy, cx, cy, mbf, mb, C.byref(v), th,
+                                                      int(mono), int(self.check_ori), _p(out), C.byref(n),
+                                                      self.device_id))
+        return n.value, out
+
+
+class BatchMatcher:
+    """Device-resident batched brute-force matcher (orbgpu_match_bf_batch_device)."""
+
+    def __init__(self, max_pairs, cap, device_id=0):
+        self.L = lib()
+        h = C.c_void_p()
+        check(self.L.orbgpu_matcher_create(device_id, max_pairs, cap, C.byref(h)))
+        self.h, self.max_pairs, self.cap = h, max_pairs, cap
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbgpu_matcher_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def match(self, pairs, cap, d_desc_a, d_angle_a, d_valid_a, d_na, d_desc_b, d_angle_b, d_nb, angle_stride,
+              th_low, nnratio, check_ori, d_match_b, d_nmatches, stream=0):
+        check(self.L.orbgpu_match_bf_batch_device(self.h, pairs, cap, d_desc_a, d_angle_a, d_valid_a, d_na, d_desc_b,
+                                                  d_angle_b, d_nb, angle_stride, th_low, nnratio, int(check_ori),
+                                                  d_match_b, d_nmatches, stream))
+
+    def last_sweeps(self, pairs):
+        out = np.zeros(pairs, np.int32)
+        check(self.L.orbgpu_matcher_last_sweeps(self.h, _p(out)))
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# PointCloudMapping (reference include/PointCloudMap.h:41-88)
+# --------------------------------------------------------------------------------------------
+class PointCloudMapping:
+    """Arithmetic of ORB_SLAM2::PointCloudMapping: insertKeyFrame -> back-project, transform,
+    append, voxel-filter the global map (PointCloudMap.cc:204-262). Thread/condvar protocol and
+    viewer stay on the host side of the C++ shim."""
+
+    def __init__(self, resolution, device_id=0):
+        self.L = lib()
+        h = C.c_void_p()
+        check(self.L.orbgpu_cloud_create(float(resolution), device_id, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.orbgpu_cloud_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def insertKeyFrame(self, depth, rgb, fx, fy, cx, cy, Tcw):
+        depth = np.ascontiguousarray(depth, np.float32)
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        T = np.ascontiguousarray(Tcw, np.float32)
+        h, w = depth.shape
+        check(self.L.orbgpu_cloud_insert(self.h, _p(depth), depth.strides[0] // 4, _p(rgb), rgb.strides[0], w, h, fx, fy,
+                                         cx, cy, _p(T)))
+
+    def rebuild(self, depths, rgbs, fx, fy, cx, cy, Tcws):
+        depths = [np.ascontiguousarray(d, np.float32) for d in depths]
+        rgbs = [np.ascontiguousarray(r, np.uint8) for r in rgbs]
+        Ts = [np.ascontiguousarray(t, np.float32) for t in Tcws]
+        n = len(depths)
+        h, w = depths[0].shape
+        dp = (C.c_void_p * n)(*[d.ctypes.data for d in depths])
+        rp = (C.c_void_p * n)(*[r.ctypes.data for r in rgbs])
+        tp = (C.c_void_p * n)(*[t.ctypes.data for t in Ts])
+        check(self.L.orbgpu_cloud_rebuild(self.h, n, dp, depths[0].strides[0] // 4, rp, rgbs[0].strides[0], w, h, fx, fy,
+                                          cx, cy, tp))
+
+    def size(self):
+        n = C.c_int64()
+        check(self.L.orbgpu_cloud_size(self.h, C.byref(n)))
+        return n.value
+
+    def download(self):
+        n = self.size()
+        out = np.zeros(max(1, n), POINT_DTYPE)
+        got = C.c_int64()
+        check(self.L.orbgpu_cloud_download(self.h, _p(out), max(1, n), C.byref(got)))
+        return out[:got.value].copy()
+
+    def last_overflow(self):
+        o = C.c_int32()
+        check(self.L.orbgpu_cloud_last_overflow(self.h, C.byref(o)))
+        return bool(o.value)
+
+
+def backproject(depth, rgb, fx, fy, cx, cy, Tcw=None, device_id=0):
+    depth = np.ascontiguousarray(depth, np.float32)
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w = depth.shape
+    cap = ((h + 2) // 3) * ((w + 2) // 3)
+    out = np.zeros(max(1, cap), POINT_DTYPE)
+    n = C.c_int64()
+    T = None if Tcw is None else np.ascontiguousarray(Tcw, np.float32)
+    check(lib().orbgpu_backproject(_p(depth), depth.strides[0] // 4, _p(rgb), rgb.strides[0], w, h, fx, fy, cx, cy,
+                                   _p(T), _p(out), max(1, cap), C.byref(n), device_id))
+    return out[:n.value].copy()
+
+
+def voxel_filter(points, resolution, device_id=0):
+    points = np.ascontiguousarray(points, POINT_DTYPE)
+    out = np.zeros(max(1, len(points)), POINT_DTYPE)
+    n = C.c_int64()
+    ov = C.c_int32()
+    check(lib().orbgpu_voxel_filter(_p(points), len(points), float(resolution), _p(out), max(1, len(points)),
+                                    C.byref(n), C.byref(ov), device_id))
+    return out[:n.value].copy(), bool(ov.value)
