@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of ORB extract + brute-force Hamming match (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N=1 directly)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+
+A *step* = one batch of `--batch` synthetic 640x480 frames already resident in HBM: 8-level ORB
+extraction at 1000 features (pyramid, per-cell FAST, quadtree, orientation, blur, rBRIEF) followed by
+`batch` brute-force matches of consecutive frames (frame b vs b-1; the first against the last frame
+of the previous step).  Everything runs through the C ABI of liborbgpu.so on the calling stream;
+torch only owns device memory, the stream and (N>1) the RCCL process group.
+
+Multi-GPU: frames shard by sequence, one independent sequence per rank, no data-path collective
+ -> "weak" scaling; RCCL carries only the barrier and the max-time / frame-count
+reductions.
+
+Besides the contract's JSON line the script reports
+  roofline     -- the dominant kernel (longest average duration, HIP events on the launch stream,
+                  recorded by the library around every stage of every timed step) priced against
+                  the 8 TB/s HBM peak with SURVEY.md 8d's algorithmic bytes;
+  cpu_baseline -- the CPU oracle ("port" of the reference algorithm) timed on this host, rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# SURVEY.md 8d algorithmic bytes per 640x480 / 1000-feature frame
+PYR_PX = [307200, 213200, 147852, 102860, 71379, 49601, 34454, 23986]
+
+
+def algorithmic_bytes(stage, n_kp, n_cand):
+    tot = sum(PYR_PX)
+    if stage == "pyramid":
+        return sum(PYR_PX[:-1]) + sum(PYR_PX[1:])  # R levels 0..6 + W levels 1..7 = 1 569 878 B
+    if stage == "fast":
+        return tot  # every level read once; outputs negligible
+    if stage == "blur":
+        return 2 * tot
+    if stage == "orient":
+        return n_kp * (749 + 28 + 16)  # disc gather + key point + aux record
+    if stage == "describe":
+        return n_kp * (512 + 32)
+    if stage == "quadtree":
+        return 4 * n_cand * 2 + 4 * n_kp  # candidate keys compacted (R+W) + selected keys
+    raise KeyError(stage)
+
+
+def cpu_baseline(frames, seconds_budget=18.0):
+    """Oracle (kind 'port'): extract + BF match of consecutive frames, single thread."""
+    from oracle import oracle_py as O
+    libpath = None
+    try:  # -march=native build on THIS host's CPU; falls back to the portable build
+        tmp = os.path.join(tempfile.gettempdir(), "liborb_oracle_native_%d.so" % os.getpid())
+        O.build(out=tmp, extra_cflags="-O3 -march=native -fPIC -std=c11 -ffp-contract=off -fno-fast-math")
+        libpath = tmp
+    except Exception:
+        O.build()
+    e = O.Extractor(1000, libpath=libpath)
+    L = O.lib(libpath)
+    t0 = time.perf_counter()
+    n = 0
+    prev = None
+    import ctypes as C
+    for img in frames:
+        k, d = e.extract(img)
+        if prev is not None:
+            pk, pd = prev
+            out = np.zeros(max(1, len(d)), np.int32)
+            L.ora_match_bf(pd.ctypes.data_as(C.c_void_p), np.ascontiguousarray(pk["angle"]).ctypes.data_as(C.c_void_p),
+                           None, len(pd), d.ctypes.data_as(C.c_void_p),
+                           np.ascontiguousarray(k["angle"]).ctypes.data_as(C.c_void_p), len(d), 50, 0.7, 1,
+                           out.ctypes.data_as(C.c_void_p))
+        prev = (k, d)
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic 640x480 frames, 1000 features, extract + BF match vs previous frame, "
+                      "oracle built -O3 -march=native -ffp-contract=off, host has %d cores" % (n, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step and per GPU")
+    ap.add_argument("--pool", type=int, default=1024, help="distinct resident frames cycled through (> Infinity Cache)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from orb_slam2_map_amd import lib as G
+    from orb_slam2_map_amd.synth import Stream
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    G.lib()  # fail loudly if the HIP extension is missing
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU visible: bench.py measures the HIP path only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    W, H, NFEAT = 640, 480, 1000
+    B, POOL = args.batch, max(args.pool, args.batch)
+    POOL = (POOL // B) * B
+    # one independent sequence per rank
+    st = Stream(W, H, 1234 + 1000 * rank)
+    host_pool = np.stack([st.frame(t)[0] for t in range(POOL)])
+    frames = torch.from_numpy(host_pool).cuda(local_rank)
+
+    ext = G.ORBextractor(NFEAT, max_batch=B, device_id=local_rank)
+    cap = ext.max_keypoints(W, H)
+    kps = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B + 1, dtype=torch.int32, device="cuda")
+    matcher = G.BatchMatcher(B, cap, device_id=local_rank)
+    match_b = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    nmatch = torch.zeros(B, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    KP, DS = cap * 28, cap * 32
+
+    def step(i):
+        src = frames[(i * B) % POOL:(i * B) % POOL + B]
+        # slot 0 carries the previous step's last frame; this step's frames go to slots 1..B
+        ext.extract_batch_device(src.data_ptr(), B, W, H, W, W * H, kps.data_ptr() + KP, desc.data_ptr() + DS, cap,
+                                 nout.data_ptr() + 4, stream)
+        matcher.match(B, cap, desc.data_ptr(), kps.data_ptr() + 12, None, nout.data_ptr(), desc.data_ptr() + DS,
+                      kps.data_ptr() + KP + 12, nout.data_ptr() + 4, 28, 50, 0.7, True, match_b.data_ptr(),
+                      nmatch.data_ptr(), stream)
+        kps[0].copy_(kps[B], non_blocking=True)
+        desc[0].copy_(desc[B], non_blocking=True)
+        nout[0:1].copy_(nout[B:B + 1], non_blocking=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ext.set_profiling(True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    stage_ms = ext.stage_times()
+    ext.set_profiling(False)
+    match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    nfr = torch.tensor([float(B * args.steps)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nfr, op=dist.ReduceOp.SUM)
+    elapsed_max, total_frames = float(t.item()), float(nfr.item())
+
+    # sanity of the measured work (rank-local): every frame produced key points and matches
+    n_host = nout.cpu().numpy()
+    nm_host = nmatch.cpu().numpy()
+    sweeps = matcher.last_sweeps(B)
+    assert n_host[1:].min() > 0 and nm_host.min() >= 0, "benchmark produced empty frames"
+    n_kp = float(n_host[1:].mean())
+
+    if rank == 0:
+        # dominant kernel of the extraction pipeline + its roofline fraction
+        n_cand = 13700.0  # typical FAST survivors per synthetic frame (tests/golden); used for the quadtree row only
+        dom = max(stage_ms, key=lambda k: stage_ms[k])
+        ach = algorithmic_bytes(dom, n_kp, n_cand) * B / (stage_ms[dom] * 1e-3) / 1e9
+        per_stage = {k: {"ms": round(v, 4),
+                         "GB/s": round(algorithmic_bytes(k, n_kp, n_cand) * B / (max(v, 1e-6) * 1e-3) / 1e9, 1)}
+                     for k, v in stage_ms.items()}
+        out = {
+            "metric": "frames/sec ORB extract+match (640x480, 1000 feat)",
+            "value": total_frames / elapsed_max,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "C2: synthetic 640x480 RGB-D stream, 1000 features, 8 levels, extract + BF-Hamming "
+                                   "match of consecutive frames", "frames_per_step_per_gpu": B,
+                       "resident_frame_pool": POOL, "sequences": world, "parallelism": "1 sequence per GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "ms_per_launch": stage_ms[dom], "frames_per_launch": B},
+            "stages": per_stage,
+            "match_ms_per_step": round(match_ms, 4),
+            "keypoints_per_frame": n_kp,
+            "matches_per_frame": float(nm_host.mean()),
+            "bf_sweeps_max": int(sweeps.max()),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline([host_pool[i] for i in range(min(POOL, 400))])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

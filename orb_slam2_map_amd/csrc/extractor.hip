@@ -938,9 +938,11 @@ struct orbgpu_extractor {
     DevBuf d_dbg;
     hipStream_t stream = nullptr;
     int last_batch = 0, last_cap = 0;
+    // profiling: one event set per profiled call (up to PROF_SLOTS), averaged by stage_times()
+    static constexpr int PROF_SLOTS = 256;
     bool profiling = false;
-    hipEvent_t ev[ST_COUNT + 1] = {};
-    bool ev_valid = false;
+    std::vector<hipEvent_t> ev;  // PROF_SLOTS * (ST_COUNT + 1), created lazily
+    int prof_calls = 0;
 };
 
 namespace orbgpu {
@@ -1180,11 +1182,14 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     int rc = e->d_aux.reserve(sizeof(KpAux) * (size_t)cap * batch);
     if (rc != ORBGPU_OK)
         return rc;
-    const bool prof = e->profiling;
-    if (prof && !e->ev[0])
-        for (int i = 0; i <= ST_COUNT; i++)
-            ORBGPU_HIP_TRY(hipEventCreate(&e->ev[i]));
-#define MARK(i) if (prof) ORBGPU_HIP_TRY(hipEventRecord(e->ev[i], st))
+    const bool prof = e->profiling && e->prof_calls < orbgpu_extractor::PROF_SLOTS;
+    if (prof && e->ev.empty()) {
+        e->ev.resize((size_t)orbgpu_extractor::PROF_SLOTS * (ST_COUNT + 1), nullptr);
+        for (auto &x : e->ev)
+            ORBGPU_HIP_TRY(hipEventCreate(&x));
+    }
+    hipEvent_t *evs = prof ? &e->ev[(size_t)e->prof_calls * (ST_COUNT + 1)] : nullptr;
+#define MARK(i) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[i], st))
     MARK(0);
     {
         const LevelGeom &g = e->geom[0];
@@ -1219,7 +1224,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     MARK(6);
 #undef MARK
     ORBGPU_HIP_TRY(hipGetLastError());
-    e->ev_valid = prof;
+    if (prof)
+        e->prof_calls++;
     e->last_batch = batch;
     e->last_cap = cap;
     (void)w;
@@ -1276,9 +1282,9 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
                       &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
     for (DevBuf *b : bufs)
         b->release();
-    for (int i = 0; i <= ST_COUNT; i++)
-        if (e->ev[i])
-            (void)hipEventDestroy(e->ev[i]);
+    for (auto &x : e->ev)
+        if (x)
+            (void)hipEventDestroy(x);
     if (e->stream)
         (void)hipStreamDestroy(e->stream);
     delete e;
@@ -1474,6 +1480,7 @@ int orbgpu_extractor_set_profiling(orbgpu_extractor *e, int32_t enable)
 {
     ORBGPU_REQUIRE(e, "null argument");
     e->profiling = enable != 0;
+    e->prof_calls = 0;
     return ORBGPU_OK;
 }
 int orbgpu_extractor_stage_count(void) { return ST_COUNT; }
@@ -1481,10 +1488,24 @@ const char *orbgpu_extractor_stage_name(int32_t i) { return (i >= 0 && i < ST_CO
 int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms)
 {
     ORBGPU_REQUIRE(e && ms, "null argument");
-    ORBGPU_REQUIRE(e->ev_valid, "no profiled call recorded");
-    ORBGPU_HIP_TRY(hipEventSynchronize(e->ev[ST_COUNT]));
+    ORBGPU_REQUIRE(e->prof_calls > 0, "no profiled call recorded");
+    int rc = select_device(e->prm.device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
     for (int i = 0; i < ST_COUNT; i++)
-        ORBGPU_HIP_TRY(hipEventElapsedTime(&ms[i], e->ev[i], e->ev[i + 1]));
+        ms[i] = 0.f;
+    for (int c = 0; c < e->prof_calls; c++) {
+        hipEvent_t *evs = &e->ev[(size_t)c * (ST_COUNT + 1)];
+        ORBGPU_HIP_TRY(hipEventSynchronize(evs[ST_COUNT]));
+        for (int i = 0; i < ST_COUNT; i++) {
+            float t = 0.f;
+            ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
+            ms[i] += t;
+        }
+    }
+    for (int i = 0; i < ST_COUNT; i++)
+        ms[i] /= (float)e->prof_calls;
+    e->prof_calls = 0;  // start a new averaging window
     return ORBGPU_OK;
 }
 

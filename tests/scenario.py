@@ -1,0 +1,73 @@
+"""Synthetic tracking scenarios for the projection matchers (test-side helper; uses the oracle).
+
+World frame == camera frame of the *current* frame pushed through a rigid transform Tcw, so that
+map points created from the previous frame's key points project onto the image content they came
+from (the synthetic stream is a translating window of one canvas, see orb_slam2_map_amd/synth.py).
+"""
+import numpy as np
+
+
+def rigid(rx=0.01, ry=-0.02, rz=0.015, t=(0.03, -0.02, 0.05)):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = t
+    return T.astype(np.float32)
+
+
+def make_frame(mod, kps, desc, depth, stream, scale_factors):
+    """Frame SoA (mvKeysUn == mvKeys: zero distortion) with mvuRight from ComputeStereoFromRGBD."""
+    from oracle import oracle_py as O
+    ur, _ = O.compute_stereo_from_rgbd(kps["x"], kps["y"], kps["x"], depth, float(stream.bf))
+    return mod.Frame(kps["x"], kps["y"], kps["octave"], kps["angle"], ur, desc, stream.w, stream.h, scale_factors)
+
+
+def world_points_from_prev(kps_prev, depth_prev, shift, stream, Tcw, rng, jitter=0.6):
+    """3-D points (world) for the previous frame's key points so that they land, in the current
+    frame, at their old pixel minus the window shift (+ jitter)."""
+    fx, fy, cx, cy = float(stream.fx), float(stream.fy), float(stream.cx), float(stream.cy)
+    u = kps_prev["x"].astype(np.float64) - shift[0] + rng.normal(0, jitter, len(kps_prev))
+    v = kps_prev["y"].astype(np.float64) - shift[1] + rng.normal(0, jitter, len(kps_prev))
+    d = depth_prev[kps_prev["y"].astype(np.int64), kps_prev["x"].astype(np.int64)].astype(np.float64)
+    has_depth = d > 0
+    d = np.where(has_depth, d, 2.0)
+    Pc = np.stack([(u - cx) * d / fx, (v - cy) * d / fy, d], 1)
+    T = Tcw.astype(np.float64)
+    Pw = (Pc - T[:3, 3]) @ T[:3, :3]  # R^T (Pc - t)
+    return Pw.astype(np.float32), has_depth
+
+
+def local_map(O, stream, Tcw, world_pos, desc, octave, scale_factors, rng, obs_zero_frac=0.0):
+    """Pre-fills the MapPoint tracking scratch exactly as Frame::isInFrustum does (oracle)."""
+    m = len(world_pos)
+    sf = np.asarray(scale_factors, np.float32)
+    log_sf = float(np.log(np.float32(sf[1])))
+    T = Tcw.astype(np.float64)
+    Ow = -T[:3, :3].T @ T[:3, 3]
+    out = {k: np.zeros(m, dt) for k, dt in (("in_view", np.uint8), ("bad", np.uint8), ("obs_pos", np.uint8),
+                                            ("level", np.int32), ("view_cos", np.float32), ("proj_x", np.float32),
+                                            ("proj_y", np.float32), ("proj_xr", np.float32))}
+    out["desc"] = np.ascontiguousarray(desc, np.uint8)
+    out["obs_pos"][:] = (rng.random(m) >= obs_zero_frac).astype(np.uint8)
+    out["bad"][:] = (rng.random(m) < 0.02).astype(np.uint8)
+    for i in range(m):
+        P = world_pos[i].astype(np.float64)
+        dist = float(np.linalg.norm(P - Ow))
+        normal = (Ow - P) / max(dist, 1e-9)
+        normal = -normal  # PO.dot(Pn) must be positive: Pn points from the camera to the point side
+        # scale-invariance distances as MapPoint::UpdateNormalAndDepth would set them (MapPoint.cc:352-371)
+        lvl = int(octave[i])
+        max_d = np.float32(dist * sf[lvl])
+        min_d = np.float32(max_d / sf[-1])
+        ok, px, py, pxr, level, vc = O.is_in_frustum(Tcw, float(stream.fx), float(stream.fy), float(stream.cx),
+                                                     float(stream.cy), float(stream.bf), stream.w, stream.h,
+                                                     world_pos[i], normal.astype(np.float32), float(min_d),
+                                                     float(max_d), log_sf)
+        if ok and 0 <= level < len(sf):
+            out["in_view"][i] = 1
+            out["proj_x"][i], out["proj_y"][i], out["proj_xr"][i] = px, py, pxr
+            out["level"][i], out["view_cos"][i] = level, vc
+    return out

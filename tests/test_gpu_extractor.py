@@ -1,0 +1,217 @@
+"""GPU parity: ORBextractor path (HIP, through the C ABI) vs the CPU oracle. Bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import corners_to_array
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
+
+
+def assert_same_keypoints(gk, gd, ok, od, what):
+    assert len(gk) == len(ok), "%s: key point count %d != oracle %d" % (what, len(gk), len(ok))
+    for f in FIELDS:
+        a = np.ascontiguousarray(gk[f]).view(np.uint32)
+        b = np.ascontiguousarray(ok[f]).view(np.uint32)
+        bad = np.nonzero(a != b)[0]
+        assert len(bad) == 0, "%s: field %s differs at %d rows, first %d: gpu %r oracle %r" % (
+            what, f, len(bad), bad[0], gk[f][bad[0]], ok[f][bad[0]])
+    assert gd.shape == od.shape and np.array_equal(gd, od), "%s: descriptor bits differ in %d rows" % (
+        what, int((gd != od).any(1).sum()))
+
+
+def check_stages(gpu, ge, oe, frame, nlevels, what):
+    """Pyramid bytes, blurred bytes, FAST candidates and quadtree selection, level by level."""
+    for l in range(nlevels):
+        raw, pitch = ge.debug_read(gpu.DBG_PYRAMID_PADDED, frame, l)
+        op = oe.pyramid_level(l)
+        hh, ww = op.shape
+        gp = raw.reshape(-1, pitch)[:hh, :ww]
+        assert np.array_equal(gp, op), "%s L%d: padded pyramid differs at %d px" % (what, l, int((gp != op).sum()))
+        ob = oe.blurred_level(l)
+        if ob is not None:
+            braw, _ = ge.debug_read(gpu.DBG_BLURRED_PADDED, frame, l)
+            gb = braw.reshape(-1, pitch)[19:hh - 19, 19:ww - 19]
+            assert np.array_equal(gb, ob), "%s L%d: blurred level differs at %d px" % (what, l, int((gb != ob).sum()))
+        gc, _ = ge.debug_read(gpu.DBG_CANDIDATES, frame, l)
+        oc = corners_to_array(oe.level_candidates(l))
+        assert gc.shape == oc.shape and np.array_equal(gc, oc), "%s L%d: FAST candidates differ (%d vs %d)" % (
+            what, l, len(gc), len(oc))
+        gs, _ = ge.debug_read(gpu.DBG_SELECTED, frame, l)
+        os_ = corners_to_array(oe.level_selected(l))
+        assert gs.shape == os_.shape and np.array_equal(gs, os_), "%s L%d: quadtree selection differs (%d vs %d)" % (
+            what, l, len(gs), len(os_))
+
+
+@pytest.mark.parametrize("w,h,nfeat,batch", [(640, 480, 1000, 3), (1280, 960, 2000, 2)])
+def test_extract_matches_oracle_stage_by_stage(gpu, oracle, w, h, nfeat, batch):
+    """C2 / C3 configurations (BASELINE.json configs[1], configs[2]) on the seeded synthetic stream."""
+    from orb_slam2_map_amd.synth import Stream
+    st = Stream(w, h, 1234)
+    imgs = st.gray_batch(0, batch)
+    ge = gpu.ORBextractor(nfeat, max_batch=batch)
+    oe = oracle.Extractor(nfeat)
+    gk, gd = ge.extract_batch(imgs)
+    for f in range(batch):
+        ok, od = oe.extract(imgs[f])
+        check_stages(gpu, ge, oe, f, 8, "%dx%d frame %d" % (w, h, f))
+        assert_same_keypoints(gk[f], gd[f], ok, od, "%dx%d frame %d" % (w, h, f))
+        assert len(gk[f]) <= ge.max_keypoints(w, h)
+
+
+def test_getters_match_oracle(gpu, oracle):
+    for nfeat, sf, nl in ((1000, 1.2, 8), (2000, 1.2, 8), (500, 1.5, 5), (1500, 1.1, 12)):
+        ge = gpu.ORBextractor(nfeat, sf, nl)
+        oe = oracle.Extractor(nfeat, sf, nl)
+        assert ge.GetLevels() == nl
+        assert np.float32(ge.GetScaleFactor()) == np.float32(sf)
+        assert np.array_equal(ge.GetScaleFactors(), oe.scale_factors())
+        assert np.array_equal(ge.GetInverseScaleFactors(), oe.inv_scale_factors())
+        assert np.array_equal(ge.GetScaleSigmaSquares(), oe.sigma2())
+        assert np.array_equal(ge.GetInverseScaleSigmaSquares(), oe.inv_sigma2())
+        assert np.array_equal(ge.quotas(), oe.quotas())
+
+
+@pytest.mark.parametrize("w,h", [(333, 251), (752, 480), (1241, 376), (320, 240)])
+def test_ragged_sizes(gpu, oracle, w, h):
+    """Sizes that are not multiples of anything (EuRoC 752x480, KITTI 1241x376, odd)."""
+    from orb_slam2_map_amd.synth import Stream
+    st = Stream(w, h, 77)
+    img = st.frame(3)[0]
+    ge = gpu.ORBextractor(1000)
+    oe = oracle.Extractor(1000)
+    gk, gd = ge(img)
+    ok, od = oe.extract(img)
+    check_stages(gpu, ge, oe, 0, 8, "%dx%d" % (w, h))
+    assert_same_keypoints(gk, gd, ok, od, "%dx%d" % (w, h))
+
+
+def test_strided_input_and_single_call(gpu, oracle, stream640):
+    """operator() on a cv::Mat ROI: row stride larger than the width."""
+    big = np.zeros((480, 700), np.uint8)
+    img = stream640.frame(5)[0]
+    big[:, :640] = img
+    view = big[:, :640]
+    import ctypes as C
+    ge = gpu.ORBextractor(1000)
+    cap = ge.max_keypoints(640, 480)
+    kps = np.zeros(cap, gpu.KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int32()
+    gpu.check(ge.L.orbgpu_extract(ge.h, view.ctypes.data_as(C.c_void_p), 640, 480, view.strides[0],
+                                  kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+    ok, od = oracle.Extractor(1000).extract(img)
+    assert_same_keypoints(kps[:n.value], desc[:n.value], ok, od, "strided")
+
+
+def test_low_texture_threshold_fallback(gpu, oracle):
+    """Smooth image with faint structure: most cells fall back to minThFAST (ORBextractor.cc:812-816),
+    fewer candidates than the quota, so the quadtree ends with singleton nodes."""
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:480, 0:640]
+    img = 120 + 20 * np.sin(xx / 37.0) + 15 * np.cos(yy / 23.0)
+    for _ in range(60):
+        cx, cy = rng.integers(30, 610), rng.integers(30, 450)
+        img[cy:cy + 9, cx:cx + 9] += rng.integers(9, 16)
+    img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    ge = gpu.ORBextractor(1000)
+    oe = oracle.Extractor(1000)
+    gk, gd = ge(img)
+    ok, od = oe.extract(img)
+    assert 0 < len(ok) < 900
+    check_stages(gpu, ge, oe, 0, 8, "low texture")
+    assert_same_keypoints(gk, gd, ok, od, "low texture")
+
+
+def test_constant_and_empty_images(gpu, oracle):
+    ge = gpu.ORBextractor(1000)
+    gk, gd = ge(np.full((480, 640), 128, np.uint8))
+    assert len(gk) == 0 and gd.shape == (0, 32)
+    gk, gd = ge(np.zeros((0, 0), np.uint8))  # ORBextractor.cc:1046: empty image -> no output
+    assert len(gk) == 0
+
+
+def test_dense_corners_high_candidate_count(gpu, oracle):
+    """Checkerboard + noise: far more candidates than the quota in every cell."""
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:480, 0:640]
+    img = ((xx // 6 + yy // 6) % 2) * 120 + 60 + rng.integers(-8, 9, (480, 640))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    ge = gpu.ORBextractor(1000)
+    oe = oracle.Extractor(1000)
+    gk, gd = ge(img)
+    ok, od = oe.extract(img)
+    check_stages(gpu, ge, oe, 0, 8, "checkerboard")
+    assert_same_keypoints(gk, gd, ok, od, "checkerboard")
+
+
+def test_too_small_image_is_rejected(gpu):
+    ge = gpu.ORBextractor(1000)
+    with pytest.raises(gpu.OrbGpuError) as ei:
+        ge(np.zeros((120, 160), np.uint8))
+    assert ei.value.status == gpu.EINVAL
+
+
+def test_capacity_error(gpu, stream640):
+    import ctypes as C
+    ge = gpu.ORBextractor(1000)
+    img = stream640.frame(0)[0]
+    kps = np.zeros(100, gpu.KEYPOINT_DTYPE)
+    desc = np.zeros((100, 32), np.uint8)
+    n = C.c_int32()
+    rc = ge.L.orbgpu_extract(ge.h, img.ctypes.data_as(C.c_void_p), 640, 480, 640, kps.ctypes.data_as(C.c_void_p),
+                             desc.ctypes.data_as(C.c_void_p), 100, C.byref(n))
+    assert rc == gpu.ECAPACITY
+
+
+def test_golden_fixture_on_gpu(gpu):
+    """Committed golden vectors (tests/golden, produced by the oracle) replayed on the GPU."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "extract_640x480_seed1234_f0.npz"))
+    from orb_slam2_map_amd.synth import Stream
+    img = Stream(640, 480, 1234).frame(0)[0]
+    gk, gd = gpu.ORBextractor(1000)(img)
+    assert len(gk) == len(g["x"])
+    for f in FIELDS:
+        assert np.array_equal(np.ascontiguousarray(gk[f]).view(np.uint32), g[f].view(np.uint32)), f
+    assert np.array_equal(gd, g["desc"])
+
+
+def test_batch_equals_single_and_is_deterministic(gpu, stream640):
+    """Size-independent properties at the bench batch size: batched == per-frame, run twice == same."""
+    imgs = stream640.gray_batch(10, 16)
+    ge = gpu.ORBextractor(1000, max_batch=16)
+    k1, d1 = ge.extract_batch(imgs)
+    k2, d2 = ge.extract_batch(imgs)
+    single = gpu.ORBextractor(1000)
+    for f in range(16):
+        assert np.array_equal(k1[f], k2[f]) and np.array_equal(d1[f], d2[f])
+    for f in (0, 7, 15):
+        ks, ds = single(imgs[f])
+        assert np.array_equal(ks, k1[f]) and np.array_equal(ds, d1[f])
+    # structural invariants of the reference's output (E3', E4, E8)
+    for f in range(16):
+        k = k1[f]
+        assert 900 <= len(k) <= ge.max_keypoints(640, 480)
+        assert np.all(np.diff(k["octave"]) >= 0), "levels are concatenated in order"
+        assert np.all((k["angle"] >= 0) & (k["angle"] < 360))
+        assert set(np.unique(k["size"])) <= {31, 37, 44, 53, 64, 77, 92, 111}
+
+
+def test_pyramid_getter(gpu, oracle, stream640):
+    import ctypes as C
+    img = stream640.frame(2)[0]
+    ge = gpu.ORBextractor(1000)
+    ge(img)
+    oe = oracle.Extractor(1000)
+    oe.extract(img)
+    for l in (0, 3, 7):
+        op = oe.pyramid_level(l)
+        hh, ww = op.shape[0] - 38, op.shape[1] - 38
+        dst = np.zeros((hh, ww), np.uint8)
+        w_, h_ = C.c_int32(), C.c_int32()
+        gpu.check(ge.L.orbgpu_extractor_get_pyramid_level(ge.h, 0, l, dst.ctypes.data_as(C.c_void_p), ww, C.byref(w_),
+                                                          C.byref(h_)))
+        assert (w_.value, h_.value) == (ww, hh)
+        assert np.array_equal(dst, op[19:19 + hh, 19:19 + ww])

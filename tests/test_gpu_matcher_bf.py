@@ -1,0 +1,134 @@
+"""GPU parity: Hamming distance and the brute-force matcher vs the oracle. Bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def low_entropy(rng, n, pool, flip=0.02):
+    base = pool[rng.integers(0, len(pool), n)].copy()
+    noise = (rng.random((n, 32)) < flip).astype(np.uint8) << rng.integers(0, 8, (n, 32)).astype(np.uint8)
+    return base ^ noise
+
+
+def test_hamming_vs_popcount(gpu):
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (4096, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (4096, 32), dtype=np.uint8)
+    a[:3] = 0
+    b[:3] = (0, 255, 1)
+    b[1] = 255
+    ref = np.unpackbits(a ^ b, axis=1).sum(1)
+    out = gpu.ORBmatcher.DescriptorDistance(a, b)
+    assert np.array_equal(out, ref)
+    assert out[1] == 256
+
+
+def test_bf_on_extracted_frames(gpu, oracle, stream640):
+    """C2: consecutive synthetic frames, extract on the GPU, match on GPU vs oracle."""
+    ge = gpu.ORBextractor(1000, max_batch=4)
+    imgs = stream640.gray_batch(0, 4)
+    k, d = ge.extract_batch(imgs)
+    for ratio, ori in ((0.7, True), (0.9, True), (0.6, False)):
+        m = gpu.ORBmatcher(ratio, ori)
+        for f in range(3):
+            ng, mg = m.MatchBruteForce(d[f], k[f]["angle"], d[f + 1], k[f + 1]["angle"])
+            no, mo = oracle.match_bf(d[f], k[f]["angle"], d[f + 1], k[f + 1]["angle"], nnratio=ratio,
+                                     check_orientation=ori)
+            assert ng == no and np.array_equal(mg, mo), "ratio %.1f ori %s frame %d" % (ratio, ori, f)
+            assert ng > 100, "the synthetic stream must produce real matches"
+
+
+@pytest.mark.parametrize("seed,na,nb,ratio,th", [(5, 900, 1000, 0.6, 50), (6, 1000, 900, 0.9, 50),
+                                                (7, 1016, 1016, 1.5, 80), (8, 50, 2000, 2.0, 256),
+                                                (9, 2016, 2016, 1.2, 100)])
+def test_bf_conflict_stress(gpu, oracle, seed, na, nb, ratio, th):
+    """Few distinct descriptors -> many A rows compete for the same B row, so the greedy claim
+    order (ORBmatcher.cc:209-210,232) decides the result; the sweeps must reach the same fixpoint."""
+    rng = np.random.default_rng(seed)
+    pool = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    a, b = low_entropy(rng, na, pool), low_entropy(rng, nb, pool)
+    aa = (rng.random(na) * 360).astype(np.float32)
+    ab = (rng.random(nb) * 360).astype(np.float32)
+    valid = (rng.random(na) > 0.1).astype(np.uint8)
+    m = gpu.ORBmatcher(ratio, True)
+    ng, mg = m.MatchBruteForce(a, aa, b, ab, valid_a=valid, th_low=th)
+    no, mo = oracle.match_bf(a, aa, b, ab, valid_a=valid, th_low=th, nnratio=ratio)
+    assert ng == no and np.array_equal(mg, mo)
+
+
+def test_bf_adversarial_chain(gpu, oracle):
+    """A chain of dependent claims: A row i prefers B row i-1 unless it is taken -> needs ~n sweeps,
+    exercising the serial fallback path."""
+    n = 120
+    rng = np.random.default_rng(2)
+    b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    a = np.zeros((n, 32), np.uint8)
+    a[0] = b[0]
+    for i in range(1, n):
+        # equidistant (1 bit each) to b[i-1] and b[i]... tie -> lower index wins, so row i takes b[i-1]
+        # only if it is free; build descriptor half-way between the two
+        a[i] = b[i - 1]
+        diff = np.unpackbits(b[i - 1] ^ b[i])
+        idx = np.nonzero(diff)[0]
+        half = idx[: len(idx) // 2]
+        bits = np.unpackbits(a[i])
+        bits[half] ^= 1
+        a[i] = np.packbits(bits)
+    ang = np.zeros(n, np.float32)
+    m = gpu.ORBmatcher(10.0, False)
+    ng, mg = m.MatchBruteForce(a, ang, b, ang, th_low=256)
+    no, mo = oracle.match_bf(a, ang, b, ang, th_low=256, nnratio=10.0, check_orientation=False)
+    assert ng == no and np.array_equal(mg, mo)
+
+
+def test_bf_edge_cases(gpu, oracle):
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 256, (10, 32), dtype=np.uint8)
+    ang = np.zeros(10, np.float32)
+    m = gpu.ORBmatcher(0.7, True)
+    n, mb = m.MatchBruteForce(a[:0], ang[:0], a, ang)
+    assert n == 0 and np.all(mb == -1)
+    n, mb = m.MatchBruteForce(a, ang, a[:0], ang[:0])
+    assert n == 0 and len(mb) == 0
+    # identical sets: every row matches itself (distance 0 < ratio * second)
+    n, mb = m.MatchBruteForce(a, ang, a, ang)
+    no, mo = oracle.match_bf(a, ang, a, ang, nnratio=0.7)
+    assert n == no == 10 and np.array_equal(mb, mo) and np.array_equal(mb, np.arange(10))
+    # single B row: second distance stays 256
+    n, mb = m.MatchBruteForce(a, ang, a[:1], ang[:1])
+    no, mo = oracle.match_bf(a, ang, a[:1], ang[:1], nnratio=0.7)
+    assert n == no and np.array_equal(mb, mo)
+
+
+def test_bf_batched_device_path(gpu, oracle, stream640):
+    """The device-resident batched entry point the benchmark times (pairs of consecutive frames)."""
+    torch = pytest.importorskip("torch")
+    B = 6
+    imgs = torch.from_numpy(stream640.gray_batch(20, B)).cuda()
+    ge = gpu.ORBextractor(1000, max_batch=B)
+    cap = ge.max_keypoints(640, 480)
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ge.extract_batch_device(imgs.data_ptr(), B, 640, 480, 640, 640 * 480, kps.data_ptr(), desc.data_ptr(), cap,
+                            nout.data_ptr(), stream)
+    bm = gpu.BatchMatcher(B - 1, cap)
+    match_b = torch.full((B - 1, cap), -7, dtype=torch.int32, device="cuda")
+    nm = torch.zeros(B - 1, dtype=torch.int32, device="cuda")
+    bm.match(B - 1, cap, desc.data_ptr(), kps.data_ptr() + 12, None, nout.data_ptr(), desc.data_ptr() + cap * 32,
+             kps.data_ptr() + cap * 28 + 12, nout.data_ptr() + 4, 28, 50, 0.7, True, match_b.data_ptr(),
+             nm.data_ptr(), stream)
+    torch.cuda.synchronize()
+    n = nout.cpu().numpy()
+    k = kps.cpu().numpy()
+    d = desc.cpu().numpy()
+    mb = match_b.cpu().numpy()
+    sweeps = bm.last_sweeps(B - 1)
+    assert np.all(sweeps > 0) and np.all(sweeps <= 12), sweeps
+    for p in range(B - 1):
+        no, mo = oracle.match_bf(d[p, :n[p]], k[p, :n[p], 3], d[p + 1, :n[p + 1]], k[p + 1, :n[p + 1], 3], nnratio=0.7)
+        assert int(nm[p]) == no
+        assert np.array_equal(mb[p, :n[p + 1]], mo)
+        assert np.all(mb[p, n[p + 1]:] == -1)
