@@ -431,7 +431,7 @@ static int run_projection(Uploader &up, const FrameDev &F, const std::vector<Que
 }
 
 // cv::Mat 3x3 * 3x1 + 3x1 (CV_32F): cv::gemm small-matrix path -> float products summed left to
-// right, then one add of the C term (see oracle/orb_oracle_match.c rt_apply; adopted convention).
+// right, then one add of the C term (adopted convention, DESIGN.md "float conventions").
 static void rt_apply(const float *T, const float *p, float *out)
 {
     for (int i = 0; i < 3; i++) {

@@ -5,6 +5,7 @@ or no HIP device is visible, calls fail loudly (OrbGpuError / OSError).
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -82,6 +83,14 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
+    if "torch" not in sys.modules:
+        # torch wheels bundle their own HIP runtime; if liborbgpu.so pulls in /opt/rocm's copy first,
+        # a later `import torch` in the same process cannot see the GPU ("No HIP GPUs are available").
+        # Loading torch first makes both share one runtime.  Pure plumbing: nothing here uses torch.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise OSError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(the HIP extension is the product; there is no CPU fallback)" % LIB_PATH)
@@ -233,11 +242,6 @@ class ORBextractor:
 
     def pyramid_level(self, frame, level):
         """mvImagePyramid[level] of `frame` of the last call (ORBextractor.h:85)."""
-        w, h = C.c_int32(), C.c_int32()
-        buf = np.zeros((8192, 8192), np.uint8) if False else None
-        # query the size first with a generous scratch row
-        probe = np.zeros(1, np.uint8)
-        del probe, buf
         raw, pitch = self.debug_read(DBG_PYRAMID_PADDED, frame, level)
         img = raw.reshape(-1, pitch)
         return img

@@ -16,8 +16,7 @@ def test_hamming_vs_popcount(gpu):
     a = rng.integers(0, 256, (4096, 32), dtype=np.uint8)
     b = rng.integers(0, 256, (4096, 32), dtype=np.uint8)
     a[:3] = 0
-    b[:3] = (0, 255, 1)
-    b[1] = 255
+    b[0], b[1], b[2] = 0, 255, 1
     ref = np.unpackbits(a ^ b, axis=1).sum(1)
     out = gpu.ORBmatcher.DescriptorDistance(a, b)
     assert np.array_equal(out, ref)
