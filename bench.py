@@ -103,27 +103,24 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from orb_slam2_map_amd import dist as D
     from orb_slam2_map_amd import lib as G
     from orb_slam2_map_amd.synth import Stream
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local_rank, world = D.env_rank()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     G.lib()  # fail loudly if the HIP extension is missing
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: bench.py measures the HIP path only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    D.init("nccl", rank, world)  # RCCL; carries the barrier and two scalar reductions only
 
     W, H, NFEAT = 640, 480, 1000
     B, POOL = args.batch, max(args.pool, args.batch)
     POOL = (POOL // B) * B
     # one independent sequence per rank
-    st = Stream(W, H, 1234 + 1000 * rank)
+    st = Stream(W, H, D.sequence_seed(1234, rank))
     host_pool = np.stack([st.frame(t)[0] for t in range(POOL)])
     frames = torch.from_numpy(host_pool).cuda(local_rank)
 
@@ -175,12 +172,7 @@ def main():
     ext.set_profiling(False)
     match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    nfr = torch.tensor([float(B * args.steps)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(nfr, op=dist.ReduceOp.SUM)
-    elapsed_max, total_frames = float(t.item()), float(nfr.item())
+    elapsed_max, total_frames = D.aggregate(elapsed, B * args.steps, world, device="cuda")
 
     # sanity of the measured work (rank-local): every frame produced key points and matches
     n_host = nout.cpu().numpy()
@@ -225,8 +217,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([host_pool[i] for i in range(min(POOL, 400))])
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    D.finalize(world)
 
 
 if __name__ == "__main__":

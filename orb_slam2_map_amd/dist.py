@@ -1,0 +1,55 @@
+"""Multi-GPU harness: one process per GPU, one independent RGB-D sequence per rank.
+
+The hot path has no exchange step -- extraction is per frame and matching is per sequence -- so
+there is NO data-path collective.  torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests) carries only the start barrier and the two tiny reductions that form
+the aggregate throughput: max elapsed time over ranks and the sum of processed frames.
+"""
+import os
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def sequence_seed(base_seed, rank):
+    """Seed of the synthetic sequence rank `rank` owns (frames shard by sequence, never by frame)."""
+    return base_seed + 1000 * rank
+
+
+def shard_sequences(n_sequences, rank, world):
+    """Sequences owned by `rank` when there are more sequences than ranks (round-robin)."""
+    return [s for s in range(n_sequences) if s % world == rank]
+
+
+def init(backend, rank, world):
+    import torch.distributed as dist
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+
+
+def barrier(world):
+    import torch.distributed as dist
+    if world > 1:
+        dist.barrier()
+
+
+def aggregate(elapsed_s, frames, world, device="cpu"):
+    """(max elapsed over ranks, total frames over ranks)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    n = torch.tensor([float(frames)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(n.item())
+
+
+def finalize(world):
+    import torch.distributed as dist
+    if world > 1 and dist.is_initialized():
+        dist.destroy_process_group()

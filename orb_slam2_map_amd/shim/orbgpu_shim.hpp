@@ -1,0 +1,403 @@
+// orbgpu_shim.hpp -- C++ host side above the C ABI: re-creates the reference's three hot-path
+// interfaces (ORB_SLAM2::ORBextractor, ORBmatcher::SearchByProjection x2 + DescriptorDistance,
+// PointCloudMapping) on top of liborbgpu.so.
+//
+// The reference's own classes depend on OpenCV 2.4 / PCL 1.7 (absent from the build image), so
+// everything that touches Frame / MapPoint / KeyFrame / cv::Mat is a template on those types: inside
+// the reference tree the templates bind to the real classes (INTEGRATION.md shows the three edits);
+// in this repository tests/shim_test.cpp binds them to small stand-ins with the same member names.
+// Field names, argument meaning and return values follow the reference (file:line cited per item).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "orbgpu.h"
+
+namespace orbgpu_shim {
+
+inline void check(int status, const char *what)
+{
+    if (status != ORBGPU_OK)
+        throw std::runtime_error(std::string(what) + ": " + orbgpu_last_error_string());
+}
+
+// --------------------------------------------------------------------------------------------
+// ORBextractor (reference include/ORBextractor.h:46-110)
+// KeyPointT must be layout-compatible with cv::KeyPoint (pt.x, pt.y, size, angle, response,
+// octave, class_id = 28 bytes), which orbgpu_keypoint mirrors.
+// --------------------------------------------------------------------------------------------
+template <typename KeyPointT> class ORBextractorT {
+  public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractorT(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id = 0)
+    {
+        static_assert(sizeof(KeyPointT) == sizeof(orbgpu_keypoint), "KeyPointT must match cv::KeyPoint");
+        orbgpu_extractor_params p{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id, 1};
+        check(orbgpu_extractor_create(&p, &h_), "ORBextractor");
+        nlevels_ = nlevels;
+        scaleFactor_ = scaleFactor;
+        mvScaleFactor.resize(nlevels);
+        mvInvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels);
+        mvInvLevelSigma2.resize(nlevels);
+        check(orbgpu_extractor_get_scale_factors(h_, mvScaleFactor.data()), "scale factors");
+        check(orbgpu_extractor_get_inv_scale_factors(h_, mvInvScaleFactor.data()), "scale factors");
+        check(orbgpu_extractor_get_sigma2(h_, mvLevelSigma2.data()), "scale factors");
+        check(orbgpu_extractor_get_inv_sigma2(h_, mvInvLevelSigma2.data()), "scale factors");
+    }
+    ~ORBextractorT() { orbgpu_extractor_destroy(h_); }
+    ORBextractorT(const ORBextractorT &) = delete;
+    ORBextractorT &operator=(const ORBextractorT &) = delete;
+
+    // operator()(InputArray image, InputArray mask, vector<KeyPoint>&, OutputArray descriptors)
+    // (ORBextractor.h:59-61).  `image`: 8-bit gray rows x cols with `step` bytes per row; the mask is
+    // ignored as in the reference; descriptors: N x 32 bytes, contiguous (ORBextractor.cc:1068).
+    void operator()(const uint8_t *image, int rows, int cols, size_t step, std::vector<KeyPointT> &keypoints,
+                    std::vector<uint8_t> &descriptors)
+    {
+        keypoints.clear();
+        descriptors.clear();
+        if (!image || rows <= 0 || cols <= 0)
+            return;  // ORBextractor.cc:1046
+        int32_t cap = 0;
+        check(orbgpu_extractor_max_keypoints(h_, cols, rows, &cap), "ORBextractor::operator()");
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int32_t n = 0;
+        check(orbgpu_extract(h_, image, cols, rows, step, reinterpret_cast<orbgpu_keypoint *>(keypoints.data()),
+                             descriptors.data(), cap, &n),
+              "ORBextractor::operator()");
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32);
+        last_rows_ = rows;
+        last_cols_ = cols;
+    }
+
+    int GetLevels() { return nlevels_; }
+    float GetScaleFactor() { return scaleFactor_; }
+    std::vector<float> GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // mvImagePyramid[level] (ORBextractor.h:85): lazily copied from the device; only stereo
+    // matching reads it (Frame.cc:471,561,578).
+    void GetPyramidLevel(int level, std::vector<uint8_t> &pixels, int &width, int &height)
+    {
+        // level size as ComputePyramid computes it (ORBextractor.cc:1112)
+        int32_t w = (int32_t)lrintf((float)last_cols_ * mvInvScaleFactor[level]);
+        int32_t h = (int32_t)lrintf((float)last_rows_ * mvInvScaleFactor[level]);
+        pixels.resize((size_t)w * h);
+        check(orbgpu_extractor_get_pyramid_level(h_, 0, level, pixels.data(), (size_t)w, &w, &h), "pyramid");
+        width = w;
+        height = h;
+    }
+
+    orbgpu_extractor *handle() { return h_; }
+
+  protected:
+    orbgpu_extractor *h_ = nullptr;
+    int nlevels_ = 0, last_rows_ = 0, last_cols_ = 0;
+    float scaleFactor_ = 0;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+// --------------------------------------------------------------------------------------------
+// ORBmatcher (reference include/ORBmatcher.h:41-106)
+// --------------------------------------------------------------------------------------------
+constexpr int FRAME_GRID_ROWS = ORBGPU_GRID_ROWS, FRAME_GRID_COLS = ORBGPU_GRID_COLS;
+
+// Flattens the Frame members the matcher reads into the ABI's SoA view.  FrameT needs the
+// reference's member names: N, mvKeysUn[i].pt/.octave/.angle, mvuRight, descriptor rows via
+// desc_row(F,i), mGrid[COLS][ROWS], mnMinX.., mfGridElementWidthInv.., mvScaleFactors.
+template <typename FrameT> struct FrameSoA {
+    std::vector<float> x, y, angle, uright;
+    std::vector<int32_t> octave, cell_start, cell_items;
+    std::vector<uint8_t> desc;
+    orbgpu_frame_view view{};
+    template <typename DescRow> FrameSoA(const FrameT &F, DescRow desc_row)
+    {
+        const int n = F.N;
+        x.resize(n), y.resize(n), angle.resize(n), uright.resize(n), octave.resize(n), desc.resize((size_t)n * 32);
+        for (int i = 0; i < n; i++) {
+            x[i] = F.mvKeysUn[i].pt.x;
+            y[i] = F.mvKeysUn[i].pt.y;
+            angle[i] = F.mvKeysUn[i].angle;
+            octave[i] = F.mvKeysUn[i].octave;
+            uright[i] = F.mvuRight[i];
+            std::memcpy(&desc[(size_t)i * 32], desc_row(F, i), 32);
+        }
+        cell_start.assign(FRAME_GRID_COLS * FRAME_GRID_ROWS + 1, 0);
+        for (int ix = 0; ix < FRAME_GRID_COLS; ix++)
+            for (int iy = 0; iy < FRAME_GRID_ROWS; iy++) {
+                const auto &cell = F.mGrid[ix][iy];
+                cell_start[ix * FRAME_GRID_ROWS + iy + 1] = cell_start[ix * FRAME_GRID_ROWS + iy] + (int32_t)cell.size();
+                for (size_t k = 0; k < cell.size(); k++)
+                    cell_items.push_back((int32_t)cell[k]);
+            }
+        if (cell_items.empty())
+            cell_items.push_back(0);
+        view.n = n;
+        view.kp_x = x.data(), view.kp_y = y.data(), view.kp_octave = octave.data(), view.kp_angle = angle.data();
+        view.u_right = uright.data(), view.desc = desc.data();
+        view.min_x = F.mnMinX, view.max_x = F.mnMaxX, view.min_y = F.mnMinY, view.max_y = F.mnMaxY;
+        view.grid_inv_w = F.mfGridElementWidthInv, view.grid_inv_h = F.mfGridElementHeightInv;
+        view.scale_factors = F.mvScaleFactors.data(), view.nlevels = (int32_t)F.mvScaleFactors.size();
+        view.cell_start = cell_start.data(), view.cell_items = cell_items.data();
+    }
+};
+
+template <typename FrameT, typename MapPointT> class ORBmatcherT {
+  public:
+    static const int TH_LOW = ORBGPU_TH_LOW, TH_HIGH = ORBGPU_TH_HIGH, HISTO_LENGTH = ORBGPU_HISTO_LENGTH;
+
+    ORBmatcherT(float nnratio = 0.6f, bool checkOri = true, int device_id = 0)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device_id)
+    {
+    }
+
+    // static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b)  (ORBmatcher.h:44)
+    static int DescriptorDistance(const uint8_t *a, const uint8_t *b, int device_id = 0)
+    {
+        int32_t d = 0;
+        check(orbgpu_hamming256(a, b, 1, &d, device_id), "DescriptorDistance");
+        return d;
+    }
+
+    // int SearchByProjection(Frame &F, const std::vector<MapPoint*> &vpMapPoints, const float th=3)
+    // (ORBmatcher.h:48, ORBmatcher.cc:45-129).  desc_row(F,i) / mp_desc(pMP) return 32-byte rows.
+    template <typename DescRow, typename MpDesc>
+    int SearchByProjection(FrameT &F, const std::vector<MapPointT *> &vpMapPoints, const float th, DescRow desc_row,
+                           MpDesc mp_desc)
+    {
+        FrameSoA<FrameT> soa(F, desc_row);
+        const int m = (int)vpMapPoints.size();
+        std::vector<uint8_t> in_view(m), bad(m), obs(m), desc((size_t)std::max(m, 1) * 32);
+        std::vector<int32_t> level(m);
+        std::vector<float> vcos(m), px(m), py(m), pxr(m);
+        for (int i = 0; i < m; i++) {
+            MapPointT *p = vpMapPoints[i];
+            in_view[i] = p->mbTrackInView;
+            bad[i] = p->isBad();
+            obs[i] = p->Observations() > 0;
+            level[i] = p->mnTrackScaleLevel;
+            vcos[i] = p->mTrackViewCos;
+            px[i] = p->mTrackProjX, py[i] = p->mTrackProjY, pxr[i] = p->mTrackProjXR;
+            std::memcpy(&desc[(size_t)i * 32], mp_desc(p), 32);
+        }
+        orbgpu_mappoint_view mv{m,         in_view.data(), bad.data(), obs.data(), level.data(),
+                                vcos.data(), px.data(),      py.data(),  pxr.data(), desc.data()};
+        // F.mvpMapPoints -> indices: points of the list by position, others by their Observations()
+        std::vector<int32_t> k2m(F.N, -1);
+        for (int j = 0; j < F.N; j++) {
+            MapPointT *p = F.mvpMapPoints[j];
+            if (!p)
+                continue;
+            int idx = -1;
+            for (int i = 0; i < m && idx < 0; i++)
+                if (vpMapPoints[i] == p)
+                    idx = i;
+            k2m[j] = idx >= 0 ? idx : (p->Observations() > 0 ? -2 : -1);
+        }
+        std::vector<int32_t> before = k2m;
+        int32_t nmatches = 0;
+        check(orbgpu_search_by_projection(&soa.view, &mv, th, mfNNratio, k2m.data(), &nmatches, device_),
+              "SearchByProjection");
+        for (int j = 0; j < F.N; j++)
+            if (k2m[j] != before[j] && k2m[j] >= 0)
+                F.mvpMapPoints[j] = vpMapPoints[k2m[j]];  // ORBmatcher.cc:123
+        return nmatches;
+    }
+
+    // int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)
+    // (ORBmatcher.h:52, ORBmatcher.cc:1328-1470).  Tcw(F) returns the 16 floats of F.mTcw (row-major);
+    // world_pos(pMP) the 3 floats of GetWorldPos().
+    template <typename DescRow, typename MpDesc, typename TcwOf, typename WorldPos>
+    int SearchByProjection(FrameT &CurrentFrame, const FrameT &LastFrame, const float th, const bool bMono,
+                           DescRow desc_row, MpDesc mp_desc, TcwOf Tcw, WorldPos world_pos)
+    {
+        FrameSoA<FrameT> cur(CurrentFrame, desc_row);
+        const int n = LastFrame.N;
+        std::vector<uint8_t> has(n), outl(n), obs(n), desc((size_t)std::max(n, 1) * 32);
+        std::vector<float> wp((size_t)std::max(n, 1) * 3), ang(n);
+        std::vector<int32_t> oct(n);
+        for (int i = 0; i < n; i++) {
+            MapPointT *p = LastFrame.mvpMapPoints[i];
+            has[i] = p != nullptr;
+            outl[i] = LastFrame.mvbOutlier[i];
+            oct[i] = LastFrame.mvKeys[i].octave;
+            ang[i] = LastFrame.mvKeysUn[i].angle;
+            if (p) {
+                obs[i] = p->Observations() > 0;
+                const float *w = world_pos(p);
+                wp[3 * i] = w[0], wp[3 * i + 1] = w[1], wp[3 * i + 2] = w[2];
+                std::memcpy(&desc[(size_t)i * 32], mp_desc(p), 32);
+            }
+        }
+        orbgpu_lastframe_view lv{n, has.data(), outl.data(), obs.data(), wp.data(), desc.data(), oct.data(), ang.data(),
+                                 Tcw(LastFrame)};
+        std::vector<int32_t> k2m(CurrentFrame.N, -1);
+        for (int j = 0; j < CurrentFrame.N; j++)
+            if (MapPointT *p = CurrentFrame.mvpMapPoints[j])
+                k2m[j] = p->Observations() > 0 ? -2 : -1;
+        std::vector<int32_t> before = k2m;
+        int32_t nmatches = 0;
+        check(orbgpu_search_by_projection_last(&cur.view, Tcw(CurrentFrame), CurrentFrame.fx, CurrentFrame.fy,
+                                               CurrentFrame.cx, CurrentFrame.cy, CurrentFrame.mbf, CurrentFrame.mb, &lv,
+                                               th, bMono, mbCheckOrientation, k2m.data(), &nmatches, device_),
+              "SearchByProjection(last)");
+        for (int j = 0; j < CurrentFrame.N; j++) {
+            if (k2m[j] == before[j])
+                continue;
+            CurrentFrame.mvpMapPoints[j] = k2m[j] >= 0 ? LastFrame.mvpMapPoints[k2m[j]] : nullptr;  // :1428, :1461
+        }
+        return nmatches;
+    }
+
+  protected:
+    float mfNNratio;
+    bool mbCheckOrientation;
+    int device_;
+};
+
+// --------------------------------------------------------------------------------------------
+// PointCloudMapping (reference include/PointCloudMap.h:41-88, src/PointCloudMap.cc)
+// Keeps the reference's thread / condition-variable protocol; the per-key-frame arithmetic runs on
+// the GPU.  KeyFrameT needs mImDep (float depth), mImRGB (8UC3), fx, fy, cx, cy and GetPose();
+// the accessors below adapt cv::Mat (or a stand-in).  Visualisation, StatisticalOutlierRemoval and
+// the PCD writer of the reference stay host-side and are not re-created here.
+// --------------------------------------------------------------------------------------------
+struct ImageView {
+    const void *data;
+    int rows, cols;
+    size_t step;  // bytes
+};
+
+template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
+  public:
+    PointCloudMappingT(double resolution_, Adapter adapter = Adapter(), int device_id = 0)
+        : resolution(resolution_), adapt(adapter)
+    {
+        check(orbgpu_cloud_create(resolution, device_id, &cloud_), "PointCloudMapping");
+        viewerThread = std::make_shared<std::thread>(&PointCloudMappingT::viewer, this);  // PointCloudMap.cc:53
+    }
+    ~PointCloudMappingT()
+    {
+        if (viewerThread && viewerThread->joinable())
+            shutdown();
+        orbgpu_cloud_destroy(cloud_);
+    }
+
+    void insertKeyFrame(KeyFrameT *kf)  // PointCloudMap.cc:69-76
+    {
+        std::unique_lock<std::mutex> lck(keyframeMutex);
+        keyframes.push_back(kf);
+        keyFrameUpdated.notify_one();
+    }
+
+    void shutdown()  // PointCloudMap.cc:59-67
+    {
+        {
+            std::unique_lock<std::mutex> lck(shutDownMutex);
+            shutDownFlag = true;
+            keyFrameUpdated.notify_one();
+        }
+        viewerThread->join();
+    }
+
+    void viewer()  // PointCloudMap.cc:182-289, no-loop branch; see rebuild() for the loop-closure branch
+    {
+        while (true) {
+            {
+                std::unique_lock<std::mutex> lck(keyframeMutex);
+                keyFrameUpdated.wait(lck, [&] { return shutDownFlagLocked() || keyframes.size() > lastKeyframeSize; });
+            }
+            size_t N;
+            {
+                std::unique_lock<std::mutex> lck(keyframeMutex);
+                N = keyframes.size();
+            }
+            for (size_t i = lastKeyframeSize; i < N; i++)
+                insertOne(keyframes[i]);
+            lastKeyframeSize = N;
+            if (shutDownFlagLocked())
+                break;
+        }
+    }
+
+    // loop-closure branch (PointCloudMap.cc:217-243): regenerate every key frame with its new pose
+    void rebuild(const std::vector<KeyFrameT *> &kfs)
+    {
+        std::vector<const float *> depth, Tcw;
+        std::vector<const uint8_t *> rgb;
+        std::vector<std::vector<float>> poses;
+        if (kfs.empty())
+            return;
+        ImageView d0 = adapt.depth(kfs[0]), c0 = adapt.rgb(kfs[0]);
+        for (KeyFrameT *kf : kfs) {
+            depth.push_back((const float *)adapt.depth(kf).data);
+            rgb.push_back((const uint8_t *)adapt.rgb(kf).data);
+            poses.emplace_back(16);
+            adapt.pose(kf, poses.back().data());
+        }
+        for (auto &p : poses)
+            Tcw.push_back(p.data());
+        std::unique_lock<std::mutex> lck(cloudMutex);
+        check(orbgpu_cloud_rebuild(cloud_, (int)kfs.size(), depth.data(), d0.step / sizeof(float), rgb.data(), c0.step,
+                                   d0.cols, d0.rows, adapt.fx(kfs[0]), adapt.fy(kfs[0]), adapt.cx(kfs[0]),
+                                   adapt.cy(kfs[0]), Tcw.data()),
+              "PointCloudMapping::rebuild");
+    }
+
+    // globalMapRGBD (PointCloudMap.h:55)
+    std::vector<orbgpu_point_xyzrgba> globalMap()
+    {
+        std::unique_lock<std::mutex> lck(cloudMutex);
+        int64_t n = 0;
+        check(orbgpu_cloud_size(cloud_, &n), "size");
+        std::vector<orbgpu_point_xyzrgba> out((size_t)std::max<int64_t>(n, 1));
+        check(orbgpu_cloud_download(cloud_, out.data(), (int64_t)out.size(), &n), "download");
+        out.resize((size_t)n);
+        return out;
+    }
+
+  protected:
+    bool shutDownFlagLocked()
+    {
+        std::unique_lock<std::mutex> lck(shutDownMutex);
+        return shutDownFlag;
+    }
+    void insertOne(KeyFrameT *kf)
+    {
+        ImageView d = adapt.depth(kf), c = adapt.rgb(kf);
+        float Tcw[16];
+        adapt.pose(kf, Tcw);
+        std::unique_lock<std::mutex> lck(cloudMutex);
+        check(orbgpu_cloud_insert(cloud_, (const float *)d.data, d.step / sizeof(float), (const uint8_t *)c.data, c.step,
+                                  d.cols, d.rows, adapt.fx(kf), adapt.fy(kf), adapt.cx(kf), adapt.cy(kf), Tcw),
+              "PointCloudMapping::insertKeyFrame");
+    }
+
+    orbgpu_cloud *cloud_ = nullptr;
+    std::shared_ptr<std::thread> viewerThread;
+    bool shutDownFlag = false;
+    std::mutex shutDownMutex, keyframeMutex, cloudMutex;
+    std::condition_variable keyFrameUpdated;
+    std::vector<KeyFrameT *> keyframes;
+    size_t lastKeyframeSize = 0;
+    double resolution = 0.01;
+    Adapter adapt;
+};
+
+} // namespace orbgpu_shim

@@ -1,0 +1,176 @@
+// Exercises the C++ shim (orb_slam2_map_amd/shim/orbgpu_shim.hpp) with stand-ins that carry the
+// reference's member names (Frame.h / MapPoint.h / KeyFrame.h).  Reads a scenario file written by
+// tests/test_shim.py, runs extractor -> SearchByProjection x2 -> PointCloudMapping through the shim
+// and writes the results for comparison with the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "orbgpu_shim.hpp"
+
+struct Point2f { float x, y; };
+struct KeyPoint { Point2f pt; float size, angle, response; int octave, class_id; };  // cv::KeyPoint layout
+
+struct MapPoint {  // members read by the matcher: MapPoint.h:91-96 + accessors
+    bool mbTrackInView = false;
+    int mnTrackScaleLevel = 0;
+    float mTrackViewCos = 0, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
+    bool bad = false;
+    int nObs = 1;
+    float world[3] = {0, 0, 0};
+    uint8_t desc[32];
+    int id = -1;
+    bool isBad() const { return bad; }
+    int Observations() const { return nObs; }
+};
+
+struct Frame {  // Frame.h:100-190
+    int N = 0;
+    std::vector<KeyPoint> mvKeys, mvKeysUn;
+    std::vector<float> mvuRight;
+    std::vector<uint8_t> mDescriptors;
+    std::vector<MapPoint *> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    std::vector<size_t> mGrid[orbgpu_shim::FRAME_GRID_COLS][orbgpu_shim::FRAME_GRID_ROWS];
+    float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    std::vector<float> mvScaleFactors;
+    float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0;
+    float mTcw[16];
+};
+
+struct KeyFrame {
+    std::vector<float> mImDep;
+    std::vector<uint8_t> mImRGB;
+    int rows = 0, cols = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    float pose[16];
+};
+struct KFAdapter {
+    orbgpu_shim::ImageView depth(KeyFrame *k) const { return {k->mImDep.data(), k->rows, k->cols, (size_t)k->cols * 4}; }
+    orbgpu_shim::ImageView rgb(KeyFrame *k) const { return {k->mImRGB.data(), k->rows, k->cols, (size_t)k->cols * 3}; }
+    void pose(KeyFrame *k, float *T) const { std::memcpy(T, k->pose, 64); }
+    float fx(KeyFrame *k) const { return k->fx; }
+    float fy(KeyFrame *k) const { return k->fy; }
+    float cx(KeyFrame *k) const { return k->cx; }
+    float cy(KeyFrame *k) const { return k->cy; }
+};
+
+template <typename T> static void rd(std::ifstream &f, T *p, size_t n) { f.read(reinterpret_cast<char *>(p), sizeof(T) * n); }
+template <typename T> static void wr(std::ofstream &f, const T *p, size_t n) { f.write(reinterpret_cast<const char *>(p), sizeof(T) * n); }
+
+// Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:230-245, 382-392) for the stand-in
+static void assign_grid(Frame &F)
+{
+    for (int i = 0; i < F.N; i++) {
+        const int px = (int)roundf((F.mvKeysUn[i].pt.x - F.mnMinX) * F.mfGridElementWidthInv);
+        const int py = (int)roundf((F.mvKeysUn[i].pt.y - F.mnMinY) * F.mfGridElementHeightInv);
+        if (px < 0 || px >= orbgpu_shim::FRAME_GRID_COLS || py < 0 || py >= orbgpu_shim::FRAME_GRID_ROWS)
+            continue;
+        F.mGrid[px][py].push_back(i);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: shim_test <scenario.bin> <out.bin> [--compile-only]\n");
+        return 2;
+    }
+    try {
+        std::ifstream in(argv[1], std::ios::binary);
+        std::ofstream out(argv[2], std::ios::binary);
+        int32_t hdr[4];  // w, h, nfeatures, n_map
+        rd(in, hdr, 4);
+        const int w = hdr[0], h = hdr[1], nfeat = hdr[2], m = hdr[3];
+        float cam[6];  // fx fy cx cy bf th
+        rd(in, cam, 6);
+        std::vector<uint8_t> gray((size_t)w * h), rgb((size_t)w * h * 3);
+        std::vector<float> depth((size_t)w * h);
+        rd(in, gray.data(), gray.size());
+        rd(in, rgb.data(), rgb.size());
+        rd(in, depth.data(), depth.size());
+        float Tcw[16];
+        rd(in, Tcw, 16);
+
+        // ---- extractor through the reference's interface
+        orbgpu_shim::ORBextractorT<KeyPoint> extractor(nfeat, 1.2f, 8, 20, 7);
+        Frame F;
+        extractor(gray.data(), h, w, (size_t)w, F.mvKeys, F.mDescriptors);
+        F.N = (int)F.mvKeys.size();
+        F.mvKeysUn = F.mvKeys;  // zero distortion (Frame.cc:406-410)
+        F.mvScaleFactors = extractor.GetScaleFactors();
+        F.mnMinX = 0, F.mnMaxX = (float)w, F.mnMinY = 0, F.mnMaxY = (float)h;
+        F.mfGridElementWidthInv = (float)orbgpu_shim::FRAME_GRID_COLS / (F.mnMaxX - F.mnMinX);
+        F.mfGridElementHeightInv = (float)orbgpu_shim::FRAME_GRID_ROWS / (F.mnMaxY - F.mnMinY);
+        F.fx = cam[0], F.fy = cam[1], F.cx = cam[2], F.cy = cam[3], F.mbf = cam[4], F.mb = cam[4] / cam[0];
+        std::memcpy(F.mTcw, Tcw, 64);
+        F.mvuRight.assign(F.N, -1.f);
+        for (int i = 0; i < F.N; i++) {  // Frame::ComputeStereoFromRGBD (Frame.cc:641-662)
+            const float d = depth[(size_t)(int)F.mvKeys[i].pt.y * w + (int)F.mvKeys[i].pt.x];
+            if (d > 0)
+                F.mvuRight[i] = F.mvKeysUn[i].pt.x - F.mbf / d;
+        }
+        F.mvpMapPoints.assign(F.N, nullptr);
+        F.mvbOutlier.assign(F.N, false);
+        assign_grid(F);
+        int32_t n = F.N;
+        wr(out, &n, 1);
+        wr(out, F.mvKeys.data(), F.mvKeys.size());
+        wr(out, F.mDescriptors.data(), F.mDescriptors.size());
+
+        // ---- local map points with pre-filled tracking scratch
+        std::vector<MapPoint> mps(m);
+        std::vector<MapPoint *> vp(m);
+        for (int i = 0; i < m; i++) {
+            MapPoint &p = mps[i];
+            uint8_t flags[3];
+            int32_t lvl;
+            float f4[4];
+            rd(in, flags, 3);
+            rd(in, &lvl, 1);
+            rd(in, f4, 4);
+            rd(in, p.world, 3);
+            rd(in, p.desc, 32);
+            p.mbTrackInView = flags[0], p.bad = flags[1], p.nObs = flags[2] ? 1 : 0;
+            p.mnTrackScaleLevel = lvl, p.mTrackViewCos = f4[0], p.mTrackProjX = f4[1], p.mTrackProjY = f4[2],
+            p.mTrackProjXR = f4[3];
+            p.id = i;
+            vp[i] = &p;
+        }
+        auto desc_row = [](const Frame &fr, int i) { return &fr.mDescriptors[(size_t)i * 32]; };
+        auto mp_desc = [](MapPoint *p) { return p->desc; };
+        orbgpu_shim::ORBmatcherT<Frame, MapPoint> matcher(0.8f, true);
+        const int nm = matcher.SearchByProjection(F, vp, cam[5], desc_row, mp_desc);
+        int32_t nm32 = nm;
+        wr(out, &nm32, 1);
+        for (int j = 0; j < F.N; j++) {
+            int32_t id = F.mvpMapPoints[j] ? F.mvpMapPoints[j]->id : -1;
+            wr(out, &id, 1);
+        }
+        const int dist = orbgpu_shim::ORBmatcherT<Frame, MapPoint>::DescriptorDistance(mps[0].desc, mps[m - 1].desc);
+        int32_t d32 = dist;
+        wr(out, &d32, 1);
+
+        // ---- point cloud thread protocol
+        KeyFrame kf;
+        kf.mImDep = depth, kf.mImRGB = rgb, kf.rows = h, kf.cols = w;
+        kf.fx = cam[0], kf.fy = cam[1], kf.cx = cam[2], kf.cy = cam[3];
+        std::memcpy(kf.pose, Tcw, 64);
+        std::vector<orbgpu_point_xyzrgba> cloud;
+        {
+            orbgpu_shim::PointCloudMappingT<KeyFrame, KFAdapter> mapping(0.05);
+            mapping.insertKeyFrame(&kf);
+            mapping.shutdown();
+            cloud = mapping.globalMap();
+        }
+        int64_t nc = (int64_t)cloud.size();
+        wr(out, &nc, 1);
+        wr(out, cloud.data(), cloud.size());
+        std::printf("shim ok: %d key points, %d projection matches, %lld map points\n", n, nm, (long long)nc);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "shim_test failed: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,101 @@
+"""C++ shim (orb_slam2_map_amd/shim/orbgpu_shim.hpp): the reference's three class interfaces on top
+of the C ABI.  CPU part: it compiles and links with g++.  GPU part: extractor -> SearchByProjection ->
+PointCloudMapping through the shim equal the oracle."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import scenario
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "orb_slam2_map_amd")
+
+
+def build_exe(tmpdir):
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(PKG, "liborbgpu.so")):
+        ge.build()
+    exe = os.path.join(tmpdir, "shim_test")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "shim"),
+           os.path.join(ROOT, "tests", "shim_test.cpp"), "-o", exe, "-L" + PKG, "-lorbgpu", "-Wl,-rpath," + PKG,
+           "-Wl,-rpath,/opt/rocm/lib", "-pthread"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return exe
+
+
+def test_shim_compiles_and_links():
+    with tempfile.TemporaryDirectory() as d:
+        exe = build_exe(d)
+        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_shim_end_to_end(gpu, oracle, stream640):
+    st = stream640
+    rng = np.random.default_rng(11)
+    t_cur = 12
+    g, rgb, depth = st.frame(t_cur)
+    oe = oracle.Extractor(1000)
+    ok, od = oe.extract(g)
+    sf = oe.scale_factors()
+    Tcw = scenario.rigid()
+    # local map from two earlier frames (oracle extraction; the shim extracts the current frame itself)
+    wp, dsc, octv = [], [], []
+    ox, oy = st.offset(t_cur)
+    for t in (11, 10):
+        gp, _, dp = st.frame(t)
+        k, d = oracle.Extractor(1000).extract(gp)
+        px, py = st.offset(t)
+        P, _ = scenario.world_points_from_prev(k, dp, (ox - px, oy - py), st, Tcw, rng)
+        wp.append(P), dsc.append(d), octv.append(k["octave"])
+    wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
+    mp = scenario.local_map(oracle, st, Tcw, wp, dsc, octv, sf, rng, obs_zero_frac=0.1)
+    th = 3.0
+    with tempfile.TemporaryDirectory() as d:
+        exe = build_exe(d)
+        scen, outp = os.path.join(d, "scen.bin"), os.path.join(d, "out.bin")
+        with open(scen, "wb") as f:
+            f.write(struct.pack("<4i", 640, 480, 1000, len(wp)))
+            f.write(struct.pack("<6f", float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), th))
+            f.write(g.tobytes()), f.write(rgb.tobytes()), f.write(depth.tobytes()), f.write(Tcw.astype("<f4").tobytes())
+            for i in range(len(wp)):
+                f.write(struct.pack("<3B", int(mp["in_view"][i]), int(mp["bad"][i]), int(mp["obs_pos"][i])))
+                f.write(struct.pack("<i", int(mp["level"][i])))
+                f.write(struct.pack("<4f", float(mp["view_cos"][i]), float(mp["proj_x"][i]), float(mp["proj_y"][i]),
+                                    float(mp["proj_xr"][i])))
+                f.write(wp[i].astype("<f4").tobytes()), f.write(mp["desc"][i].tobytes())
+        r = subprocess.run([exe, scen, outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        buf = open(outp, "rb").read()
+    n = struct.unpack_from("<i", buf, 0)[0]
+    off = 4
+    kps = np.frombuffer(buf, oracle.KEYPOINT_DTYPE, n, off)
+    off += 28 * n
+    desc = np.frombuffer(buf, np.uint8, 32 * n, off).reshape(n, 32)
+    off += 32 * n
+    assert n == len(ok) and kps.tobytes() == ok.tobytes() and np.array_equal(desc, od)
+    nm = struct.unpack_from("<i", buf, off)[0]
+    off += 4
+    k2m = np.frombuffer(buf, np.int32, n, off)
+    off += 4 * n
+    of = scenario.make_frame(oracle, ok, od, depth, st, sf)
+    no, ko = oracle.search_by_projection(of, mp, th, 0.8, np.full(n, -1, np.int32))
+    assert nm == no and np.array_equal(k2m, ko) and no > 50
+    dist = struct.unpack_from("<i", buf, off)[0]
+    off += 4
+    assert dist == oracle.descriptor_distance(mp["desc"][0], mp["desc"][-1])
+    nc = struct.unpack_from("<q", buf, off)[0]
+    off += 8
+    cloud = np.frombuffer(buf, oracle.POINT_DTYPE, nc, off)
+    R, t = oracle.pose_inverse(Tcw)
+    ocloud, _ = oracle.voxel_filter(oracle.transform_points(
+        oracle.backproject(depth, rgb, float(st.fx), float(st.fy), float(st.cx), float(st.cy)), R, t), 0.05)
+    assert nc == len(ocloud)
+    for fld in "xyz":
+        assert np.max(np.abs(cloud[fld] - ocloud[fld])) <= 1e-4
