@@ -37,7 +37,6 @@ struct LevelGeom {
     float scale;
     int patch;
     int xtab_off, ytab_off;  // resize tables (levels >= 1)
-    int tile_first, ntiles_x, ntiles_y;  // blur tiles
 };
 
 struct CellDesc {
@@ -56,9 +55,6 @@ struct YTab {
     int16_t b0, b1;
 };
 
-struct BlurTile {
-    short level, tx, ty, pad;
-};
 
 // packed FAST key: y[31:20] x[19:8] response[7:0]; x,y relative to (minBorderX,minBorderY)
 __host__ __device__ __forceinline__ uint32_t pack_key(int x, int y, int resp)
@@ -795,51 +791,100 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
 
 // ---------------------------------------------------------------------------------------------
 // K5: GaussianBlur(7x7, sigma 2, REFLECT_101), OpenCV 2.4 8-bit fixed-point path (A3).
-// Separable, taps x256 = [18,34,49,55,49,34,18]; dst = sat_u8((sum + 32768) >> 16).  The border
-// the reference gets from REFLECT_101 on the cloned level equals the pyramid's own 19-px
-// reflect-101 border, so the kernel simply reads the padded plane.  Tile 64x32 per workgroup.
+// taps x256 = [18,34,49,55,49,34,18]; dst = sat_u8((sum_y sum_x k_y k_x p + 32768) >> 16).  Integer
+// arithmetic, so any summation order is exact.  The border the reference gets from REFLECT_101 on
+// the cloned level equals the pyramid's own 19-px reflect-101 border: the kernel reads the padded
+// plane and never branches on image edges.
+//
+// Register-only streaming kernel, no LDS: a thread owns a column strip of 4 output pixels (one
+// aligned dword of the padded plane) x BLUR_ROWS rows.  Per input row it loads 3 aligned dwords
+// (12 bytes cover the 10 it needs), forms the four 7-tap horizontal sums with v_alignbyte +
+// v_dot4_u32_u8, keeps the last 7 row sums in registers and emits one output dword per row.
+// HBM-bound: each pixel is fetched once from HBM (neighbouring strips re-read through L1/L2).
 // ---------------------------------------------------------------------------------------------
-constexpr int BT_W = 64, BT_H = 32;
+constexpr int BLUR_ROWS = 28;  // output rows per strip (4 x 7: the 7-row register ring unrolls evenly)
+
+struct BlurGeom {  // strips of all levels, flattened
+    int first[ORBGPU_MAX_LEVELS + 1];  // first strip index of each level
+    int nsx[ORBGPU_MAX_LEVELS];        // strips per row of strips
+    int nlevels;
+};
+
+__device__ __forceinline__ void blur_hsum(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t h[4])
+{
+    // window bytes 0..11 = padded columns 4s-4 .. 4s+7; output pixel p has its centre at byte 4+p
+    const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps 0..3
+    const uint32_t K1 = 49u | (34u << 8) | (18u << 16);                 // taps 4..6
+    const uint32_t a1 = __builtin_amdgcn_alignbyte(d1, d0, 1), b1 = __builtin_amdgcn_alignbyte(d2, d1, 1);
+    const uint32_t a2 = __builtin_amdgcn_alignbyte(d1, d0, 2), b2 = __builtin_amdgcn_alignbyte(d2, d1, 2);
+    const uint32_t a3 = __builtin_amdgcn_alignbyte(d1, d0, 3), b3 = __builtin_amdgcn_alignbyte(d2, d1, 3);
+    h[0] = __builtin_amdgcn_udot4(b1, K1, __builtin_amdgcn_udot4(a1, K0, 0u, false), false);
+    h[1] = __builtin_amdgcn_udot4(b2, K1, __builtin_amdgcn_udot4(a2, K0, 0u, false), false);
+    h[2] = __builtin_amdgcn_udot4(b3, K1, __builtin_amdgcn_udot4(a3, K0, 0u, false), false);
+    h[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
+}
+
+__device__ __forceinline__ uint32_t blur_vsum(const uint32_t r0[4], const uint32_t r1[4], const uint32_t r2[4],
+                                              const uint32_t r3[4], const uint32_t r4[4], const uint32_t r5[4],
+                                              const uint32_t r6[4])
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        uint32_t s = 18u * (r0[p] + r6[p]) + 34u * (r1[p] + r5[p]) + 49u * (r2[p] + r4[p]) + 55u * r3[p];
+        s = (s + 32768u) >> 16;
+        s = s > 255u ? 255u : s;
+        out |= s << (8 * p);
+    }
+    return out;
+}
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                              size_t frame_pyr, const LevelGeom *__restrict__ geom,
-                                              const BlurTile *__restrict__ tiles)
+                                              size_t frame_pyr, const LevelGeom *__restrict__ geom, BlurGeom bg)
 {
-    __shared__ uint8_t in[(BT_H + 6) * (BT_W + 8)];
-    __shared__ uint16_t hz[(BT_H + 6) * BT_W];
-    const int tid = threadIdx.x;
-    const BlurTile t = tiles[blockIdx.x];
+    const int strip = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
-    const LevelGeom g = geom[t.level];
-    const int x0 = t.tx * BT_W, y0 = t.ty * BT_H;
-    const uint8_t *src = pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)(y0 + EDGE - 3) * g.pitch + (x0 + EDGE - 3);
-    // rows beyond the padded plane are never needed for valid outputs; clamp the row to stay in bounds
-    const int max_row = g.h + 2 * EDGE - 1 - (y0 + EDGE - 3);
-    const int max_col = g.pitch - 1 - (x0 + EDGE - 3);
-    for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-        int r = i / (BT_W + 6), c = i - r * (BT_W + 6);
-        in[r * (BT_W + 8) + c] = src[(size_t)min(r, max_row) * g.pitch + min(c, max_col)];
-    }
-    __syncthreads();
-    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
-        int r = i / BT_W, c = i - r * BT_W;
-        const uint8_t *p = &in[r * (BT_W + 8) + c];
-        hz[i] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
-    }
-    __syncthreads();
-    const int c = tid & 63, rg = tid >> 6;
-    uint8_t *dst = blur + (size_t)f * frame_pyr + g.plane_off + (size_t)(y0 + EDGE) * g.pitch + (x0 + EDGE);
+    if (strip >= bg.first[bg.nlevels])
+        return;
+    int level = 0;
 #pragma unroll
-    for (int k = 0; k < BT_H / 4; k++) {
-        const int r = rg * (BT_H / 4) + k;
-        const uint16_t *p = &hz[r * BT_W + c];
-        int s = 18 * (p[0] + p[6 * BT_W]) + 34 * (p[BT_W] + p[5 * BT_W]) + 49 * (p[2 * BT_W] + p[4 * BT_W]) +
-                55 * p[3 * BT_W];
-        int v = (s + 32768) >> 16;
-        v = v > 255 ? 255 : v;
-        if (x0 + c < g.w && y0 + r < g.h)
-            dst[(size_t)r * g.pitch + c] = (uint8_t)v;
+    for (int l = 1; l < ORBGPU_MAX_LEVELS; l++)
+        level += (l < bg.nlevels && strip >= bg.first[l]) ? 1 : 0;
+    const LevelGeom g = geom[level];
+    const int local = strip - bg.first[level];
+    const int sy = local / bg.nsx[level], sx = local - sy * bg.nsx[level];
+    // padded dword column: the image starts at padded byte 19 -> first strip is dword 4 (bytes 16..19)
+    const int col = (4 + sx) * 4;
+    const int y0 = sy * BLUR_ROWS;          // first output row (image coordinates)
+    const int rows = min(BLUR_ROWS, g.h - y0);
+    const size_t plane = (size_t)f * frame_pyr + g.plane_off;
+    const uint8_t *src = pyr + plane + (size_t)(y0 + EDGE - 3) * g.pitch + (col - 4);
+    uint8_t *dst = blur + plane + (size_t)(y0 + EDGE) * g.pitch + col;
+
+    uint32_t r0[4], r1[4], r2[4], r3[4], r4[4], r5[4], r6[4];
+#define BLUR_LOAD(R, row)                                                                                    \
+    {                                                                                                        \
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);               \
+        blur_hsum(q[0], q[1], q[2], R);                                                                      \
     }
+#define BLUR_STEP(A, B, C, D, E, F, G, k)                                                                    \
+    if ((k) < rows) {                                                                                        \
+        BLUR_LOAD(G, (k) + 6)                                                                                \
+        *reinterpret_cast<uint32_t *>(dst + (size_t)(k) * g.pitch) = blur_vsum(A, B, C, D, E, F, G);         \
+    }
+    BLUR_LOAD(r0, 0) BLUR_LOAD(r1, 1) BLUR_LOAD(r2, 2) BLUR_LOAD(r3, 3) BLUR_LOAD(r4, 4) BLUR_LOAD(r5, 5)
+#pragma unroll 1
+    for (int k = 0; k < BLUR_ROWS; k += 7) {
+        BLUR_STEP(r0, r1, r2, r3, r4, r5, r6, k)
+        BLUR_STEP(r1, r2, r3, r4, r5, r6, r0, k + 1)
+        BLUR_STEP(r2, r3, r4, r5, r6, r0, r1, k + 2)
+        BLUR_STEP(r3, r4, r5, r6, r0, r1, r2, k + 3)
+        BLUR_STEP(r4, r5, r6, r0, r1, r2, r3, k + 4)
+        BLUR_STEP(r5, r6, r0, r1, r2, r3, r4, k + 5)
+        BLUR_STEP(r6, r0, r1, r2, r3, r4, r5, k + 6)
+    }
+#undef BLUR_STEP
+#undef BLUR_LOAD
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -927,12 +972,12 @@ struct orbgpu_extractor {
     int cfg_w = 0, cfg_h = 0, cfg_batch = 0;
     std::vector<LevelGeom> geom;
     std::vector<CellDesc> cells;
-    std::vector<BlurTile> tiles;
+    BlurGeom blur_geom;
     size_t frame_pyr = 0, frame_slots = 0;
     int sel_cap_total = 0, ncap = 0, max_kp = 0;
     size_t qt_lds = 0;
     // device state
-    DevBuf d_geom, d_cells, d_tiles, d_xtab, d_ytab, d_pattern;
+    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
     DevBuf d_in, d_kps, d_desc, d_nout;  // staging for the host entry points
     DevBuf d_dbg;
@@ -996,7 +1041,6 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     const int nl = e->nlevels;
     std::vector<LevelGeom> geom(nl);
     std::vector<CellDesc> cells;
-    std::vector<BlurTile> tiles;
     std::vector<XTab> xtab;
     std::vector<YTab> ytab;
     size_t plane_off = 0;
@@ -1069,13 +1113,6 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         g.sel_off = sel_off;
         sel_off += g.sel_cap;
         ncap = std::max(ncap, g.sel_cap);
-        // blur tiles
-        g.tile_first = (int)tiles.size();
-        g.ntiles_x = (g.w + BT_W - 1) / BT_W;
-        g.ntiles_y = (g.h + BT_H - 1) / BT_H;
-        for (int ty = 0; ty < g.ntiles_y; ty++)
-            for (int tx = 0; tx < g.ntiles_x; tx++)
-                tiles.push_back(BlurTile{(short)l, (short)tx, (short)ty, 0});
         // resize tables (cv::resize INTER_LINEAR 8U, A2)
         g.xtab_off = (int)xtab.size();
         g.ytab_off = (int)ytab.size();
@@ -1123,7 +1160,22 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
 
     e->geom = geom;
     e->cells = cells;
-    e->tiles = tiles;
+    {
+        BlurGeom &bgm = e->blur_geom;
+        memset(&bgm, 0, sizeof(bgm));
+        bgm.nlevels = nl;
+        int acc = 0;
+        for (int l = 0; l < nl; l++) {
+            // strips start at padded dword 4 (bytes 16..19 hold image column 0) and must cover column w-1
+            const int nsx = (geom[l].w + EDGE - 1) / 4 - 4 + 1;
+            const int nsy = (geom[l].h + BLUR_ROWS - 1) / BLUR_ROWS;
+            bgm.first[l] = acc;
+            bgm.nsx[l] = nsx;
+            acc += nsx * nsy;
+        }
+        for (int l = nl; l <= ORBGPU_MAX_LEVELS; l++)
+            bgm.first[l] = acc;
+    }
     e->frame_pyr = plane_off;
     e->frame_slots = (size_t)slot_off;
     e->sel_cap_total = sel_off;
@@ -1138,7 +1190,6 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
 #define RSV(buf, n) if ((rc = (buf).reserve(n)) != ORBGPU_OK) return rc
     RSV(e->d_geom, sizeof(LevelGeom) * nl);
     RSV(e->d_cells, sizeof(CellDesc) * cells.size());
-    RSV(e->d_tiles, sizeof(BlurTile) * tiles.size());
     RSV(e->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1));
     RSV(e->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1));
     RSV(e->d_pattern, 1024);
@@ -1155,7 +1206,6 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
 #undef RSV
     ORBGPU_HIP_TRY(hipMemcpy(e->d_geom.p, geom.data(), sizeof(LevelGeom) * nl, hipMemcpyHostToDevice));
     ORBGPU_HIP_TRY(hipMemcpy(e->d_cells.p, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
-    ORBGPU_HIP_TRY(hipMemcpy(e->d_tiles.p, tiles.data(), sizeof(BlurTile) * tiles.size(), hipMemcpyHostToDevice));
     if (!xtab.empty()) {
         ORBGPU_HIP_TRY(hipMemcpy(e->d_xtab.p, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice));
         ORBGPU_HIP_TRY(hipMemcpy(e->d_ytab.p, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice));
@@ -1216,8 +1266,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out);
     MARK(4);
-    hipLaunchKernelGGL(k_blur, dim3((unsigned)e->tiles.size(), batch), dim3(256), 0, st, pyr, blur, e->frame_pyr, dg,
-                       e->d_tiles.as<BlurTile>());
+    hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
+                       e->frame_pyr, dg, e->blur_geom);
     MARK(5);
     hipLaunchKernelGGL(k_describe, dim3((std::min(cap, e->max_kp) + 7) / 8, batch), dim3(256), 0, st, blur,
                        e->frame_pyr, dg, e->d_aux.as<KpAux>(), d_n_out, cap, e->d_pattern.as<int8_t>(), d_desc);
@@ -1277,7 +1327,7 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
         return ORBGPU_OK;
     (void)hipSetDevice(e->prm.device_id);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_tiles, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_pyr,
+    DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_pyr,
                       &e->d_blur, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
                       &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
     for (DevBuf *b : bufs)
