@@ -8,8 +8,10 @@
 // claimed by an earlier A row is invisible to later ones (:209-210, :232).  The GPU computes the
 // same result as the unique fixpoint of a triangular system: sweep s recomputes EVERY row in
 // parallel, hiding from row i the B rows claimed by rows < i in sweep s-1.  Row 0 is final after
-// sweep 0, row i after at most i+1 sweeps; in practice 2-4 sweeps suffice.  A sweep that changes
-// nothing proves convergence; a serial single-wave pass is the bounded fallback.
+// sweep 0, row i after at most i+1 sweeps; in practice 2-7 sweeps suffice and a sweep that changes
+// nothing proves convergence.  The all-pairs Hamming work is done ONCE (k_bf_topk keeps the 4 best B
+// rows of every A row); the sweeps (k_bf_resolve, one workgroup per pair, claim tables in LDS) only walk
+// those cached lists and fall back to an exact full scan of a row when its list cannot decide.
 #include "common.h"
 #include "matcher_common.h"
 
@@ -21,206 +23,230 @@ namespace orbgpu {
 
 constexpr int BF_ROWS_PER_WAVE = 8;
 constexpr int BF_ROWS_PER_BLOCK = 4 * BF_ROWS_PER_WAVE;
-constexpr int BF_MAX_SWEEPS = 12;
+constexpr int BF_TOPK = 4;
+constexpr uint32_t BF_KEY_NONE = 0xFFFFFFFFu;  // "no further candidate"
 
-struct Best2 {
-    int b1, i1, b2;
-};
+// key = distance << 12 | B index: ascending keys = the order in which the reference's sequential scan
+// would prefer candidates (smaller distance first, lower index first among equals)
+__device__ __forceinline__ uint32_t bf_key(int dist, int j) { return ((uint32_t)dist << 12) | (uint32_t)j; }
+__device__ __forceinline__ int bf_key_dist(uint32_t k) { return k == BF_KEY_NONE ? 256 : (int)(k >> 12); }
+__device__ __forceinline__ int bf_key_idx(uint32_t k) { return (int)(k & 0xFFFu); }
 
-__device__ __forceinline__ Best2 merge_best2(Best2 a, int ob1, int oi1, int ob2)
+__device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
 {
-    Best2 r;
-    const bool other_first = (ob1 < a.b1) || (ob1 == a.b1 && oi1 < a.i1);
-    r.b1 = other_first ? ob1 : a.b1;
-    r.i1 = other_first ? oi1 : a.i1;
-    r.b2 = min(min(a.b2, ob2), max(a.b1, ob1));
-    return r;
+    const uint32_t lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
 }
 
-__device__ __forceinline__ Best2 wave_best2(Best2 v)
+// insert into a sorted 4-list (keeps the 4 smallest)
+__device__ __forceinline__ void top4_insert(uint32_t t[4], uint32_t k)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int ob1 = __shfl_xor(v.b1, off, 64);
-        const int oi1 = __shfl_xor(v.i1, off, 64);
-        const int ob2 = __shfl_xor(v.b2, off, 64);
-        v = merge_best2(v, ob1, oi1, ob2);
+    if (k < t[3]) {
+        t[3] = k;
+        cswap(t[2], t[3]);
+        cswap(t[1], t[2]);
+        cswap(t[0], t[1]);
     }
-    return v;
 }
 
-// One sweep.  grid = (ceil(cap / BF_ROWS_PER_BLOCK), pairs).  Dynamic LDS: B descriptors as four
-// u64 planes (conflict-free ds_read_b64 per lane) + the claim table.
-__global__ __launch_bounds__(256) void k_bf_sweep(int sweep, int cap, const uint8_t *__restrict__ desc_a,
-                                                  const uint8_t *__restrict__ valid_a,
-                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
-                                                  const int *__restrict__ nb_p, int th_low, float nnratio,
-                                                  int *__restrict__ match_a, int *__restrict__ claim3,
-                                                  int *__restrict__ changed)
+// 4 smallest of two sorted 4-lists (bitonic split + sort)
+__device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
+{
+    uint32_t c0 = min(t[0], o[3]), c1 = min(t[1], o[2]), c2 = min(t[2], o[1]), c3 = min(t[3], o[0]);
+    cswap(c0, c2);
+    cswap(c1, c3);
+    cswap(c0, c1);
+    cswap(c2, c3);
+    cswap(c1, c2);
+    t[0] = c0;
+    t[1] = c1;
+    t[2] = c2;
+    t[3] = c3;
+}
+
+// Pass 1: for every A row the BF_TOPK best B rows over ALL B rows (claims are applied in pass 2).
+// grid = (ceil(cap / BF_ROWS_PER_BLOCK), pairs).  Dynamic LDS: B descriptors as four u64 planes
+// (conflict-free ds_read_b64 per lane).
+__global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
+                                                 const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
+                                                 const int *__restrict__ nb_p, uint32_t *__restrict__ topk)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     const int pair = blockIdx.y;
     const int na = min(na_p[pair], cap), nb = min(nb_p[pair], cap);
-    int *chg = changed + (size_t)pair * (BF_MAX_SWEEPS + 1);
-    if (sweep > 0 && chg[sweep - 1] == 0)
-        return;  // converged in an earlier sweep (match_a is final)
     const int row0 = blockIdx.x * BF_ROWS_PER_BLOCK;
-    int *c_rd = claim3 + ((size_t)pair * 3 + (sweep % 3)) * cap;
-    int *c_wr = claim3 + ((size_t)pair * 3 + ((sweep + 1) % 3)) * cap;
-    int *c_cl = claim3 + ((size_t)pair * 3 + ((sweep + 2) % 3)) * cap;
-    // clear the table sweep+1 will write (grid-strided over this pair's blocks)
-    for (int j = row0 + threadIdx.x; j < min(row0 + BF_ROWS_PER_BLOCK, cap); j += 256)
-        c_cl[j] = INT_MAX;
-    if (row0 >= na || na <= 0)
+    if (row0 >= na)
         return;
-
-    uint64_t *bplane = reinterpret_cast<uint64_t *>(smem);          // [4][nbp]
+    uint64_t *bplane = reinterpret_cast<uint64_t *>(smem);  // [4][nbp]
     const int nbp = (nb + 63) & ~63;
-    int *claim = reinterpret_cast<int *>(smem + (size_t)32 * nbp);  // [nbp]
     const uint64_t *gb = reinterpret_cast<const uint64_t *>(desc_b + (size_t)pair * cap * 32);
     for (int i = threadIdx.x; i < nb * 4; i += 256) {
         const int j = i >> 2, w = i & 3;
         bplane[w * nbp + j] = gb[i];
     }
-    for (int j = threadIdx.x; j < nb; j += 256)
-        claim[j] = c_rd[j];
     __syncthreads();
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t *ga = reinterpret_cast<const uint64_t *>(desc_a + (size_t)pair * cap * 32);
-    int *m = match_a + (size_t)pair * cap;
-    const uint8_t *va = valid_a ? valid_a + (size_t)pair * cap : nullptr;
-    int n_changed = 0;
+    uint32_t *tk = topk + (size_t)pair * cap * BF_TOPK;
     for (int r = 0; r < BF_ROWS_PER_WAVE; r++) {
         const int i = row0 + wave * BF_ROWS_PER_WAVE + r;
         if (i >= na)
             break;
-        int result = -1;
-        if (!va || va[i]) {
-            uint64_t a[4];
+        uint64_t a[4];
 #pragma unroll
-            for (int w = 0; w < 4; w++)
-                a[w] = ga[(size_t)i * 4 + w];
-            Best2 v{256, INT_MAX, 256};
-            for (int j = lane; j < nb; j += 64) {
-                if (claim[j] < i)
-                    continue;  // claimed by an earlier A row (:209-210)
-                const int d = __popcll(a[0] ^ bplane[j]) + __popcll(a[1] ^ bplane[nbp + j]) +
-                              __popcll(a[2] ^ bplane[2 * nbp + j]) + __popcll(a[3] ^ bplane[3 * nbp + j]);
-                if (d < v.b1) {
-                    v.b2 = v.b1;
-                    v.b1 = d;
-                    v.i1 = j;
-                } else if (d < v.b2) {
-                    v.b2 = d;
-                }
-            }
-            v = wave_best2(v);
-            // :228-231
-            if (v.b1 <= th_low && (float)v.b1 < nnratio * (float)v.b2)
-                result = v.i1;
+        for (int w = 0; w < 4; w++)
+            a[w] = ga[(size_t)i * 4 + w];
+        uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
+        for (int j = lane; j < nb; j += 64) {
+            const int d = __popcll(a[0] ^ bplane[j]) + __popcll(a[1] ^ bplane[nbp + j]) +
+                          __popcll(a[2] ^ bplane[2 * nbp + j]) + __popcll(a[3] ^ bplane[3 * nbp + j]);
+            top4_insert(t, bf_key(d, j));
         }
-        if (lane == 0) {
-            if (sweep == 0 || m[i] != result)
-                n_changed++;
-            m[i] = result;
-            if (result >= 0)
-                atomicMin(&c_wr[result], i);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                o[k] = (uint32_t)__shfl_xor((int)t[k], off, 64);
+            top4_merge(t, o);
         }
+        if (lane < 4)
+            tk[(size_t)i * BF_TOPK + lane] = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : t[3];
     }
-    if (lane == 0 && n_changed)
-        atomicAdd(&chg[sweep], n_changed);
 }
 
-// Bounded fallback: exact serial greedy pass by one wave per pair, only if the sweeps did not
-// converge.
-__global__ __launch_bounds__(64) void k_bf_serial(int cap, const uint8_t *__restrict__ desc_a,
-                                                  const uint8_t *__restrict__ valid_a,
-                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
-                                                  const int *__restrict__ nb_p, int th_low, float nnratio,
-                                                  int *__restrict__ match_a, int *__restrict__ claim3,
-                                                  int *__restrict__ changed)
+// Exact best/second over the B rows visible to A row i (full scan; used only when the cached top-K
+// list cannot decide).  One thread.
+__device__ void bf_full_scan(const uint64_t *__restrict__ ga, const uint64_t *__restrict__ gb, int i, int nb,
+                             const int *claim, int &b1, int &i1, int &b2)
 {
-    const int pair = blockIdx.x;
-    int *chg = changed + (size_t)pair * (BF_MAX_SWEEPS + 1);
-    if (chg[BF_MAX_SWEEPS - 1] == 0)
-        return;
-    const int na = min(na_p[pair], cap), nb = min(nb_p[pair], cap);
-    const int lane = threadIdx.x;
-    int *claimed = claim3 + (size_t)pair * 3 * cap;  // reuse table 0 as 0/1 flags
-    for (int j = lane; j < nb; j += 64)
-        claimed[j] = 0;
-    __syncthreads();
-    const uint64_t *ga = reinterpret_cast<const uint64_t *>(desc_a + (size_t)pair * cap * 32);
-    const uint64_t *gb = reinterpret_cast<const uint64_t *>(desc_b + (size_t)pair * cap * 32);
-    int *m = match_a + (size_t)pair * cap;
-    const uint8_t *va = valid_a ? valid_a + (size_t)pair * cap : nullptr;
-    for (int i = 0; i < na; i++) {
-        int result = -1;
-        if (!va || va[i]) {
-            uint64_t a[4];
-            for (int w = 0; w < 4; w++)
-                a[w] = ga[(size_t)i * 4 + w];
-            Best2 v{256, INT_MAX, 256};
-            for (int j = lane; j < nb; j += 64) {
-                if (claimed[j])
-                    continue;
-                uint64_t b[4];
-                for (int w = 0; w < 4; w++)
-                    b[w] = gb[(size_t)j * 4 + w];
-                const int d = hamming256(a, b);
-                if (d < v.b1) {
-                    v.b2 = v.b1;
-                    v.b1 = d;
-                    v.i1 = j;
-                } else if (d < v.b2) {
-                    v.b2 = d;
-                }
-            }
-            v = wave_best2(v);
-            if (v.b1 <= th_low && (float)v.b1 < nnratio * (float)v.b2)
-                result = v.i1;
+    uint64_t a[4] = {ga[(size_t)i * 4], ga[(size_t)i * 4 + 1], ga[(size_t)i * 4 + 2], ga[(size_t)i * 4 + 3]};
+    b1 = 256;
+    i1 = -1;
+    b2 = 256;
+    for (int j = 0; j < nb; j++) {
+        if (claim[j] < i)
+            continue;
+        uint64_t b[4] = {gb[(size_t)j * 4], gb[(size_t)j * 4 + 1], gb[(size_t)j * 4 + 2], gb[(size_t)j * 4 + 3]};
+        const int d = hamming256(a, b);
+        if (d < b1) {
+            b2 = b1;
+            b1 = d;
+            i1 = j;
+        } else if (d < b2) {
+            b2 = d;
         }
-        if (lane == 0) {
-            m[i] = result;
-            if (result >= 0)
-                claimed[result] = 1;
-        }
-        __syncthreads();  // single wave: orders the flag store before the next row's loads
     }
-    if (lane == 0)
-        chg[BF_MAX_SWEEPS] = 1;  // diagnostic: fallback used
 }
 
-// Scatter A->B matches, rotation-histogram consistency (:262-285), count.  One workgroup per pair.
-__global__ __launch_bounds__(256) void k_bf_finish(int cap, const int *__restrict__ na_p,
-                                                   const int *__restrict__ nb_p, const int *__restrict__ match_a,
-                                                   const uint8_t *__restrict__ angle_a,
-                                                   const uint8_t *__restrict__ angle_b, size_t angle_stride,
-                                                   int check_orientation, int *__restrict__ match_b,
-                                                   int *__restrict__ nmatches, const int *__restrict__ changed,
-                                                   int *__restrict__ sweeps_used)
+// Pass 2: the greedy claim order of the reference as a fixpoint, one workgroup per pair.  Every sweep
+// re-decides every A row in parallel from its cached candidate list, hiding the B rows that rows < i
+// claimed in the previous sweep (two claim tables in LDS).  Row i is final after at most i+1 sweeps and
+// a sweep without changes is the sequential result, so the loop (bounded by na+1) is always exact.
+// Then: scatter A->B, rotation-histogram consistency (ORBmatcher.cc:262-285), count.
+__global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__restrict__ desc_a,
+                                                     const uint8_t *__restrict__ valid_a,
+                                                     const int *__restrict__ na_p,
+                                                     const uint8_t *__restrict__ desc_b,
+                                                     const int *__restrict__ nb_p,
+                                                     const uint32_t *__restrict__ topk, int th_low, float nnratio,
+                                                     const uint8_t *__restrict__ angle_a,
+                                                     const uint8_t *__restrict__ angle_b, size_t angle_stride,
+                                                     int check_orientation, int *__restrict__ match_b,
+                                                     int *__restrict__ nmatches, int *__restrict__ sweeps_used)
 {
+    extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int histo[ORBGPU_HISTO_LENGTH];
     __shared__ int s_keep[3];
-    __shared__ int s_count;
+    __shared__ int s_count, s_changed;
     const int pair = blockIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int na = min(na_p[pair], cap), nb = min(nb_p[pair], cap);
-    const int *m = match_a + (size_t)pair * cap;
+    int *claimA = reinterpret_cast<int *>(smem);  // [cap] read
+    int *claimB = claimA + cap;                   // [cap] written
+    int *match = claimB + cap;                    // [cap]
+    const uint64_t *ga = reinterpret_cast<const uint64_t *>(desc_a + (size_t)pair * cap * 32);
+    const uint64_t *gb = reinterpret_cast<const uint64_t *>(desc_b + (size_t)pair * cap * 32);
+    const uint32_t *tk = topk + (size_t)pair * cap * BF_TOPK;
+    const uint8_t *va = valid_a ? valid_a + (size_t)pair * cap : nullptr;
     int *mb = match_b + (size_t)pair * cap;
-    const uint8_t *aa = angle_a + (size_t)pair * cap * angle_stride;
-    const uint8_t *ab = angle_b + (size_t)pair * cap * angle_stride;
-    for (int j = threadIdx.x; j < cap; j += 256)
+
+    for (int j = tid; j < cap; j += nt) {
+        claimA[j] = INT_MAX;
+        match[j] = -2;  // "undecided": differs from every possible result
+    }
+    __syncthreads();
+    int sweeps = 0;
+    for (int iter = 0; iter <= na + 1; iter++) {
+        for (int j = tid; j < nb; j += nt)
+            claimB[j] = INT_MAX;
+        if (tid == 0)
+            s_changed = 0;
+        __syncthreads();
+        bool changed = false;
+        for (int i = tid; i < na; i += nt) {
+            int result = -1;
+            if (!va || va[i]) {
+                const uint4 k4 = *reinterpret_cast<const uint4 *>(tk + (size_t)i * BF_TOPK);
+                const uint32_t key[4] = {k4.x, k4.y, k4.z, k4.w};
+                int b1 = 256, i1 = -1, b2 = 256, found = 0;
+                bool complete = false;  // list exhausted: every B row has been considered
+#pragma unroll
+                for (int k = 0; k < BF_TOPK; k++) {
+                    if (key[k] == BF_KEY_NONE) {
+                        complete = true;
+                    } else if (found < 2 && !(claimA[bf_key_idx(key[k])] < i)) {
+                        if (found == 0) {
+                            b1 = bf_key_dist(key[k]);
+                            i1 = bf_key_idx(key[k]);
+                        } else {
+                            b2 = bf_key_dist(key[k]);
+                        }
+                        found++;
+                    }
+                }
+                // a visible best that already fails the threshold needs no second distance
+                const bool decided = found == 2 || complete || (found == 1 && b1 > th_low);
+                if (!decided)
+                    bf_full_scan(ga, gb, i, nb, claimA, b1, i1, b2);
+                if (b1 <= th_low && (float)b1 < nnratio * (float)b2)  // ORBmatcher.cc:228-231
+                    result = i1;
+            }
+            if (match[i] != result) {
+                changed = true;
+                match[i] = result;
+            }
+            if (result >= 0)
+                atomicMin(&claimB[result], i);
+        }
+        if (changed)
+            s_changed = 1;
+        __syncthreads();
+        sweeps++;
+        const bool again = s_changed != 0;
+        __syncthreads();
+        if (!again)
+            break;
+        int *t = claimA;
+        claimA = claimB;
+        claimB = t;
+    }
+
+    // ---- finish
+    for (int j = tid; j < cap; j += nt)
         mb[j] = -1;
-    if (threadIdx.x < ORBGPU_HISTO_LENGTH)
-        histo[threadIdx.x] = 0;
-    if (threadIdx.x == 0)
+    if (tid < ORBGPU_HISTO_LENGTH)
+        histo[tid] = 0;
+    if (tid == 0)
         s_count = 0;
     __syncthreads();
+    const uint8_t *aa = angle_a + (size_t)pair * cap * angle_stride;
+    const uint8_t *ab = angle_b + (size_t)pair * cap * angle_stride;
     int cnt = 0;
-    for (int i = threadIdx.x; i < na; i += 256) {
-        const int j = m[i];
-        if (j < 0 || j >= nb)
+    for (int i = tid; i < na; i += nt) {
+        const int j = match[i];
+        if (j < 0)
             continue;
         cnt++;
         if (check_orientation) {
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(256) void k_bf_finish(int cap, const int *__restric
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         int i1 = -1, i2 = -1, i3 = -1;
         if (check_orientation)
             three_maxima(histo, ORBGPU_HISTO_LENGTH, i1, i2, i3);
@@ -239,9 +265,9 @@ __global__ __launch_bounds__(256) void k_bf_finish(int cap, const int *__restric
         s_keep[2] = i3;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < na; i += 256) {
-        const int j = m[i];
-        if (j < 0 || j >= nb)
+    for (int i = tid; i < na; i += nt) {
+        const int j = match[i];
+        if (j < 0)
             continue;
         bool keep = true;
         if (check_orientation) {
@@ -256,16 +282,12 @@ __global__ __launch_bounds__(256) void k_bf_finish(int cap, const int *__restric
             cnt--;
     }
     cnt = wave_reduce_add(cnt);
-    if ((threadIdx.x & 63) == 0)
+    if ((tid & 63) == 0)
         atomicAdd(&s_count, cnt);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         nmatches[pair] = s_count;
-        const int *chg = changed + (size_t)pair * (BF_MAX_SWEEPS + 1);
-        int s = 0;
-        while (s < BF_MAX_SWEEPS && chg[s] != 0)
-            s++;
-        sweeps_used[pair] = chg[BF_MAX_SWEEPS] ? -1 : s + 1;
+        sweeps_used[pair] = sweeps;
     }
 }
 
@@ -289,7 +311,7 @@ using namespace orbgpu;
 struct orbgpu_matcher {
     int device_id = 0;
     int max_pairs = 0, cap = 0;
-    DevBuf d_match_a, d_claim, d_changed, d_sweeps;
+    DevBuf d_topk, d_sweeps;
     int last_pairs = 0;
 };
 
@@ -311,15 +333,16 @@ int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orb
     m->max_pairs = max_pairs;
     m->cap = cap;
     const size_t P = (size_t)max_pairs;
-    if ((rc = m->d_match_a.reserve(sizeof(int) * P * cap)) != ORBGPU_OK ||
-        (rc = m->d_claim.reserve(sizeof(int) * P * 3 * cap)) != ORBGPU_OK ||
-        (rc = m->d_changed.reserve(sizeof(int) * P * (BF_MAX_SWEEPS + 1))) != ORBGPU_OK ||
+    if ((rc = m->d_topk.reserve(sizeof(uint32_t) * P * cap * BF_TOPK)) != ORBGPU_OK ||
         (rc = m->d_sweeps.reserve(sizeof(int) * P)) != ORBGPU_OK) {
         orbgpu_matcher_destroy(m);
         return rc;
     }
-    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_sweep),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 4096 + 256);
+    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_topk),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 4096 + 256);
+    if (he == hipSuccess)
+        he = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_resolve),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4096 + 256);
     if (he != hipSuccess) {
         set_error("hipFuncSetAttribute: %s", hipGetErrorString(he));
         orbgpu_matcher_destroy(m);
@@ -335,9 +358,7 @@ int orbgpu_matcher_destroy(orbgpu_matcher *m)
         return ORBGPU_OK;
     (void)hipSetDevice(m->device_id);
     (void)hipDeviceSynchronize();
-    m->d_match_a.release();
-    m->d_claim.release();
-    m->d_changed.release();
+    m->d_topk.release();
     m->d_sweeps.release();
     delete m;
     return ORBGPU_OK;
@@ -358,23 +379,14 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
     if (rc != ORBGPU_OK)
         return rc;
     hipStream_t st = (hipStream_t)hip_stream;
-    int *match_a = m->d_match_a.as<int>();
-    int *claim = m->d_claim.as<int>();
-    int *changed = m->d_changed.as<int>();
-    // tables 0 and 1 start empty (sweep 0 reads table 0 and writes table 1)
-    ORBGPU_HIP_TRY(hipMemsetAsync(claim, 0x7F, sizeof(int) * (size_t)pairs * 3 * cap, st));
-    ORBGPU_HIP_TRY(hipMemsetAsync(changed, 0, sizeof(int) * (size_t)pairs * (BF_MAX_SWEEPS + 1), st));
+    uint32_t *topk = m->d_topk.as<uint32_t>();
     const int nbp = (cap + 63) & ~63;
-    const size_t lds = (size_t)36 * nbp;
     const dim3 grid((cap + BF_ROWS_PER_BLOCK - 1) / BF_ROWS_PER_BLOCK, pairs);
-    for (int s = 0; s < BF_MAX_SWEEPS; s++)
-        hipLaunchKernelGGL(k_bf_sweep, grid, dim3(256), lds, st, s, cap, d_desc_a, d_valid_a, d_na, d_desc_b, d_nb,
-                           th_low, nnratio, match_a, claim, changed);
-    hipLaunchKernelGGL(k_bf_serial, dim3(pairs), dim3(64), 0, st, cap, d_desc_a, d_valid_a, d_na, d_desc_b, d_nb,
-                       th_low, nnratio, match_a, claim, changed);
-    hipLaunchKernelGGL(k_bf_finish, dim3(pairs), dim3(256), 0, st, cap, d_na, d_nb, match_a,
-                       reinterpret_cast<const uint8_t *>(d_angle_a), reinterpret_cast<const uint8_t *>(d_angle_b),
-                       angle_stride, check_orientation, d_match_b, d_nmatches, changed, m->d_sweeps.as<int>());
+    hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), (size_t)32 * nbp, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk);
+    hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), (size_t)12 * cap, st, cap, d_desc_a, d_valid_a, d_na,
+                       d_desc_b, d_nb, topk, th_low, nnratio, reinterpret_cast<const uint8_t *>(d_angle_a),
+                       reinterpret_cast<const uint8_t *>(d_angle_b), angle_stride, check_orientation, d_match_b,
+                       d_nmatches, m->d_sweeps.as<int>());
     ORBGPU_HIP_TRY(hipGetLastError());
     m->last_pairs = pairs;
     return ORBGPU_OK;

@@ -58,7 +58,7 @@ def test_bf_conflict_stress(gpu, oracle, seed, na, nb, ratio, th):
 
 def test_bf_adversarial_chain(gpu, oracle):
     """A chain of dependent claims: A row i prefers B row i-1 unless it is taken -> needs ~n sweeps,
-    exercising the serial fallback path."""
+    far more than the typical 2-7."""
     n = 120
     rng = np.random.default_rng(2)
     b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
@@ -125,7 +125,7 @@ def test_bf_batched_device_path(gpu, oracle, stream640):
     d = desc.cpu().numpy()
     mb = match_b.cpu().numpy()
     sweeps = bm.last_sweeps(B - 1)
-    assert np.all(sweeps > 0) and np.all(sweeps <= 12), sweeps
+    assert np.all(sweeps > 0) and np.all(sweeps <= 64), sweeps
     for p in range(B - 1):
         no, mo = oracle.match_bf(d[p, :n[p]], k[p, :n[p], 3], d[p + 1, :n[p + 1]], k[p + 1, :n[p + 1], 3], nnratio=0.7)
         assert int(nm[p]) == no
