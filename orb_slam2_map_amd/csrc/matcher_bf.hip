@@ -116,28 +116,40 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
     }
 }
 
-// Exact best/second over the B rows visible to A row i (full scan; used only when the cached top-K
-// list cannot decide).  One thread.
-__device__ void bf_full_scan(const uint64_t *__restrict__ ga, const uint64_t *__restrict__ gb, int i, int nb,
-                             const int *claim, int &b1, int &i1, int &b2)
+// Exact best/second over the B rows visible to A row i: full scan by one wave (lanes stride over the
+// B rows; ties resolve to the lower index exactly as the sequential scan does).  Used only when the
+// cached top-K list cannot decide.
+__device__ void bf_full_scan_wave(const uint64_t *__restrict__ ga, const uint64_t *__restrict__ gb, int i, int nb,
+                                  const int *claim, int &b1, int &i1, int &b2)
 {
+    const int lane = threadIdx.x & 63;
     uint64_t a[4] = {ga[(size_t)i * 4], ga[(size_t)i * 4 + 1], ga[(size_t)i * 4 + 2], ga[(size_t)i * 4 + 3]};
-    b1 = 256;
-    i1 = -1;
-    b2 = 256;
-    for (int j = 0; j < nb; j++) {
+    int v1 = 256, vi = INT_MAX, v2 = 256;
+    for (int j = lane; j < nb; j += 64) {
         if (claim[j] < i)
             continue;
         uint64_t b[4] = {gb[(size_t)j * 4], gb[(size_t)j * 4 + 1], gb[(size_t)j * 4 + 2], gb[(size_t)j * 4 + 3]};
         const int d = hamming256(a, b);
-        if (d < b1) {
-            b2 = b1;
-            b1 = d;
-            i1 = j;
-        } else if (d < b2) {
-            b2 = d;
+        if (d < v1) {
+            v2 = v1;
+            v1 = d;
+            vi = j;
+        } else if (d < v2) {
+            v2 = d;
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o1 = __shfl_xor(v1, off, 64), oi = __shfl_xor(vi, off, 64), o2 = __shfl_xor(v2, off, 64);
+        const bool other_first = (o1 < v1) || (o1 == v1 && oi < vi);
+        const int n2 = min(min(v2, o2), max(v1, o1));
+        v1 = other_first ? o1 : v1;
+        vi = other_first ? oi : vi;
+        v2 = n2;
+    }
+    b1 = v1;
+    i1 = vi == INT_MAX ? -1 : vi;
+    b2 = v2;
 }
 
 // Pass 2: the greedy claim order of the reference as a fixpoint, one workgroup per pair.  Every sweep
@@ -159,13 +171,14 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int histo[ORBGPU_HISTO_LENGTH];
     __shared__ int s_keep[3];
-    __shared__ int s_count, s_changed;
+    __shared__ int s_count, s_changed, s_nslow;
     const int pair = blockIdx.x;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int na = min(na_p[pair], cap), nb = min(nb_p[pair], cap);
     int *claimA = reinterpret_cast<int *>(smem);  // [cap] read
     int *claimB = claimA + cap;                   // [cap] written
     int *match = claimB + cap;                    // [cap]
+    int *slow = match + cap;                      // [cap] rows whose cached list cannot decide
     const uint64_t *ga = reinterpret_cast<const uint64_t *>(desc_a + (size_t)pair * cap * 32);
     const uint64_t *gb = reinterpret_cast<const uint64_t *>(desc_b + (size_t)pair * cap * 32);
     const uint32_t *tk = topk + (size_t)pair * cap * BF_TOPK;
@@ -181,12 +194,16 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
     for (int iter = 0; iter <= na + 1; iter++) {
         for (int j = tid; j < nb; j += nt)
             claimB[j] = INT_MAX;
-        if (tid == 0)
+        if (tid == 0) {
             s_changed = 0;
+            s_nslow = 0;
+        }
         __syncthreads();
         bool changed = false;
+        // (a) one thread per row: decide from the cached candidate list; undecidable rows are queued
         for (int i = tid; i < na; i += nt) {
             int result = -1;
+            bool decided = true;
             if (!va || va[i]) {
                 const uint4 k4 = *reinterpret_cast<const uint4 *>(tk + (size_t)i * BF_TOPK);
                 const uint32_t key[4] = {k4.x, k4.y, k4.z, k4.w};
@@ -207,11 +224,13 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
                     }
                 }
                 // a visible best that already fails the threshold needs no second distance
-                const bool decided = found == 2 || complete || (found == 1 && b1 > th_low);
-                if (!decided)
-                    bf_full_scan(ga, gb, i, nb, claimA, b1, i1, b2);
-                if (b1 <= th_low && (float)b1 < nnratio * (float)b2)  // ORBmatcher.cc:228-231
+                decided = found == 2 || complete || (found == 1 && b1 > th_low);
+                if (decided && b1 <= th_low && (float)b1 < nnratio * (float)b2)  // ORBmatcher.cc:228-231
                     result = i1;
+            }
+            if (!decided) {
+                slow[atomicAdd(&s_nslow, 1)] = i;
+                continue;
             }
             if (match[i] != result) {
                 changed = true;
@@ -219,6 +238,28 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
             }
             if (result >= 0)
                 atomicMin(&claimB[result], i);
+        }
+        __syncthreads();
+        // (b) one wave per queued row: exact full scan
+        {
+            const int nslow = s_nslow;
+            const int wave = tid >> 6, nw = nt >> 6;
+            for (int r = wave; r < nslow; r += nw) {
+                const int i = slow[r];
+                int b1, i1, b2;
+                bf_full_scan_wave(ga, gb, i, nb, claimA, b1, i1, b2);
+                if ((tid & 63) == 0) {
+                    int result = -1;
+                    if (b1 <= th_low && (float)b1 < nnratio * (float)b2)
+                        result = i1;
+                    if (match[i] != result) {
+                        changed = true;
+                        match[i] = result;
+                    }
+                    if (result >= 0)
+                        atomicMin(&claimB[result], i);
+                }
+            }
         }
         if (changed)
             s_changed = 1;
@@ -342,7 +383,7 @@ int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orb
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 4096 + 256);
     if (he == hipSuccess)
         he = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_resolve),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4096 + 256);
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096 + 256);
     if (he != hipSuccess) {
         set_error("hipFuncSetAttribute: %s", hipGetErrorString(he));
         orbgpu_matcher_destroy(m);
@@ -383,7 +424,7 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
     const int nbp = (cap + 63) & ~63;
     const dim3 grid((cap + BF_ROWS_PER_BLOCK - 1) / BF_ROWS_PER_BLOCK, pairs);
     hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), (size_t)32 * nbp, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk);
-    hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), (size_t)12 * cap, st, cap, d_desc_a, d_valid_a, d_na,
+    hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), (size_t)16 * cap, st, cap, d_desc_a, d_valid_a, d_na,
                        d_desc_b, d_nb, topk, th_low, nnratio, reinterpret_cast<const uint8_t *>(d_angle_a),
                        reinterpret_cast<const uint8_t *>(d_angle_b), angle_stride, check_orientation, d_match_b,
                        d_nmatches, m->d_sweeps.as<int>());
