@@ -138,166 +138,235 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: per-cell FAST-9/16 + 3x3 NMS + per-cell threshold fallback
+// K2: FAST-9/16 with NMS and per-cell threshold fallback
 //     (ORBextractor.cc:789-829 calling cv::FAST(sub, kps, th, true), A4)
 //
-// One 256-thread workgroup per (cell, frame).  The (cell+6)^2 sub-image is staged in LDS; phase A
-// tests the 9-of-16 arc condition at the lower threshold with bit masks; phase B computes the exact
-// corner score s (largest t such that the pixel is a corner for every threshold < s) only for the
-// compacted corner list; phase C applies the strict 3x3 NMS of cv::FAST restricted to the cell's
-// interior at iniThFAST and, if that leaves nothing, at minThFAST; survivors are written in
-// row-major order (cv::FAST's output order) with a ballot-based ordered compaction.
+// Two kernels.
+//  k_fast_score  -- the corner score map s(x,y) of every level: s = max over the 16 arcs of 9
+//     contiguous ring pixels of the minimum |centre - ring| (dark and bright polarity), clamped to
+//     [0,255].  A pixel is a FAST corner for threshold t  <=>  s > t, and cv::FAST's cornerScore is
+//     s-1, so one map serves both thresholds.  Register-only streaming like k_blur: a thread owns 4
+//     pixels x FS_ROWS rows, keeps a 7-row x 12-byte window in registers, unpacks ring bytes with
+//     v_perm_b32 into packed 16-bit lanes and runs the min/max network with v_pk_min/max_i16 (two
+//     pixels per instruction, no divergence, no LDS).
+//  k_fast_nms    -- one wave per 30-px cell: strict 3x3 non-maximum suppression restricted to the
+//     cell's interior (cv::FAST sees only the sub-image: neighbours outside count as 0) at iniThFAST
+//     and, if that leaves the cell empty, at minThFAST; survivors leave in row-major order (cv::FAST's
+//     output order, which the quadtree's "first maximum" rule depends on) via ballot ranks.
 // ---------------------------------------------------------------------------------------------
-constexpr int TP = 72;        // LDS tile pitch  (cell + 6 <= 72)
-constexpr int TROWS = 72;     // LDS tile rows
-constexpr int SP = 68;        // score map pitch (cell + 2)
+constexpr int FS_ROWS = 28;   // output rows per strip (4 x 7)
+constexpr int SP = 72;        // LDS score tile pitch (cell interior + 2 <= 68)
 constexpr int MAX_CELL = 66;  // max cell interior edge
 
-__device__ __forceinline__ bool has_arc9(uint32_t m16)
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 as_pk(uint32_t u) { return __builtin_bit_cast(pk16, u); }
+__device__ __forceinline__ uint32_t as_u32(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 pkmin(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ pk16 pkmax(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+
+// score of two pixels at once from their 16 packed ring differences d[k] = centre - ring[k]
+__device__ __forceinline__ pk16 fast_score_pk(const pk16 d[16])
 {
-    uint32_t x = m16 | (m16 << 16);
-    x &= x >> 1;
-    x &= x >> 2;
-    x &= x >> 4;
-    x &= x >> 1;
-    return (x & 0xFFFFu) != 0;
+    pk16 m2[16], m4[16], m8[16];
+    pk16 dark, bright;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m2[k] = pkmin(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m4[k] = pkmin(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m8[k] = pkmin(m4[k], m4[(k + 4) & 15]);
+    dark = pkmin(m8[0], d[8]);
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+        dark = pkmax(dark, pkmin(m8[k], d[(k + 8) & 15]));
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m2[k] = pkmax(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m4[k] = pkmax(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m8[k] = pkmax(m4[k], m4[(k + 4) & 15]);
+    bright = pkmax(m8[0], d[8]);
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+        bright = pkmin(bright, pkmax(m8[k], d[(k + 8) & 15]));
+    const pk16 zero = {0, 0};
+    return pkmax(pkmax(dark, zero - bright), zero);  // values are in [0,255]
 }
 
-// ring offsets (dx,dy), A4
-#define ORBGPU_RING(F)                                                                                       \
-    F(0, 0, 3) F(1, 1, 3) F(2, 2, 2) F(3, 3, 1) F(4, 3, 0) F(5, 3, -1) F(6, 2, -2) F(7, 1, -3) F(8, 0, -3)    \
-        F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
+// v_perm selectors that zero-extend bytes (o, o+2) resp. (o+1, o+3) of the 8-byte pair {lo,hi}
+#define ORBGPU_SEL_EVEN(o) ((uint32_t)(o) | 0x0c00u | ((uint32_t)((o) + 2) << 16) | 0x0c000000u)
+#define ORBGPU_SEL_ODD(o) ((uint32_t)((o) + 1) | 0x0c00u | ((uint32_t)((o) + 3) << 16) | 0x0c000000u)
 
-__device__ __forceinline__ int fast_score(const uint8_t *c)
+struct Row3 {
+    uint32_t d[3];  // 12 bytes of one padded row: columns 4c-4 .. 4c+7
+};
+
+// ring byte of output pixel p in row window R at horizontal offset dx: window byte 4 + p + dx
+template <int DX> __device__ __forceinline__ void ring_pair(const Row3 &R, pk16 &even, pk16 &odd)
 {
-    const int v = c[0];
-    int d[16];
-#define LD(i, dx, dy) d[i] = v - (int)c[(dy) * TP + (dx)];
-    ORBGPU_RING(LD)
-#undef LD
-    int m2[16], m4[16], m8[16];
-    int best_dark = -256, best_bright = -256;
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m2[k] = min(d[k], d[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m4[k] = min(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m8[k] = min(m4[k], m4[(k + 4) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        best_dark = max(best_dark, min(m8[k], d[(k + 8) & 15]));
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m2[k] = max(d[k], d[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m4[k] = max(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m8[k] = max(m4[k], m4[(k + 4) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        best_bright = max(best_bright, -max(m8[k], d[(k + 8) & 15]));
-    return max(best_dark, best_bright);
+    constexpr int s = 4 + DX, q = s >> 2, o = s & 3;
+    even = as_pk(__builtin_amdgcn_perm(R.d[q + 1], R.d[q], ORBGPU_SEL_EVEN(o)));
+    odd = as_pk(__builtin_amdgcn_perm(R.d[q + 1], R.d[q], ORBGPU_SEL_ODD(o)));
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, size_t frame_pyr,
-                                                    const LevelGeom *__restrict__ geom,
-                                                    const CellDesc *__restrict__ cells, int ncells_total,
-                                                    uint32_t *__restrict__ slots, size_t frame_slots,
-                                                    int *__restrict__ cell_cnt, int ini_th, int min_th)
+// scores of the 4 pixels of the strip in the row whose window is r3 (r0..r6 = rows y-3..y+3)
+__device__ __forceinline__ uint32_t fast_score_row(const Row3 &r0, const Row3 &r1, const Row3 &r2, const Row3 &r3,
+                                                   const Row3 &r4, const Row3 &r5, const Row3 &r6)
 {
-    __shared__ uint8_t tile[TP * TROWS];
-    __shared__ uint8_t smap[SP * SP];
-    __shared__ uint16_t clist[MAX_CELL * MAX_CELL];
-    __shared__ int s_ccount;
-    __shared__ int s_wave_cnt[4];
-    __shared__ int s_base;
+    pk16 ce, co, e[16], o[16];
+    ring_pair<0>(r3, ce, co);
+    // ring order A4: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+    ring_pair<0>(r6, e[0], o[0]);
+    ring_pair<1>(r6, e[1], o[1]);
+    ring_pair<2>(r5, e[2], o[2]);
+    ring_pair<3>(r4, e[3], o[3]);
+    ring_pair<3>(r3, e[4], o[4]);
+    ring_pair<3>(r2, e[5], o[5]);
+    ring_pair<2>(r1, e[6], o[6]);
+    ring_pair<1>(r0, e[7], o[7]);
+    ring_pair<0>(r0, e[8], o[8]);
+    ring_pair<-1>(r0, e[9], o[9]);
+    ring_pair<-2>(r1, e[10], o[10]);
+    ring_pair<-3>(r2, e[11], o[11]);
+    ring_pair<-3>(r3, e[12], o[12]);
+    ring_pair<-3>(r4, e[13], o[13]);
+    ring_pair<-2>(r5, e[14], o[14]);
+    ring_pair<-1>(r6, e[15], o[15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        e[k] = ce - e[k];
+        o[k] = co - o[k];
+    }
+    const pk16 se = fast_score_pk(e), so = fast_score_pk(o);
+    // bytes: px0 = se.lo, px1 = so.lo, px2 = se.hi, px3 = so.hi
+    return __builtin_amdgcn_perm(as_u32(so), as_u32(se), 0x06020400u);
+}
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const CellDesc cd = cells[blockIdx.x];
+struct StripGeom {  // strips of all levels, flattened (shared by k_blur and k_fast_score)
+    int first[ORBGPU_MAX_LEVELS + 1];  // first strip index of each level
+    int nsx[ORBGPU_MAX_LEVELS];        // strips per row of strips
+    int nlevels;
+};
+
+__global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ smap,
+                                                    size_t frame_pyr, const LevelGeom *__restrict__ geom,
+                                                    StripGeom sg)
+{
+    const int strip = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
+    if (strip >= sg.first[sg.nlevels])
+        return;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < ORBGPU_MAX_LEVELS; l++)
+        level += (l < sg.nlevels && strip >= sg.first[l]) ? 1 : 0;
+    const LevelGeom g = geom[level];
+    const int local = strip - sg.first[level];
+    const int sy = local / sg.nsx[level], sx = local - sy * sg.nsx[level];
+    // detection region: image x,y in [19, w-19) x [19, h-19)  ->  padded columns from 38: dword 9
+    const int col = (9 + sx) * 4;
+    const int y0 = EDGE + sy * FS_ROWS;  // first output row (image coordinates)
+    const int rows = min(FS_ROWS, g.h - EDGE - y0);
+    const size_t plane = (size_t)f * frame_pyr + g.plane_off;
+    const uint8_t *src = pyr + plane + (size_t)(y0 + EDGE - 3) * g.pitch + (col - 4);
+    uint8_t *dst = smap + plane + (size_t)(y0 + EDGE) * g.pitch + col;
+
+    Row3 r0, r1, r2, r3, r4, r5, r6;
+#define FS_LOAD(R, row)                                                                                      \
+    {                                                                                                        \
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);               \
+        R.d[0] = q[0];                                                                                       \
+        R.d[1] = q[1];                                                                                       \
+        R.d[2] = q[2];                                                                                       \
+    }
+#define FS_STEP(A, B, C, D, E, F, G, k)                                                                      \
+    if ((k) < rows) {                                                                                        \
+        FS_LOAD(G, (k) + 6)                                                                                  \
+        *reinterpret_cast<uint32_t *>(dst + (size_t)(k) * g.pitch) = fast_score_row(A, B, C, D, E, F, G);    \
+    }
+    FS_LOAD(r0, 0) FS_LOAD(r1, 1) FS_LOAD(r2, 2) FS_LOAD(r3, 3) FS_LOAD(r4, 4) FS_LOAD(r5, 5)
+#pragma unroll 1
+    for (int k = 0; k < FS_ROWS; k += 7) {
+        FS_STEP(r0, r1, r2, r3, r4, r5, r6, k)
+        FS_STEP(r1, r2, r3, r4, r5, r6, r0, k + 1)
+        FS_STEP(r2, r3, r4, r5, r6, r0, r1, k + 2)
+        FS_STEP(r3, r4, r5, r6, r0, r1, r2, k + 3)
+        FS_STEP(r4, r5, r6, r0, r1, r2, r3, k + 4)
+        FS_STEP(r5, r6, r0, r1, r2, r3, r4, k + 5)
+        FS_STEP(r6, r0, r1, r2, r3, r4, r5, k + 6)
+    }
+#undef FS_STEP
+#undef FS_LOAD
+}
+
+// One wave per (cell, frame); 4 cells per workgroup, no workgroup barrier (waves are independent).
+__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ smap, size_t frame_pyr,
+                                                  const LevelGeom *__restrict__ geom,
+                                                  const CellDesc *__restrict__ cells, int ncells_total,
+                                                  uint32_t *__restrict__ slots, size_t frame_slots,
+                                                  int *__restrict__ cell_cnt, int ini_th, int min_th)
+{
+    __shared__ uint8_t tiles[4][SP * (MAX_CELL + 2)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ci = blockIdx.x * 4 + wave;
+    const int f = blockIdx.y;
+    if (ci >= ncells_total)
+        return;
+    const CellDesc cd = cells[ci];
     const LevelGeom g = geom[cd.level];
-    const int tw = cd.x1 - cd.x0, th = cd.y1 - cd.y0;
-    const int iw = tw - 6, ih = th - 6;
-    int *out_cnt = cell_cnt + (size_t)f * ncells_total + blockIdx.x;
+    const int iw = cd.x1 - cd.x0 - 6, ih = cd.y1 - cd.y0 - 6;
+    int *out_cnt = cell_cnt + (size_t)f * ncells_total + ci;
     if (iw <= 0 || ih <= 0) {
-        if (tid == 0)
+        if (lane == 0)
             *out_cnt = 0;
         return;
     }
-    const uint8_t *src =
-        pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)(cd.y0 + EDGE) * g.pitch + (cd.x0 + EDGE);
-    for (int i = tid; i < tw * th; i += 256) {
-        int ty = i / tw, tx = i - ty * tw;
-        tile[ty * TP + tx] = src[(size_t)ty * g.pitch + tx];
+    uint8_t *tile = tiles[wave];
+    // zero ring + interior from the score map
+    const uint8_t *src = smap + (size_t)f * frame_pyr + g.plane_off + (size_t)(cd.y0 + 3 + EDGE) * g.pitch +
+                         (cd.x0 + 3 + EDGE);
+    const int tw = iw + 2, th = ih + 2;
+    const float inv_tw = 1.0f / (float)tw;
+    for (int i = lane; i < tw * th; i += 64) {
+        const int ty = (int)(((float)i + 0.5f) * inv_tw), tx = i - ty * tw;
+        uint8_t v = 0;
+        if (tx >= 1 && tx <= iw && ty >= 1 && ty <= ih)
+            v = src[(size_t)(ty - 1) * g.pitch + (tx - 1)];
+        tile[ty * SP + tx] = v;
     }
-    for (int i = tid; i < (ih + 2) * SP; i += 256)
-        smap[i] = 0;
-    if (tid == 0) {
-        s_ccount = 0;
-        s_base = 0;
-    }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- phase A: arc test at the lower of the two thresholds
-    const int tlow = min(ini_th, min_th);
-    const int npix = iw * ih;
-    for (int p = tid; p < npix; p += 256) {
-        int iy = p / iw, ix = p - iy * iw;
-        const uint8_t *c = &tile[(iy + 3) * TP + ix + 3];
-        const int v = c[0];
-        const int hi = v + tlow, lo = v - tlow;
-        uint32_t mb = 0, md = 0;
-#define TST(i, dx, dy)                                                                                       \
-    {                                                                                                        \
-        int q = c[(dy) * TP + (dx)];                                                                         \
-        mb |= (uint32_t)(q > hi) << i;                                                                       \
-        md |= (uint32_t)(q < lo) << i;                                                                       \
-    }
-        ORBGPU_RING(TST)
-#undef TST
-        if (has_arc9(mb) || has_arc9(md)) {
-            int slot = atomicAdd(&s_ccount, 1);
-            clist[slot] = (uint16_t)p;
-        }
-    }
-    __syncthreads();
-    // ---- phase B: exact score for the corner list
-    const int ccount = s_ccount;
-    for (int i = tid; i < ccount; i += 256) {
-        int p = clist[i];
-        int iy = p / iw, ix = p - iy * iw;
-        int s = fast_score(&tile[(iy + 3) * TP + ix + 3]);
-        smap[(iy + 1) * SP + ix + 1] = (uint8_t)s;
-    }
-    __syncthreads();
-
-    // ---- phase C: NMS + ordered compaction, iniThFAST first, minThFAST if the cell stays empty
     uint32_t *out = slots + (size_t)f * frame_slots + cd.slot_off;
+    const int npix = iw * ih;
+    const float inv_iw = 1.0f / (float)iw;
     int total = 0;
     for (int pass = 0; pass < 2; pass++) {
         const int thr = pass == 0 ? ini_th : min_th;
-        for (int chunk = 0; chunk < npix; chunk += 256) {
-            const int p = chunk + tid;
+        total = 0;
+        for (int chunk = 0; chunk < npix; chunk += 64) {
+            const int p = chunk + lane;
             bool keep = false;
-            int ix = 0, iy = 0, s = 0;
+            int ix = 0, iy = 0, sc = 0;
             if (p < npix) {
-                iy = p / iw;
+                iy = (int)(((float)p + 0.5f) * inv_iw);
                 ix = p - iy * iw;
-                const uint8_t *sm = &smap[(iy + 1) * SP + ix + 1];
-                s = sm[0];
-                if (s > thr) {
-                    const int r = s - 1;
+                const uint8_t *sm = &tile[(iy + 1) * SP + ix + 1];
+                sc = sm[0];
+                if (sc > thr) {
+                    const int r = sc - 1;
                     keep = true;
 #define NB(off)                                                                                              \
     {                                                                                                        \
-        int sn = sm[off];                                                                                    \
-        int vn = sn > thr ? sn - 1 : 0;                                                                      \
+        const int sn = sm[off];                                                                              \
+        const int vn = sn > thr ? sn - 1 : 0;                                                                \
         keep = keep && (r > vn);                                                                             \
     }
                     NB(-SP - 1) NB(-SP) NB(-SP + 1) NB(-1) NB(1) NB(SP - 1) NB(SP) NB(SP + 1)
@@ -305,29 +374,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
                 }
             }
             const unsigned long long bal = __ballot(keep);
-            if (lane == 0)
-                s_wave_cnt[wave] = __popcll(bal);
-            __syncthreads();
-            int off = s_base, chunk_total = 0;
-#pragma unroll
-            for (int w = 0; w < 4; w++) {
-                const int c = s_wave_cnt[w];
-                off += w < wave ? c : 0;
-                chunk_total += c;
-            }
-            off += __popcll(bal & ((1ull << lane) - 1ull));
+            const int off = total + __popcll(bal & ((1ull << lane) - 1ull));
             if (keep && off < cd.cap)
-                out[off] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, s - 1);
-            __syncthreads();  // everyone has read s_base / s_wave_cnt
-            if (tid == 0)
-                s_base += chunk_total;
+                out[off] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, sc - 1);
+            total += __popcll(bal);
         }
-        __syncthreads();
-        total = s_base;
         if (total > 0)
             break;
     }
-    if (tid == 0)
+    if (lane == 0)
         *out_cnt = total;
 }
 
@@ -804,12 +859,6 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
 // ---------------------------------------------------------------------------------------------
 constexpr int BLUR_ROWS = 28;  // output rows per strip (4 x 7: the 7-row register ring unrolls evenly)
 
-struct BlurGeom {  // strips of all levels, flattened
-    int first[ORBGPU_MAX_LEVELS + 1];  // first strip index of each level
-    int nsx[ORBGPU_MAX_LEVELS];        // strips per row of strips
-    int nlevels;
-};
-
 __device__ __forceinline__ void blur_hsum(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t h[4])
 {
     // window bytes 0..11 = padded columns 4s-4 .. 4s+7; output pixel p has its centre at byte 4+p
@@ -840,7 +889,7 @@ __device__ __forceinline__ uint32_t blur_vsum(const uint32_t r0[4], const uint32
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                              size_t frame_pyr, const LevelGeom *__restrict__ geom, BlurGeom bg)
+                                              size_t frame_pyr, const LevelGeom *__restrict__ geom, StripGeom bg)
 {
     const int strip = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
@@ -972,13 +1021,13 @@ struct orbgpu_extractor {
     int cfg_w = 0, cfg_h = 0, cfg_batch = 0;
     std::vector<LevelGeom> geom;
     std::vector<CellDesc> cells;
-    BlurGeom blur_geom;
+    StripGeom blur_geom, fast_geom;
     size_t frame_pyr = 0, frame_slots = 0;
     int sel_cap_total = 0, ncap = 0, max_kp = 0;
     size_t qt_lds = 0;
     // device state
     DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern;
-    DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
+    DevBuf d_pyr, d_blur, d_smap, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
     DevBuf d_in, d_kps, d_desc, d_nout;  // staging for the host entry points
     DevBuf d_dbg;
     hipStream_t stream = nullptr;
@@ -1161,7 +1210,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     e->geom = geom;
     e->cells = cells;
     {
-        BlurGeom &bgm = e->blur_geom;
+        StripGeom &bgm = e->blur_geom;
         memset(&bgm, 0, sizeof(bgm));
         bgm.nlevels = nl;
         int acc = 0;
@@ -1175,6 +1224,20 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         }
         for (int l = nl; l <= ORBGPU_MAX_LEVELS; l++)
             bgm.first[l] = acc;
+        // FAST score strips: padded dword columns 9 .. floor((w-1)/4), rows [19, h-19)
+        StripGeom &fg = e->fast_geom;
+        memset(&fg, 0, sizeof(fg));
+        fg.nlevels = nl;
+        acc = 0;
+        for (int l = 0; l < nl; l++) {
+            const int nsx = (geom[l].w - 1) / 4 - 9 + 1;
+            const int nsy = (geom[l].h - 2 * EDGE + FS_ROWS - 1) / FS_ROWS;
+            fg.first[l] = acc;
+            fg.nsx[l] = nsx;
+            acc += nsx * nsy;
+        }
+        for (int l = nl; l <= ORBGPU_MAX_LEVELS; l++)
+            fg.first[l] = acc;
     }
     e->frame_pyr = plane_off;
     e->frame_slots = (size_t)slot_off;
@@ -1196,6 +1259,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     const size_t B = (size_t)batch;
     RSV(e->d_pyr, e->frame_pyr * B);
     RSV(e->d_blur, e->frame_pyr * B);
+    RSV(e->d_smap, e->frame_pyr * B);
     RSV(e->d_slots, sizeof(uint32_t) * e->frame_slots * B);
     RSV(e->d_cellcnt, sizeof(int) * cells.size() * B);
     RSV(e->d_dkey, sizeof(uint32_t) * e->frame_slots * B);
@@ -1253,9 +1317,12 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
         }
     }
     MARK(1);
-    hipLaunchKernelGGL(k_fast_cells, dim3((unsigned)e->cells.size(), batch), dim3(256), 0, st, pyr, e->frame_pyr, dg,
-                       e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
-                       e->d_cellcnt.as<int>(), e->prm.ini_th_fast, e->prm.min_th_fast);
+    hipLaunchKernelGGL(k_fast_score, dim3((e->fast_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr,
+                       e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->fast_geom);
+    hipLaunchKernelGGL(k_fast_nms, dim3(((unsigned)e->cells.size() + 3) / 4, batch), dim3(256), 0, st,
+                       e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->d_cells.as<CellDesc>(), (int)e->cells.size(),
+                       e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(), e->prm.ini_th_fast,
+                       e->prm.min_th_fast);
     MARK(2);
     hipLaunchKernelGGL(k_quadtree, dim3(nl, batch), dim3(256), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
@@ -1328,7 +1395,7 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
     (void)hipSetDevice(e->prm.device_id);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_pyr,
-                      &e->d_blur, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
+                      &e->d_blur, &e->d_smap, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
                       &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
     for (DevBuf *b : bufs)
         b->release();
