@@ -155,7 +155,6 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 //     output order, which the quadtree's "first maximum" rule depends on) via ballot ranks.
 // ---------------------------------------------------------------------------------------------
 constexpr int FS_ROWS = 28;   // output rows per strip (4 x 7)
-constexpr int SP = 72;        // LDS score tile pitch (cell interior + 2 <= 68)
 constexpr int MAX_CELL = 66;  // max cell interior edge
 
 typedef short pk16 __attribute__((ext_vector_type(2)));
@@ -306,13 +305,18 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
 }
 
 // One wave per (cell, frame); 4 cells per workgroup, no workgroup barrier (waves are independent).
+// The cell's scores are staged in LDS with aligned dword loads: lane = (row of 3, dword column of 20),
+// bytes outside the cell interior are masked to 0 (cv::FAST sees only the sub-image).
+constexpr int NT_DW = 20;            // LDS tile pitch in dwords: 4 pad + (66 + 3 alignment) bytes + 1 ring
+constexpr int NT_PITCH = NT_DW * 4;  // bytes
+
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ smap, size_t frame_pyr,
                                                   const LevelGeom *__restrict__ geom,
                                                   const CellDesc *__restrict__ cells, int ncells_total,
                                                   uint32_t *__restrict__ slots, size_t frame_slots,
                                                   int *__restrict__ cell_cnt, int ini_th, int min_th)
 {
-    __shared__ uint8_t tiles[4][SP * (MAX_CELL + 2)];
+    __shared__ __align__(16) uint8_t tiles[4][NT_PITCH * (MAX_CELL + 2)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci = blockIdx.x * 4 + wave;
     const int f = blockIdx.y;
@@ -328,17 +332,32 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ sm
         return;
     }
     uint8_t *tile = tiles[wave];
-    // zero ring + interior from the score map
-    const uint8_t *src = smap + (size_t)f * frame_pyr + g.plane_off + (size_t)(cd.y0 + 3 + EDGE) * g.pitch +
-                         (cd.x0 + 3 + EDGE);
-    const int tw = iw + 2, th = ih + 2;
-    const float inv_tw = 1.0f / (float)tw;
-    for (int i = lane; i < tw * th; i += 64) {
-        const int ty = (int)(((float)i + 0.5f) * inv_tw), tx = i - ty * tw;
-        uint8_t v = 0;
-        if (tx >= 1 && tx <= iw && ty >= 1 && ty <= ih)
-            v = src[(size_t)(ty - 1) * g.pitch + (tx - 1)];
-        tile[ty * SP + tx] = v;
+    // interior = padded columns [xs, xe), padded rows [ys, ys+ih); tile column 0 <-> padded column xa-4
+    const int xs = cd.x0 + 3 + EDGE, xe = xs + iw, ys = cd.y0 + 3 + EDGE;
+    const int xa = xs & ~3;
+    const int toff = xs - xa + 4;  // tile column of interior pixel ix = 0
+    const uint8_t *src = smap + (size_t)f * frame_pyr + g.plane_off;
+    {
+        const int lr = lane / NT_DW, dc = lane - lr * NT_DW;  // 3 rows x 20 dwords per step (lanes 60..63 idle)
+        const int col = xa - 4 + dc * 4;                      // padded column of this dword
+        // byte mask of the interior columns inside this dword
+        const int lo = min(max(xs - col, 0), 4), hi = min(max(xe - col, 0), 4);
+        uint32_t mask = 0;
+        if (hi > lo)
+            mask = (0xFFFFFFFFu >> (8 * (4 - hi))) & (0xFFFFFFFFu << (8 * lo));
+        const int th = ih + 2;
+#pragma unroll 4
+        for (int ty0 = 0; ty0 < MAX_CELL + 2; ty0 += 3) {
+            const int ty = ty0 + lr;
+            if (ty0 >= th)
+                break;
+            if (lr < 3 && ty < th) {
+                uint32_t v = 0;
+                if (mask != 0 && ty >= 1 && ty <= ih)
+                    v = *reinterpret_cast<const uint32_t *>(src + (size_t)(ys + ty - 1) * g.pitch + col) & mask;
+                *reinterpret_cast<uint32_t *>(tile + ty * NT_PITCH + dc * 4) = v;
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ sm
             if (p < npix) {
                 iy = (int)(((float)p + 0.5f) * inv_iw);
                 ix = p - iy * iw;
-                const uint8_t *sm = &tile[(iy + 1) * SP + ix + 1];
+                const uint8_t *sm = &tile[(iy + 1) * NT_PITCH + ix + toff];
                 sc = sm[0];
                 if (sc > thr) {
                     const int r = sc - 1;
@@ -369,7 +388,8 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ sm
         const int vn = sn > thr ? sn - 1 : 0;                                                                \
         keep = keep && (r > vn);                                                                             \
     }
-                    NB(-SP - 1) NB(-SP) NB(-SP + 1) NB(-1) NB(1) NB(SP - 1) NB(SP) NB(SP + 1)
+                    NB(-NT_PITCH - 1) NB(-NT_PITCH) NB(-NT_PITCH + 1) NB(-1) NB(1) NB(NT_PITCH - 1) NB(NT_PITCH)
+                        NB(NT_PITCH + 1)
 #undef NB
                 }
             }
@@ -734,7 +754,6 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelGeom *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 // K4: orientation + key-point assembly
 //     (IC_Angle :77-104, fastAtan2 A5, fix-up :837-847, scaling :1095-1101)
-// One wave per selected key point: lanes cover two rows of the radius-15 disc per step.
 // ---------------------------------------------------------------------------------------------
 struct KpAux {
     int x, y, level;
@@ -768,6 +787,11 @@ struct UMax {
     int v[16];
 };
 
+// Half a wave (32 lanes) per selected key point, lane = one row v of the radius-15 disc.  A lane
+// reads its row as 9 aligned dwords and reduces it with v_dot4_u32_u8 against per-(alignment, |v|)
+// byte-weight tables built once per workgroup in LDS: W10 holds (u+16) inside the disc (0 outside),
+// M01 holds 1 inside the disc, so  sum u*I = dot(W10) - 16*dot(M01)  and  sum I = dot(M01).
+// Integer moments: exact in any summation order.
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                 const LevelGeom *__restrict__ geom, int nlevels,
                                                 const uint32_t *__restrict__ sel, int sel_cap_total,
@@ -775,8 +799,26 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
                                                 orbgpu_keypoint *__restrict__ kps, KpAux *__restrict__ aux,
                                                 int cap, int *__restrict__ n_out)
 {
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t W10[4 * 16 * 9], M01[4 * 16 * 9];
+    for (int i = threadIdx.x; i < 4 * 16 * 9; i += 256) {
+        const int a = i / (16 * 9), av = (i / 9) % 16, j = i % 9;
+        uint32_t w = 0, m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int u = 4 * j + k - a - HALF_PATCH;
+            const int au = u < 0 ? -u : u;
+            if (au <= um.v[av]) {
+                w |= (uint32_t)(u + 16) << (8 * k);
+                m |= 1u << (8 * k);
+            }
+        }
+        W10[i] = w;
+        M01[i] = m;
+    }
+    __syncthreads();
+
+    const int hl = threadIdx.x & 31;  // lane inside the half wave = disc row index
+    const int slot = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int f = blockIdx.y;
     const int *ns = nsel + (size_t)f * nlevels;
     // locate (level, j) of this slot and the output offset
@@ -794,33 +836,38 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         }
         total += max(c, 0);
     }
-    if (slot == 0 && lane == 0)
+    if (slot == 0 && hl == 0)
         n_out[f] = bad ? -1 - total : (total > cap ? -1 - total : total);
     if (level < 0 || bad || total > cap || j >= ns[level])
         return;
     const LevelGeom g = geom[level];
     const uint32_t key = sel[(size_t)f * sel_cap_total + g.sel_off + j];
     const int x = key_x(key) + BORDER0, y = key_y(key) + BORDER0;
-    const uint8_t *center = pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)(y + EDGE) * g.pitch + (x + EDGE);
-
+    const int xl = x + EDGE - HALF_PATCH;  // leftmost padded column of the disc
+    const int a = xl & 3;
+    const int v = hl - HALF_PATCH;         // rows -15..15 (lane 31 idles)
     int m10 = 0, m01 = 0;
-    const int u = (lane & 31) - HALF_PATCH;
+    if (hl < 31) {
+        const int av = v < 0 ? -v : v;
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(
+            pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)(y + EDGE + v) * g.pitch + (xl - a));
+        const uint32_t *w = &W10[(a * 16 + av) * 9], *m = &M01[(a * 16 + av) * 9];
+        uint32_t sw = 0, sm = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int v = 2 * r + (lane >> 5) - HALF_PATCH;
-        if (v <= HALF_PATCH && (lane & 31) < 31) {
-            const int av = v < 0 ? -v : v;
-            const int au = u < 0 ? -u : u;
-            if (au <= um.v[av]) {
-                const int val = center[v * g.pitch + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
+        for (int q = 0; q < 9; q++) {
+            const uint32_t d = row[q];
+            sw = __builtin_amdgcn_udot4(d, w[q], sw, false);
+            sm = __builtin_amdgcn_udot4(d, m[q], sm, false);
         }
+        m10 = (int)sw - 16 * (int)sm;
+        m01 = v * (int)sm;
     }
-    m10 = wave_reduce_add(m10);
-    m01 = wave_reduce_add(m01);
-    if (lane == 0) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+        m10 += __shfl_xor(m10, off, 64);
+        m01 += __shfl_xor(m01, off, 64);
+    }
+    if (hl == 0) {
         const float angle = fast_atan2_deg((float)m01, (float)m10);
         orbgpu_keypoint kp;
         kp.x = (float)x;
@@ -835,12 +882,12 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         kp.octave = level;
         kp.class_id = -1;
         kps[(size_t)f * cap + out_off + j] = kp;
-        KpAux a;
-        a.x = x;
-        a.y = y;
-        a.level = level;
-        a.angle = angle;
-        aux[(size_t)f * cap + out_off + j] = a;
+        KpAux ax;
+        ax.x = x;
+        ax.y = y;
+        ax.level = level;
+        ax.angle = angle;
+        aux[(size_t)f * cap + out_off + j] = ax;
     }
 }
 
@@ -1329,7 +1376,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(), e->d_sel.as<uint32_t>(),
                        e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
     MARK(3);
-    hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 3) / 4, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
+    hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 7) / 8, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out);
     MARK(4);
