@@ -37,6 +37,7 @@ struct LevelGeom {
     float scale;
     int patch;
     int xtab_off, ytab_off;  // resize tables (levels >= 1)
+    int rs_off, rs_fast;     // fast-path strip tables (k_resize_fast); rs_fast = 0 -> k_resize_level
 };
 
 struct CellDesc {
@@ -135,6 +136,55 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
         v |= (uint32_t)(o & 0xFF) << (8 * k);
     }
     *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + x4) = v;
+}
+
+// Fast path of K1b: one thread per aligned output dword (4 pixels) of the padded plane.  The 8 source
+// bytes the 4 outputs need per source row lie inside one 12-byte aligned window (true for scale
+// factors <= 2; checked on the host, otherwise k_resize_level runs), which is fetched with 3 dword
+// loads; v_perm_b32 with host-precomputed selectors forms (left tap | right tap << 16) pairs and
+// v_dot2_u32_u16 applies the 11-bit weights.  Same integer arithmetic as k_resize_level.
+struct ResizeStrip {  // per padded output dword column of a level
+    uint32_t base_q;  // bits 0..15: window base (padded source column, multiple of 4); bits 16..19: pair select
+};
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, size_t frame_pyr,
+                                                     const LevelGeom *__restrict__ geom, int level,
+                                                     const ResizeStrip *__restrict__ strips,
+                                                     const uint4 *__restrict__ sels, const uint4 *__restrict__ wts,
+                                                     const YTab *__restrict__ ytab, int strip_off)
+{
+    const LevelGeom g = geom[level];
+    const LevelGeom gs = geom[level - 1];
+    const int sdw = blockIdx.x * 256 + threadIdx.x;  // output dword column
+    const int py = blockIdx.y;
+    const int f = blockIdx.z;
+    if (sdw * 4 >= g.pitch)
+        return;
+    const int dy = reflect101(py - EDGE, g.h);
+    const YTab yt = ytab[g.ytab_off + dy];
+    const uint32_t bq = strips[strip_off + sdw].base_q;
+    const uint4 sel = sels[strip_off + sdw], wt = wts[strip_off + sdw];
+    const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + (bq & 0xFFFFu);
+    const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + (size_t)(yt.sy0 + EDGE) * gs.pitch);
+    const uint32_t *S1 = reinterpret_cast<const uint32_t *>(base + (size_t)(yt.sy1 + EDGE) * gs.pitch);
+    const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
+    const uint32_t c0 = S1[0], c1 = S1[1], c2 = S1[2];
+    const uint32_t selv[4] = {sel.x, sel.y, sel.z, sel.w}, wv[4] = {wt.x, wt.y, wt.z, wt.w};
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool q = (bq >> (16 + k)) & 1u;
+        const uint32_t p0 = __builtin_amdgcn_perm(q ? a2 : a1, q ? a1 : a0, selv[k]);
+        const uint32_t p1 = __builtin_amdgcn_perm(q ? c2 : c1, q ? c1 : c0, selv[k]);
+        const us2 w = __builtin_bit_cast(us2, wv[k]);
+        const int t0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), w, 0u, false);
+        const int t1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), w, 0u, false);
+        const int o = ((((int)yt.b0 * (t0 >> 4)) >> 16) + (((int)yt.b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        v |= (uint32_t)(o & 0xFF) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + sdw * 4) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1073,7 +1123,7 @@ struct orbgpu_extractor {
     int sel_cap_total = 0, ncap = 0, max_kp = 0;
     size_t qt_lds = 0;
     // device state
-    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern;
+    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt;
     DevBuf d_pyr, d_blur, d_smap, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
     DevBuf d_in, d_kps, d_desc, d_nout;  // staging for the host entry points
     DevBuf d_dbg;
@@ -1139,6 +1189,8 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     std::vector<CellDesc> cells;
     std::vector<XTab> xtab;
     std::vector<YTab> ytab;
+    std::vector<ResizeStrip> rstrip;
+    std::vector<uint4> rsel, rwt;
     size_t plane_off = 0;
     int slot_off = 0, sel_off = 0, max_cells_level = 0, ncap = 0;
     for (int l = 0; l < nl; l++) {
@@ -1245,6 +1297,38 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
                 t.b1 = sat_short(cv_round_host(fy * 2048));
                 ytab.push_back(t);
             }
+            // fast-path strip tables: one entry per aligned output dword of the padded row
+            g.rs_off = (int)rstrip.size();
+            g.rs_fast = 1;
+            for (int sdw = 0; sdw < g.pitch / 4; sdw++) {
+                int cl[4], cr[4];
+                const XTab *xt[4];
+                int mn = 1 << 30;
+                for (int k = 0; k < 4; k++) {
+                    const int px = std::min(sdw * 4 + k, g.w + 2 * EDGE - 1);
+                    const int dx = reflect101(px - EDGE, g.w);
+                    xt[k] = &xtab[g.xtab_off + dx];
+                    cl[k] = xt[k]->sx + EDGE;
+                    cr[k] = xt[k]->sx1 + EDGE;
+                    mn = std::min(mn, cl[k]);
+                }
+                const int wbase = mn & ~3;
+                ResizeStrip rsx;
+                rsx.base_q = (uint32_t)wbase;
+                uint32_t sel[4], wt[4];
+                for (int k = 0; k < 4; k++) {
+                    const int ol = cl[k] - wbase, orr = cr[k] - wbase;
+                    if (ol < 0 || orr < ol || orr > 11)
+                        g.rs_fast = 0;
+                    const int q = ol >= 4 ? 1 : 0;
+                    rsx.base_q |= (uint32_t)q << (16 + k);
+                    sel[k] = (uint32_t)((ol - 4 * q) & 7) | 0x0c00u | ((uint32_t)((orr - 4 * q) & 7) << 16) | 0x0c000000u;
+                    wt[k] = (uint32_t)xt[k]->a0 | ((uint32_t)xt[k]->a1 << 16);
+                }
+                rstrip.push_back(rsx);
+                rsel.push_back(uint4{sel[0], sel[1], sel[2], sel[3]});
+                rwt.push_back(uint4{wt[0], wt[1], wt[2], wt[3]});
+            }
         }
     }
     ncap = std::max(ncap, (max_cells_level + 3) / 4);  // the cell scan reuses the [ncap*4] child-count array
@@ -1302,6 +1386,9 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_cells, sizeof(CellDesc) * cells.size());
     RSV(e->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1));
     RSV(e->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1));
+    RSV(e->d_rstrip, sizeof(ResizeStrip) * std::max<size_t>(rstrip.size(), 1));
+    RSV(e->d_rsel, sizeof(uint4) * std::max<size_t>(rsel.size(), 1));
+    RSV(e->d_rwt, sizeof(uint4) * std::max<size_t>(rwt.size(), 1));
     RSV(e->d_pattern, 1024);
     const size_t B = (size_t)batch;
     RSV(e->d_pyr, e->frame_pyr * B);
@@ -1320,6 +1407,9 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     if (!xtab.empty()) {
         ORBGPU_HIP_TRY(hipMemcpy(e->d_xtab.p, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice));
         ORBGPU_HIP_TRY(hipMemcpy(e->d_ytab.p, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpy(e->d_rstrip.p, rstrip.data(), sizeof(ResizeStrip) * rstrip.size(), hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpy(e->d_rsel.p, rsel.data(), sizeof(uint4) * rsel.size(), hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpy(e->d_rwt.p, rwt.data(), sizeof(uint4) * rwt.size(), hipMemcpyHostToDevice));
     }
     ORBGPU_HIP_TRY(hipMemcpy(e->d_pattern.p, k_pattern_host, 1024, hipMemcpyHostToDevice));
     // the blurred planes are only written inside the image; define the rest once
@@ -1359,8 +1449,13 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
         for (int l = 1; l < nl; l++) {
             const LevelGeom &gl = e->geom[l];
             dim3 gr((gl.pitch / 4 + 255) / 256, gl.h + 2 * EDGE, batch);
-            hipLaunchKernelGGL(k_resize_level, gr, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
-                               e->d_xtab.as<XTab>(), e->d_ytab.as<YTab>());
+            if (gl.rs_fast)
+                hipLaunchKernelGGL(k_resize_fast, gr, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
+                                   e->d_rstrip.as<ResizeStrip>(), e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(),
+                                   e->d_ytab.as<YTab>(), gl.rs_off);
+            else
+                hipLaunchKernelGGL(k_resize_level, gr, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
+                                   e->d_xtab.as<XTab>(), e->d_ytab.as<YTab>());
         }
     }
     MARK(1);
@@ -1441,7 +1536,8 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
         return ORBGPU_OK;
     (void)hipSetDevice(e->prm.device_id);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_pyr,
+    DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_rstrip, &e->d_rsel,
+                      &e->d_rwt, &e->d_pyr,
                       &e->d_blur, &e->d_smap, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
                       &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
     for (DevBuf *b : bufs)
