@@ -471,6 +471,7 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ sm
 // reference compares heap addresses, which is not deterministic; the oracle uses the same rule).
 // ---------------------------------------------------------------------------------------------
 struct QtShared {
+    int *ccnt_next;     // [ncap*4] child key counts of the list being built (fused relabel + count)
     int *ccnt;          // [ncap*4] child key counts (also: cell scan, best-key scratch)
     int *sa, *sb;       // scan scratch
     uint16_t *cpos;     // [ncap*4] new list position of child q
@@ -525,7 +526,7 @@ __device__ int block_excl_scan(int *a, int n, int *s_tmp /*>= 8 ints*/)
     return total;
 }
 
-__global__ __launch_bounds__(256) void k_quadtree(const LevelGeom *__restrict__ geom,
+__global__ __launch_bounds__(512) void k_quadtree(const LevelGeom *__restrict__ geom,
                                                   const CellDesc *__restrict__ cells, int ncells_total,
                                                   const uint32_t *__restrict__ slots, size_t frame_slots,
                                                   const int *__restrict__ cell_cnt,
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelGeom *__restrict__ 
         cntA = (int *)p; p += sizeof(int) * ncap;
         cntB = (int *)p; p += sizeof(int) * ncap;
         S.ccnt = (int *)p; p += sizeof(int) * ncap * 4;
+        S.ccnt_next = (int *)p; p += sizeof(int) * ncap * 4;
         S.sa = (int *)p; p += sizeof(int) * ncap;
         S.sb = (int *)p; p += sizeof(int) * ncap;
         S.cpos = (uint16_t *)p; p += sizeof(uint16_t) * ncap * 4;
@@ -621,12 +623,24 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelGeom *__restrict__ 
         s_done = 0;
     }
     __syncthreads();
+    for (int i = tid; i < 4 * n_ini; i += nt)
+        S.ccnt_next[i] = 0;
+    __syncthreads();
     for (int i = tid; i < nkeys; i += nt) {
-        int b = (int)((float)key_x(dkey[i]) / hx);
+        const uint32_t key = dkey[i];
+        int b = (int)((float)key_x(key) / hx);
         b = min(max(b, 0), n_ini - 1);
-        dnode[i] = (uint16_t)S.sa[b];
+        const int nd = S.sa[b];
+        dnode[i] = (uint16_t)nd;
+        if (cntA[nd] > 1)
+            atomicAdd(&S.ccnt_next[nd * 4 + quadrant_of(key, bndA[nd])], 1);
     }
     __syncthreads();
+    {
+        int *t = S.ccnt;
+        S.ccnt = S.ccnt_next;
+        S.ccnt_next = t;
+    }
 
     // ---- passes
     for (int iter = 0; iter < 64; iter++) {
@@ -634,16 +648,8 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelGeom *__restrict__ 
         const int phase = s_phase;
         if (s_done || n == 0)
             break;
-        // (1) child key counts of every node with >1 keys
-        for (int i = tid; i < n * 4; i += nt)
-            S.ccnt[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < nkeys; i += nt) {
-            const int nd = dnode[i];
-            if (cntA[nd] > 1)
-                atomicAdd(&S.ccnt[nd * 4 + quadrant_of(dkey[i], bndA[nd])], 1);
-        }
-        __syncthreads();
+        // (1) S.ccnt already holds the child key counts of every node with >1 keys: they are
+        //     accumulated by the key loop of the previous pass (or of the initial assignment)
 
         // (2) processing order of the expandable nodes
         for (int p = tid; p < n; p += nt)
@@ -759,20 +765,42 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelGeom *__restrict__ 
             atomicAdd(&s_nexp, my_exp);
         __syncthreads();
 
-        // (6) re-label the keys
-        for (int i = tid; i < nkeys; i += nt) {
-            const int nd = dnode[i];
-            dnode[i] = S.inE[nd] ? S.cpos[nd * 4 + quadrant_of(dkey[i], bndA[nd])] : S.opos[nd];
-        }
-        __syncthreads();
-
-        // (7) termination / phase switch (:669-673, :733-734)
+        // (6) termination / phase switch (:669-673, :733-734), decided before the key loop so that a
+        //     final pass does not count children
         if (tid == 0) {
             s_n = n2;
             if (n2 >= N || n2 == n)
                 s_done = 1;
             else if (phase == 1 && n2 + 3 * s_nexp > N)
                 s_phase = 2;
+        }
+        for (int i = tid; i < n2 * 4; i += nt)
+            S.ccnt_next[i] = 0;
+        __syncthreads();
+        const bool count_next = s_done == 0;
+
+        // (7) re-label the keys and, in the same sweep, count the children of the NEW list's nodes
+        for (int i0 = tid; i0 < nkeys; i0 += 2 * nt) {
+            const int i1 = i0 + nt;
+            const bool has1 = i1 < nkeys;
+            const int nd0 = dnode[i0], nd1 = has1 ? dnode[i1] : 0;
+            const uint32_t k0 = dkey[i0], k1 = has1 ? dkey[i1] : 0u;
+            const int nn0 = S.inE[nd0] ? S.cpos[nd0 * 4 + quadrant_of(k0, bndA[nd0])] : S.opos[nd0];
+            dnode[i0] = (uint16_t)nn0;
+            if (count_next && cntB[nn0] > 1)
+                atomicAdd(&S.ccnt_next[nn0 * 4 + quadrant_of(k0, bndB[nn0])], 1);
+            if (has1) {
+                const int nn1 = S.inE[nd1] ? S.cpos[nd1 * 4 + quadrant_of(k1, bndA[nd1])] : S.opos[nd1];
+                dnode[i1] = (uint16_t)nn1;
+                if (count_next && cntB[nn1] > 1)
+                    atomicAdd(&S.ccnt_next[nn1 * 4 + quadrant_of(k1, bndB[nn1])], 1);
+            }
+        }
+        __syncthreads();
+        {
+            int *t = S.ccnt;
+            S.ccnt = S.ccnt_next;
+            S.ccnt_next = t;
         }
         {
             short4 *tb = bndA; bndA = bndB; bndB = tb;
@@ -808,6 +836,8 @@ __global__ __launch_bounds__(256) void k_quadtree(const LevelGeom *__restrict__ 
 struct KpAux {
     int x, y, level;
     float angle;
+    float ca, sb;  // (float)cos / (float)sin of the angle in radians, evaluated in double (k_trig)
+    int pad0, pad1;
 };
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -941,6 +971,22 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     }
 }
 
+// computeOrbDescriptor's  a = (float)cos(angle), b = (float)sin(angle)  (ORBextractor.cc:112-113): the
+// float angle in radians is promoted to double for libm's cos/sin and the result rounded to float.
+// One thread per key point so the double-precision evaluation is amortised over 64 key points per wave.
+__global__ __launch_bounds__(256) void k_trig(KpAux *__restrict__ aux, const int *__restrict__ n_out, int cap)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out[f])
+        return;
+    KpAux *a = aux + (size_t)f * cap + i;
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float angle = a->angle * factorPI;
+    a->ca = (float)cos((double)angle);
+    a->sb = (float)sin((double)angle);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K5: GaussianBlur(7x7, sigma 2, REFLECT_101), OpenCV 2.4 8-bit fixed-point path (A3).
 // taps x256 = [18,34,49,55,49,34,18]; dst = sat_u8((sum_y sum_x k_y k_x p + 32768) >> 16).  Integer
@@ -1059,9 +1105,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     const int byte = threadIdx.x & 31;
     const KpAux a = aux[(size_t)f * cap + kpi];
     const LevelGeom g = geom[a.level];
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float angle = a.angle * factorPI;
-    const float ca = (float)cos((double)angle), sb = (float)sin((double)angle);
+    const float ca = a.ca, sb = a.sb;
     const uint8_t *center = blur + (size_t)f * frame_pyr + g.plane_off + (size_t)(a.y + EDGE) * g.pitch + (a.x + EDGE);
     const int8_t *p = &pat[byte * 32];
     int val = 0;
@@ -1333,7 +1377,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     }
     ncap = std::max(ncap, (max_cells_level + 3) / 4);  // the cell scan reuses the [ncap*4] child-count array
     ncap = ((ncap + 7) / 8) * 8;
-    const size_t qt_lds = (size_t)ncap * (2 * sizeof(short4) + 2 * sizeof(int) + 4 * sizeof(int) + 2 * sizeof(int) +
+    const size_t qt_lds = (size_t)ncap * (2 * sizeof(short4) + 2 * sizeof(int) + 8 * sizeof(int) + 2 * sizeof(int) +
                                           4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1) + 64;
     ORBGPU_REQUIRE(qt_lds <= 160 * 1024 - 1024, "nfeatures too large for the quadtree kernel (needs %zu B of LDS)", qt_lds);
     ORBGPU_REQUIRE((size_t)slot_off < (1u << 23), "too many FAST key slots per frame");
@@ -1466,7 +1510,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(), e->prm.ini_th_fast,
                        e->prm.min_th_fast);
     MARK(2);
-    hipLaunchKernelGGL(k_quadtree, dim3(nl, batch), dim3(256), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
+    hipLaunchKernelGGL(k_quadtree, dim3(nl, batch), dim3(512), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
                        e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(), e->d_sel.as<uint32_t>(),
                        e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
@@ -1474,6 +1518,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 7) / 8, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out);
+    hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
+                       e->d_aux.as<KpAux>(), d_n_out, cap);
     MARK(4);
     hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
                        e->frame_pyr, dg, e->blur_geom);
