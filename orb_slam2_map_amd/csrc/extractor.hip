@@ -92,11 +92,18 @@ __global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src
     const int sy = reflect101(py - EDGE, g.h);
     const uint8_t *s = src + (size_t)f * frame_stride + (size_t)sy * stride;
     uint32_t v = 0;
+    const int sx0 = x4 - EDGE;  // source column of the first of the 4 output pixels
+    if (sx0 >= 0 && sx0 + 7 < g.w && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
+        // interior: two aligned source dwords + v_alignbyte (the 19-px border shifts rows by 3 bytes)
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s) + (sx0 >> 2);
+        v = __builtin_amdgcn_alignbyte(s32[1], s32[0], sx0 & 3);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int px = min(x4 + k, g.w + 2 * EDGE - 1);
-        int sx = reflect101(px - EDGE, g.w);
-        v |= (uint32_t)s[sx] << (8 * k);
+        for (int k = 0; k < 4; k++) {
+            int px = min(x4 + k, g.w + 2 * EDGE - 1);
+            int sx = reflect101(px - EDGE, g.w);
+            v |= (uint32_t)s[sx] << (8 * k);
+        }
     }
     *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + x4) = v;
 }
@@ -1093,10 +1100,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
                                                   int cap, const int8_t *__restrict__ pattern,
                                                   uint8_t *__restrict__ desc)
 {
-    __shared__ __align__(16) int8_t pat[1024];
-    for (int i = threadIdx.x; i < 256; i += 256)
-        reinterpret_cast<uint32_t *>(pat)[i] = reinterpret_cast<const uint32_t *>(pattern)[i];
-    __syncthreads();
     const int f = blockIdx.y;
     const int n = n_out[f];
     const int kpi = blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -1105,14 +1108,17 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     const int byte = threadIdx.x & 31;
     const KpAux a = aux[(size_t)f * cap + kpi];
     const LevelGeom g = geom[a.level];
+    // this lane's 8 tests = 32 pattern bytes (x0,y0,x1,y1 per test), L1-resident table
+    const uint4 pq0 = reinterpret_cast<const uint4 *>(pattern)[byte * 2];
+    const uint4 pq1 = reinterpret_cast<const uint4 *>(pattern)[byte * 2 + 1];
+    const uint32_t pw[8] = {pq0.x, pq0.y, pq0.z, pq0.w, pq1.x, pq1.y, pq1.z, pq1.w};
     const float ca = a.ca, sb = a.sb;
     const uint8_t *center = blur + (size_t)f * frame_pyr + g.plane_off + (size_t)(a.y + EDGE) * g.pitch + (a.x + EDGE);
-    const int8_t *p = &pat[byte * 32];
     int val = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const float x0 = (float)p[4 * k], y0 = (float)p[4 * k + 1];
-        const float x1 = (float)p[4 * k + 2], y1 = (float)p[4 * k + 3];
+        const float x0 = (float)(int8_t)(pw[k] & 0xFF), y0 = (float)(int8_t)((pw[k] >> 8) & 0xFF);
+        const float x1 = (float)(int8_t)((pw[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pw[k] >> 24);
         const int r0 = __float2int_rn(x0 * sb + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sb);
         const int r1 = __float2int_rn(x1 * sb + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sb);
         const int t0 = center[r0 * g.pitch + c0];

@@ -67,7 +67,10 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 
 // Pass 1: for every A row the BF_TOPK best B rows over ALL B rows (claims are applied in pass 2).
 // grid = (ceil(cap / BF_ROWS_PER_BLOCK), pairs).  Dynamic LDS: B descriptors as four u64 planes
-// (conflict-free ds_read_b64 per lane).
+// (conflict-free ds_read_b64 per lane).  Register blocking: a wave carries BF_RB A rows at once, so
+// every B descriptor fetched from LDS (32 B per lane) is used for BF_RB distances.
+constexpr int BF_RB = 4;
+
 __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
                                                  const int *__restrict__ nb_p, uint32_t *__restrict__ topk)
@@ -89,30 +92,45 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t *ga = reinterpret_cast<const uint64_t *>(desc_a + (size_t)pair * cap * 32);
     uint32_t *tk = topk + (size_t)pair * cap * BF_TOPK;
-    for (int r = 0; r < BF_ROWS_PER_WAVE; r++) {
-        const int i = row0 + wave * BF_ROWS_PER_WAVE + r;
-        if (i >= na)
+    for (int r = 0; r < BF_ROWS_PER_WAVE; r += BF_RB) {
+        const int i0 = row0 + wave * BF_ROWS_PER_WAVE + r;
+        if (i0 >= na)
             break;
-        uint64_t a[4];
+        uint64_t a[BF_RB][4];
+        uint32_t t[BF_RB][4];
 #pragma unroll
-        for (int w = 0; w < 4; w++)
-            a[w] = ga[(size_t)i * 4 + w];
-        uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
-        for (int j = lane; j < nb; j += 64) {
-            const int d = __popcll(a[0] ^ bplane[j]) + __popcll(a[1] ^ bplane[nbp + j]) +
-                          __popcll(a[2] ^ bplane[2 * nbp + j]) + __popcll(a[3] ^ bplane[3 * nbp + j]);
-            top4_insert(t, bf_key(d, j));
-        }
+        for (int q = 0; q < BF_RB; q++) {
+            const int i = min(i0 + q, na - 1);  // rows past the end repeat the last row (results discarded)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            uint32_t o[4];
+            for (int w = 0; w < 4; w++)
+                a[q][w] = ga[(size_t)i * 4 + w];
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                o[k] = (uint32_t)__shfl_xor((int)t[k], off, 64);
-            top4_merge(t, o);
+                t[q][k] = BF_KEY_NONE;
         }
-        if (lane < 4)
-            tk[(size_t)i * BF_TOPK + lane] = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : t[3];
+        for (int j = lane; j < nb; j += 64) {
+            const uint64_t b0 = bplane[j], b1 = bplane[nbp + j], b2 = bplane[2 * nbp + j], b3 = bplane[3 * nbp + j];
+#pragma unroll
+            for (int q = 0; q < BF_RB; q++) {
+                const int d = __popcll(a[q][0] ^ b0) + __popcll(a[q][1] ^ b1) + __popcll(a[q][2] ^ b2) +
+                              __popcll(a[q][3] ^ b3);
+                top4_insert(t[q], bf_key(d, j));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BF_RB; q++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    o[k] = (uint32_t)__shfl_xor((int)t[q][k], off, 64);
+                top4_merge(t[q], o);
+            }
+            if (lane < 4 && i0 + q < na)
+                tk[(size_t)(i0 + q) * BF_TOPK + lane] =
+                    lane == 0 ? t[q][0] : lane == 1 ? t[q][1] : lane == 2 ? t[q][2] : t[q][3];
+        }
     }
 }
 
