@@ -79,33 +79,41 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len)
 // ---------------------------------------------------------------------------------------------
 // K1a: level 0 = copyMakeBorder(image, REFLECT_101)           (ORBextractor.cc:1125-1129, A6)
 // ---------------------------------------------------------------------------------------------
+constexpr int PYR_ROWS = 8;  // padded rows per thread in the pyramid kernels
+
 __global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src, size_t stride,
                                                  size_t frame_stride, uint8_t *__restrict__ pyr,
                                                  size_t frame_pyr, const LevelGeom *__restrict__ geom)
 {
     const LevelGeom g = geom[0];
     const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int py = blockIdx.y;
     const int f = blockIdx.z;
     if (x4 >= g.pitch)
         return;
-    const int sy = reflect101(py - EDGE, g.h);
-    const uint8_t *s = src + (size_t)f * frame_stride + (size_t)sy * stride;
-    uint32_t v = 0;
     const int sx0 = x4 - EDGE;  // source column of the first of the 4 output pixels
-    if (sx0 >= 0 && sx0 + 7 < g.w && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
-        // interior: two aligned source dwords + v_alignbyte (the 19-px border shifts rows by 3 bytes)
-        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s) + (sx0 >> 2);
-        v = __builtin_amdgcn_alignbyte(s32[1], s32[0], sx0 & 3);
-    } else {
+    const bool interior = sx0 >= 0 && sx0 + 7 < g.w;
+#pragma unroll 4
+    for (int rr = 0; rr < PYR_ROWS; rr++) {
+        const int py = blockIdx.y * PYR_ROWS + rr;
+        if (py >= g.h + 2 * EDGE)
+            break;
+        const int sy = reflect101(py - EDGE, g.h);
+        const uint8_t *s = src + (size_t)f * frame_stride + (size_t)sy * stride;
+        uint32_t v = 0;
+        if (interior && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
+            // interior: two aligned source dwords + v_alignbyte (the 19-px border shifts rows by 3 bytes)
+            const uint32_t *s32 = reinterpret_cast<const uint32_t *>(s) + (sx0 >> 2);
+            v = __builtin_amdgcn_alignbyte(s32[1], s32[0], sx0 & 3);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int px = min(x4 + k, g.w + 2 * EDGE - 1);
-            int sx = reflect101(px - EDGE, g.w);
-            v |= (uint32_t)s[sx] << (8 * k);
+            for (int k = 0; k < 4; k++) {
+                int px = min(x4 + k, g.w + 2 * EDGE - 1);
+                int sx = reflect101(px - EDGE, g.w);
+                v |= (uint32_t)s[sx] << (8 * k);
+            }
         }
+        *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + x4) = v;
     }
-    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + x4) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -165,33 +173,39 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     const LevelGeom g = geom[level];
     const LevelGeom gs = geom[level - 1];
     const int sdw = blockIdx.x * 256 + threadIdx.x;  // output dword column
-    const int py = blockIdx.y;
     const int f = blockIdx.z;
     if (sdw * 4 >= g.pitch)
         return;
-    const int dy = reflect101(py - EDGE, g.h);
-    const YTab yt = ytab[g.ytab_off + dy];
     const uint32_t bq = strips[strip_off + sdw].base_q;
     const uint4 sel = sels[strip_off + sdw], wt = wts[strip_off + sdw];
-    const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + (bq & 0xFFFFu);
-    const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + (size_t)(yt.sy0 + EDGE) * gs.pitch);
-    const uint32_t *S1 = reinterpret_cast<const uint32_t *>(base + (size_t)(yt.sy1 + EDGE) * gs.pitch);
-    const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
-    const uint32_t c0 = S1[0], c1 = S1[1], c2 = S1[2];
     const uint32_t selv[4] = {sel.x, sel.y, sel.z, sel.w}, wv[4] = {wt.x, wt.y, wt.z, wt.w};
-    uint32_t v = 0;
+    const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + (bq & 0xFFFFu);
+    uint8_t *dst = pyr + (size_t)f * frame_pyr + g.plane_off + sdw * 4;
+#pragma unroll 2
+    for (int rr = 0; rr < PYR_ROWS; rr++) {
+        const int py = blockIdx.y * PYR_ROWS + rr;
+        if (py >= g.h + 2 * EDGE)
+            break;
+        const int dy = reflect101(py - EDGE, g.h);
+        const YTab yt = ytab[g.ytab_off + dy];
+        const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + (size_t)(yt.sy0 + EDGE) * gs.pitch);
+        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(base + (size_t)(yt.sy1 + EDGE) * gs.pitch);
+        const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
+        const uint32_t c0 = S1[0], c1 = S1[1], c2 = S1[2];
+        uint32_t v = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const bool q = (bq >> (16 + k)) & 1u;
-        const uint32_t p0 = __builtin_amdgcn_perm(q ? a2 : a1, q ? a1 : a0, selv[k]);
-        const uint32_t p1 = __builtin_amdgcn_perm(q ? c2 : c1, q ? c1 : c0, selv[k]);
-        const us2 w = __builtin_bit_cast(us2, wv[k]);
-        const int t0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), w, 0u, false);
-        const int t1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), w, 0u, false);
-        const int o = ((((int)yt.b0 * (t0 >> 4)) >> 16) + (((int)yt.b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-        v |= (uint32_t)(o & 0xFF) << (8 * k);
+        for (int k = 0; k < 4; k++) {
+            const bool q = (bq >> (16 + k)) & 1u;
+            const uint32_t p0 = __builtin_amdgcn_perm(q ? a2 : a1, q ? a1 : a0, selv[k]);
+            const uint32_t p1 = __builtin_amdgcn_perm(q ? c2 : c1, q ? c1 : c0, selv[k]);
+            const us2 w = __builtin_bit_cast(us2, wv[k]);
+            const int t0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), w, 0u, false);
+            const int t1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), w, 0u, false);
+            const int o = ((((int)yt.b0 * (t0 >> 4)) >> 16) + (((int)yt.b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            v |= (uint32_t)(o & 0xFF) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(dst + (size_t)py * g.pitch) = v;
     }
-    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + sdw * 4) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -220,37 +234,45 @@ __device__ __forceinline__ uint32_t as_u32(pk16 v) { return __builtin_bit_cast(u
 __device__ __forceinline__ pk16 pkmin(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ pk16 pkmax(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
 
-// score of two pixels at once from their 16 packed ring differences d[k] = centre - ring[k]
+// score of two pixels at once from their 16 packed ring differences d[k] = centre - ring[k].
+// The 16 circular windows of 9 are evaluated with block prefix/suffix extrema (van Herk): the ring is
+// split into two blocks of 8; window [k, k+8] = suffix of k's block from k  +  prefix of the next block
+// up to k+8, so min9[k] = min(S[k], P[(k+8) & 15]).  59 packed ops per polarity instead of 79.
 __device__ __forceinline__ pk16 fast_score_pk(const pk16 d[16])
 {
-    pk16 m2[16], m4[16], m8[16];
-    pk16 dark, bright;
+    pk16 P[16], S[16];
+    // ---- dark arcs: max over windows of the minimum
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        m2[k] = pkmin(d[k], d[(k + 1) & 15]);
+    for (int b = 0; b < 16; b += 8) {
+        P[b] = d[b];
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        m4[k] = pkmin(m2[k], m2[(k + 2) & 15]);
+        for (int i = 1; i < 8; i++)
+            P[b + i] = pkmin(P[b + i - 1], d[b + i]);
+        S[b + 7] = d[b + 7];
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        m8[k] = pkmin(m4[k], m4[(k + 4) & 15]);
-    dark = pkmin(m8[0], d[8]);
-#pragma unroll
-    for (int k = 1; k < 16; k++)
-        dark = pkmax(dark, pkmin(m8[k], d[(k + 8) & 15]));
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m2[k] = pkmax(d[k], d[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m4[k] = pkmax(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m8[k] = pkmax(m4[k], m4[(k + 4) & 15]);
-    bright = pkmax(m8[0], d[8]);
+        for (int i = 6; i >= 0; i--)
+            S[b + i] = pkmin(S[b + i + 1], d[b + i]);
+    }
+    pk16 dark = pkmin(S[0], P[8]);
 #pragma unroll
     for (int k = 1; k < 16; k++)
-        bright = pkmin(bright, pkmax(m8[k], d[(k + 8) & 15]));
+        dark = pkmax(dark, pkmin(S[k], P[(k + 8) & 15]));
+    // ---- bright arcs: min over windows of the maximum (negated afterwards)
+#pragma unroll
+    for (int b = 0; b < 16; b += 8) {
+        P[b] = d[b];
+#pragma unroll
+        for (int i = 1; i < 8; i++)
+            P[b + i] = pkmax(P[b + i - 1], d[b + i]);
+        S[b + 7] = d[b + 7];
+#pragma unroll
+        for (int i = 6; i >= 0; i--)
+            S[b + i] = pkmax(S[b + i + 1], d[b + i]);
+    }
+    pk16 bright = pkmax(S[0], P[8]);
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+        bright = pkmin(bright, pkmax(S[k], P[(k + 8) & 15]));
     const pk16 zero = {0, 0};
     return pkmax(pkmax(dark, zero - bright), zero);  // values are in [0,255]
 }
@@ -1494,13 +1516,14 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     MARK(0);
     {
         const LevelGeom &g = e->geom[0];
-        dim3 grid((g.pitch / 4 + 255) / 256, g.h + 2 * EDGE, batch);
+        dim3 grid((g.pitch / 4 + 255) / 256, (g.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
         hipLaunchKernelGGL(k_border0, grid, dim3(256), 0, st, d_gray, stride, frame_stride, pyr, e->frame_pyr, dg);
         for (int l = 1; l < nl; l++) {
             const LevelGeom &gl = e->geom[l];
             dim3 gr((gl.pitch / 4 + 255) / 256, gl.h + 2 * EDGE, batch);
+            dim3 grf((gl.pitch / 4 + 255) / 256, (gl.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
             if (gl.rs_fast)
-                hipLaunchKernelGGL(k_resize_fast, gr, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
+                hipLaunchKernelGGL(k_resize_fast, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
                                    e->d_rstrip.as<ResizeStrip>(), e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(),
                                    e->d_ytab.as<YTab>(), gl.rs_off);
             else
