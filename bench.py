@@ -43,8 +43,10 @@ def algorithmic_bytes(stage, n_kp, n_cand):
     tot = sum(PYR_PX)
     if stage == "pyramid":
         return sum(PYR_PX[:-1]) + sum(PYR_PX[1:])  # R levels 0..6 + W levels 1..7 = 1 569 878 B
-    if stage == "fast":
-        return tot  # every level read once; outputs negligible
+    if stage == "fast_score":
+        return tot  # every level read once (the score map it writes is an intermediate, not counted)
+    if stage == "fast_nms":
+        return tot + 4 * n_cand  # score map read once + surviving keys written
     if stage == "blur":
         return 2 * tot
     if stage == "orient":

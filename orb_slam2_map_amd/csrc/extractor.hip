@@ -363,12 +363,23 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         R.d[1] = q[1];                                                                                       \
         R.d[2] = q[2];                                                                                       \
     }
+#define FS_FETCH(row)                                                                                        \
+    {                                                                                                        \
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);               \
+        nx.d[0] = q[0];                                                                                      \
+        nx.d[1] = q[1];                                                                                      \
+        nx.d[2] = q[2];                                                                                      \
+    }
 #define FS_STEP(A, B, C, D, E, F, G, k)                                                                      \
     if ((k) < rows) {                                                                                        \
-        FS_LOAD(G, (k) + 6)                                                                                  \
+        G = nx;                                                                                              \
+        if ((k) + 1 < rows)                                                                                  \
+            FS_FETCH((k) + 7)                                                                                \
         *reinterpret_cast<uint32_t *>(dst + (size_t)(k) * g.pitch) = fast_score_row(A, B, C, D, E, F, G);    \
     }
+    Row3 nx;  // next input row, fetched one step ahead
     FS_LOAD(r0, 0) FS_LOAD(r1, 1) FS_LOAD(r2, 2) FS_LOAD(r3, 3) FS_LOAD(r4, 4) FS_LOAD(r5, 5)
+    FS_FETCH(6)
 #pragma unroll 1
     for (int k = 0; k < FS_ROWS; k += 7) {
         FS_STEP(r0, r1, r2, r3, r4, r5, r6, k)
@@ -380,6 +391,7 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
         FS_STEP(r6, r0, r1, r2, r3, r4, r5, k + 6)
     }
 #undef FS_STEP
+#undef FS_FETCH
 #undef FS_LOAD
 }
 
@@ -1083,17 +1095,28 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     uint8_t *dst = blur + plane + (size_t)(y0 + EDGE) * g.pitch + col;
 
     uint32_t r0[4], r1[4], r2[4], r3[4], r4[4], r5[4], r6[4];
+    uint32_t n0, n1, n2;  // raw dwords of the next input row, fetched one step ahead
 #define BLUR_LOAD(R, row)                                                                                    \
     {                                                                                                        \
         const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);               \
         blur_hsum(q[0], q[1], q[2], R);                                                                      \
     }
+#define BLUR_FETCH(row)                                                                                      \
+    {                                                                                                        \
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);               \
+        n0 = q[0];                                                                                           \
+        n1 = q[1];                                                                                           \
+        n2 = q[2];                                                                                           \
+    }
 #define BLUR_STEP(A, B, C, D, E, F, G, k)                                                                    \
     if ((k) < rows) {                                                                                        \
-        BLUR_LOAD(G, (k) + 6)                                                                                \
+        blur_hsum(n0, n1, n2, G);                                                                            \
+        if ((k) + 1 < rows)                                                                                  \
+            BLUR_FETCH((k) + 7)                                                                              \
         *reinterpret_cast<uint32_t *>(dst + (size_t)(k) * g.pitch) = blur_vsum(A, B, C, D, E, F, G);         \
     }
     BLUR_LOAD(r0, 0) BLUR_LOAD(r1, 1) BLUR_LOAD(r2, 2) BLUR_LOAD(r3, 3) BLUR_LOAD(r4, 4) BLUR_LOAD(r5, 5)
+    BLUR_FETCH(6)
 #pragma unroll 1
     for (int k = 0; k < BLUR_ROWS; k += 7) {
         BLUR_STEP(r0, r1, r2, r3, r4, r5, r6, k)
@@ -1105,6 +1128,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         BLUR_STEP(r6, r0, r1, r2, r3, r4, r5, k + 6)
     }
 #undef BLUR_STEP
+#undef BLUR_FETCH
 #undef BLUR_LOAD
 }
 
@@ -1169,8 +1193,9 @@ static const int8_t k_pattern_host[1024] = {
 #include "orbgpu_pattern.inc"
 };
 
-enum Stage { ST_PYRAMID = 0, ST_FAST, ST_QUADTREE, ST_ORIENT, ST_BLUR, ST_DESCRIBE, ST_COUNT };
-static const char *k_stage_names[ST_COUNT] = {"pyramid", "fast", "quadtree", "orient", "blur", "describe"};
+enum Stage { ST_PYRAMID = 0, ST_FAST_SCORE, ST_FAST_NMS, ST_QUADTREE, ST_ORIENT, ST_BLUR, ST_DESCRIBE, ST_COUNT };
+static const char *k_stage_names[ST_COUNT] = {"pyramid",  "fast_score", "fast_nms", "quadtree",
+                                               "orient",   "blur",       "describe"};
 
 static inline int cv_round_host(double v) { return (int)lrint(v); }
 
@@ -1534,28 +1559,29 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     MARK(1);
     hipLaunchKernelGGL(k_fast_score, dim3((e->fast_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr,
                        e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->fast_geom);
+    MARK(2);
     hipLaunchKernelGGL(k_fast_nms, dim3(((unsigned)e->cells.size() + 3) / 4, batch), dim3(256), 0, st,
                        e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->d_cells.as<CellDesc>(), (int)e->cells.size(),
                        e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(), e->prm.ini_th_fast,
                        e->prm.min_th_fast);
-    MARK(2);
+    MARK(3);
     hipLaunchKernelGGL(k_quadtree, dim3(nl, batch), dim3(512), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
                        e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(), e->d_sel.as<uint32_t>(),
                        e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
-    MARK(3);
+    MARK(4);
     hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 7) / 8, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out);
     hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
                        e->d_aux.as<KpAux>(), d_n_out, cap);
-    MARK(4);
+    MARK(5);
     hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
                        e->frame_pyr, dg, e->blur_geom);
-    MARK(5);
+    MARK(6);
     hipLaunchKernelGGL(k_describe, dim3((std::min(cap, e->max_kp) + 7) / 8, batch), dim3(256), 0, st, blur,
                        e->frame_pyr, dg, e->d_aux.as<KpAux>(), d_n_out, cap, e->d_pattern.as<int8_t>(), d_desc);
-    MARK(6);
+    MARK(7);
 #undef MARK
     ORBGPU_HIP_TRY(hipGetLastError());
     if (prof)
