@@ -58,6 +58,22 @@ def algorithmic_bytes(stage, n_kp, n_cand):
     raise KeyError(stage)
 
 
+STAGE_KERNELS = {"pyramid": ["k_border0"] + ["k_resize_fast"] * 7, "fast_score": ["k_fast_score"],
+                 "fast_nms": ["k_fast_nms"], "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
+                 "blur": ["k_blur"], "describe": ["k_describe"]}
+
+
+def pmc_traffic(stage, frames_per_launch):
+    """HBM bytes per launch of `stage` from the committed PMC pass (profiles/r01_pmc_traffic.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 FETCH correction). None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        k = json.load(open(path))["kernels"]
+        return float(sum(k[name]["hbm_bytes_per_frame"] for name in STAGE_KERNELS[stage])) * frames_per_launch
+    except Exception:
+        return None
+
+
 def cpu_baseline(frames, seconds_budget=18.0):
     """Oracle (kind 'port'): extract + BF match of consecutive frames, single thread."""
     from oracle import oracle_py as O
@@ -208,7 +224,9 @@ def main():
                                    "match of consecutive frames", "frames_per_step_per_gpu": B,
                        "resident_frame_pool": POOL, "sequences": world, "parallelism": "1 sequence per GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
+                         "traffic_source": "profiles/r01_pmc_traffic.json (separate --pmc passes at B=64, scaled to B)",
+                         "algorithmic_bytes": algorithmic_bytes(dom, n_kp, n_cand) * B,
                          "ms_per_launch": stage_ms[dom], "frames_per_launch": B},
             "stages": per_stage,
             "match_ms_per_step": round(match_ms, 4),
