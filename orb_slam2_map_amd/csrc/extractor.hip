@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1229,8 +1230,12 @@ struct orbgpu_extractor {
     // profiling: one event set per profiled call (up to PROF_SLOTS), averaged by stage_times()
     static constexpr int PROF_SLOTS = 256;
     bool profiling = false;
-    std::vector<hipEvent_t> ev;  // PROF_SLOTS * (ST_COUNT + 1), created lazily
+    std::vector<hipEvent_t> ev;  // PROF_SLOTS * 2 * ST_COUNT (start/end per stage), created lazily
     int prof_calls = 0;
+    // the blur only depends on the pyramid: it runs on a side stream next to FAST / quadtree / orientation
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;
 };
 
 namespace orbgpu {
@@ -1532,13 +1537,15 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
         return rc;
     const bool prof = e->profiling && e->prof_calls < orbgpu_extractor::PROF_SLOTS;
     if (prof && e->ev.empty()) {
-        e->ev.resize((size_t)orbgpu_extractor::PROF_SLOTS * (ST_COUNT + 1), nullptr);
+        e->ev.resize((size_t)orbgpu_extractor::PROF_SLOTS * 2 * ST_COUNT, nullptr);
         for (auto &x : e->ev)
             ORBGPU_HIP_TRY(hipEventCreate(&x));
     }
-    hipEvent_t *evs = prof ? &e->ev[(size_t)e->prof_calls * (ST_COUNT + 1)] : nullptr;
-#define MARK(i) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[i], st))
-    MARK(0);
+    hipEvent_t *evs = prof ? &e->ev[(size_t)e->prof_calls * 2 * ST_COUNT] : nullptr;
+    hipStream_t sb = e->overlap ? e->side : st;  // stream of the blur
+#define BEGIN(stage, s) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[2 * (stage)], s))
+#define END(stage, s) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[2 * (stage) + 1], s))
+    BEGIN(ST_PYRAMID, st);
     {
         const LevelGeom &g = e->geom[0];
         dim3 grid((g.pitch / 4 + 255) / 256, (g.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
@@ -1556,33 +1563,53 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                                    e->d_xtab.as<XTab>(), e->d_ytab.as<YTab>());
         }
     }
-    MARK(1);
+    END(ST_PYRAMID, st);
+    if (e->overlap) {  // fork: blur on the side stream
+        ORBGPU_HIP_TRY(hipEventRecord(e->ev_fork, st));
+        ORBGPU_HIP_TRY(hipStreamWaitEvent(sb, e->ev_fork, 0));
+        BEGIN(ST_BLUR, sb);
+        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, sb, pyr, blur,
+                           e->frame_pyr, dg, e->blur_geom);
+        END(ST_BLUR, sb);
+        ORBGPU_HIP_TRY(hipEventRecord(e->ev_join, sb));
+    }
+    BEGIN(ST_FAST_SCORE, st);
     hipLaunchKernelGGL(k_fast_score, dim3((e->fast_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr,
                        e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->fast_geom);
-    MARK(2);
+    END(ST_FAST_SCORE, st);
+    BEGIN(ST_FAST_NMS, st);
     hipLaunchKernelGGL(k_fast_nms, dim3(((unsigned)e->cells.size() + 3) / 4, batch), dim3(256), 0, st,
                        e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->d_cells.as<CellDesc>(), (int)e->cells.size(),
                        e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(), e->prm.ini_th_fast,
                        e->prm.min_th_fast);
-    MARK(3);
+    END(ST_FAST_NMS, st);
+    BEGIN(ST_QUADTREE, st);
     hipLaunchKernelGGL(k_quadtree, dim3(nl, batch), dim3(512), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
                        e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(), e->d_sel.as<uint32_t>(),
                        e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
-    MARK(4);
+    END(ST_QUADTREE, st);
+    BEGIN(ST_ORIENT, st);
     hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 7) / 8, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out);
     hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
                        e->d_aux.as<KpAux>(), d_n_out, cap);
-    MARK(5);
-    hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
-                       e->frame_pyr, dg, e->blur_geom);
-    MARK(6);
+    END(ST_ORIENT, st);
+    if (e->overlap) {  // join
+        ORBGPU_HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
+    } else {
+        BEGIN(ST_BLUR, st);
+        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
+                           e->frame_pyr, dg, e->blur_geom);
+        END(ST_BLUR, st);
+    }
+    BEGIN(ST_DESCRIBE, st);
     hipLaunchKernelGGL(k_describe, dim3((std::min(cap, e->max_kp) + 7) / 8, batch), dim3(256), 0, st, blur,
                        e->frame_pyr, dg, e->d_aux.as<KpAux>(), d_n_out, cap, e->d_pattern.as<int8_t>(), d_desc);
-    MARK(7);
-#undef MARK
+    END(ST_DESCRIBE, st);
+#undef BEGIN
+#undef END
     ORBGPU_HIP_TRY(hipGetLastError());
     if (prof)
         e->prof_calls++;
@@ -1622,6 +1649,16 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
     e->nlevels = p->nlevels;
     build_tables(e);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he == hipSuccess)
+        he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    if (he == hipSuccess)
+        he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (he == hipSuccess)
+        he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+    {
+        const char *no = getenv("ORBGPU_NO_OVERLAP");  // diagnostic: serialise the blur on the caller's stream
+        e->overlap = !(no && no[0] == '1');
+    }
     if (he != hipSuccess) {
         set_error("hipStreamCreate: %s", hipGetErrorString(he));
         delete e;
@@ -1648,6 +1685,12 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
             (void)hipEventDestroy(x);
     if (e->stream)
         (void)hipStreamDestroy(e->stream);
+    if (e->side)
+        (void)hipStreamDestroy(e->side);
+    if (e->ev_fork)
+        (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join)
+        (void)hipEventDestroy(e->ev_join);
     delete e;
     return ORBGPU_OK;
 }
@@ -1856,11 +1899,11 @@ int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms)
     for (int i = 0; i < ST_COUNT; i++)
         ms[i] = 0.f;
     for (int c = 0; c < e->prof_calls; c++) {
-        hipEvent_t *evs = &e->ev[(size_t)c * (ST_COUNT + 1)];
-        ORBGPU_HIP_TRY(hipEventSynchronize(evs[ST_COUNT]));
+        hipEvent_t *evs = &e->ev[(size_t)c * 2 * ST_COUNT];
         for (int i = 0; i < ST_COUNT; i++) {
             float t = 0.f;
-            ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
+            ORBGPU_HIP_TRY(hipEventSynchronize(evs[2 * i + 1]));
+            ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[2 * i], evs[2 * i + 1]));
             ms[i] += t;
         }
     }
