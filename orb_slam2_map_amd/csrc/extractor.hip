@@ -1232,10 +1232,7 @@ struct orbgpu_extractor {
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // PROF_SLOTS * 2 * ST_COUNT (start/end per stage), created lazily
     int prof_calls = 0;
-    // the blur only depends on the pyramid: it runs on a side stream next to FAST / quadtree / orientation
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool overlap = true;
+
 };
 
 namespace orbgpu {
@@ -1542,7 +1539,6 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
             ORBGPU_HIP_TRY(hipEventCreate(&x));
     }
     hipEvent_t *evs = prof ? &e->ev[(size_t)e->prof_calls * 2 * ST_COUNT] : nullptr;
-    hipStream_t sb = e->overlap ? e->side : st;  // stream of the blur
 #define BEGIN(stage, s) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[2 * (stage)], s))
 #define END(stage, s) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[2 * (stage) + 1], s))
     BEGIN(ST_PYRAMID, st);
@@ -1564,15 +1560,6 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
         }
     }
     END(ST_PYRAMID, st);
-    if (e->overlap) {  // fork: blur on the side stream
-        ORBGPU_HIP_TRY(hipEventRecord(e->ev_fork, st));
-        ORBGPU_HIP_TRY(hipStreamWaitEvent(sb, e->ev_fork, 0));
-        BEGIN(ST_BLUR, sb);
-        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, sb, pyr, blur,
-                           e->frame_pyr, dg, e->blur_geom);
-        END(ST_BLUR, sb);
-        ORBGPU_HIP_TRY(hipEventRecord(e->ev_join, sb));
-    }
     BEGIN(ST_FAST_SCORE, st);
     hipLaunchKernelGGL(k_fast_score, dim3((e->fast_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr,
                        e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->fast_geom);
@@ -1596,14 +1583,12 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
                        e->d_aux.as<KpAux>(), d_n_out, cap);
     END(ST_ORIENT, st);
-    if (e->overlap) {  // join
-        ORBGPU_HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
-    } else {
-        BEGIN(ST_BLUR, st);
-        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
-                           e->frame_pyr, dg, e->blur_geom);
-        END(ST_BLUR, st);
-    }
+    // (the blur only depends on the pyramid, but running it on a side stream next to the quadtree made
+    //  both slower on MI355X: 2.43 ms vs 2.34 ms per 256-frame step -- kept serial)
+    BEGIN(ST_BLUR, st);
+    hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
+                       e->frame_pyr, dg, e->blur_geom);
+    END(ST_BLUR, st);
     BEGIN(ST_DESCRIBE, st);
     hipLaunchKernelGGL(k_describe, dim3((std::min(cap, e->max_kp) + 7) / 8, batch), dim3(256), 0, st, blur,
                        e->frame_pyr, dg, e->d_aux.as<KpAux>(), d_n_out, cap, e->d_pattern.as<int8_t>(), d_desc);
@@ -1649,16 +1634,6 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
     e->nlevels = p->nlevels;
     build_tables(e);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    if (he == hipSuccess)
-        he = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
-    if (he == hipSuccess)
-        he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-    if (he == hipSuccess)
-        he = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
-    {
-        const char *no = getenv("ORBGPU_NO_OVERLAP");  // diagnostic: serialise the blur on the caller's stream
-        e->overlap = !(no && no[0] == '1');
-    }
     if (he != hipSuccess) {
         set_error("hipStreamCreate: %s", hipGetErrorString(he));
         delete e;
@@ -1685,12 +1660,6 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
             (void)hipEventDestroy(x);
     if (e->stream)
         (void)hipStreamDestroy(e->stream);
-    if (e->side)
-        (void)hipStreamDestroy(e->side);
-    if (e->ev_fork)
-        (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join)
-        (void)hipEventDestroy(e->ev_join);
     delete e;
     return ORBGPU_OK;
 }
