@@ -38,6 +38,7 @@ struct LevelGeom {
     float scale;
     int patch;
     int xtab_off, ytab_off;  // resize tables (levels >= 1)
+    int cm_off, rf_off;      // NMS tables: column masks per padded dword, row flags per image row
     int rs_off, rs_fast;     // fast-path strip tables (k_resize_fast); rs_fast = 0 -> k_resize_level
 };
 
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
 // K2: FAST-9/16 with NMS and per-cell threshold fallback
 //     (ORBextractor.cc:789-829 calling cv::FAST(sub, kps, th, true), A4)
 //
-// Two kernels.
+// Three kernels.
 //  k_fast_score  -- the corner score map s(x,y) of every level: s = max over the 16 arcs of 9
 //     contiguous ring pixels of the minimum |centre - ring| (dark and bright polarity), clamped to
 //     [0,255].  A pixel is a FAST corner for threshold t  <=>  s > t, and cv::FAST's cornerScore is
@@ -221,10 +222,12 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
 //     pixels x FS_ROWS rows, keeps a 7-row x 12-byte window in registers, unpacks ring bytes with
 //     v_perm_b32 into packed 16-bit lanes and runs the min/max network with v_pk_min/max_i16 (two
 //     pixels per instruction, no divergence, no LDS).
-//  k_fast_nms    -- one wave per 30-px cell: strict 3x3 non-maximum suppression restricted to the
-//     cell's interior (cv::FAST sees only the sub-image: neighbours outside count as 0) at iniThFAST
-//     and, if that leaves the cell empty, at minThFAST; survivors leave in row-major order (cv::FAST's
-//     output order, which the quadtree's "first maximum" rule depends on) via ballot ranks.
+//  k_fast_nmsbits -- streaming strict 3x3 non-maximum suppression restricted to each 30-px cell's
+//     interior (cv::FAST sees only the sub-image: neighbours outside count as 0); emits survivor bits
+//     for minThFAST and iniThFAST.
+//  k_fast_cells   -- one wave per cell: chooses iniThFAST or (empty cell) minThFAST and writes the
+//     survivors in row-major order (cv::FAST's output order, which the quadtree's "first maximum"
+//     rule depends on).
 // ---------------------------------------------------------------------------------------------
 constexpr int FS_ROWS = 28;   // output rows per strip (4 x 7)
 constexpr int MAX_CELL = 66;  // max cell interior edge
@@ -396,19 +399,113 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
 #undef FS_LOAD
 }
 
-// One wave per (cell, frame); 4 cells per workgroup, no workgroup barrier (waves are independent).
-// The cell's scores are staged in LDS with aligned dword loads: lane = (row of 3, dword column of 20),
-// bytes outside the cell interior are masked to 0 (cv::FAST sees only the sub-image).
-constexpr int NT_DW = 20;            // LDS tile pitch in dwords: 4 pad + (66 + 3 alignment) bytes + 1 ring
-constexpr int NT_PITCH = NT_DW * 4;  // bytes
+// k_fast_nmsbits: streaming 3x3 non-maximum suppression over the score map with the cell structure
+// of the reference folded in: a pixel survives iff its score is strictly greater than the scores of its
+// 8 neighbours THAT LIE INSIDE THE SAME CELL INTERIOR (cv::FAST sees only the cell's sub-image, so
+// outside neighbours count as 0).  Because a survivor at the lower threshold with s > t_hi is also a
+// survivor at t_hi (a neighbour with s_n <= t_hi cannot beat it), one NMS serves both thresholds:
+//   survivor(t)  <=>  s > max(t, 1)  and  s > every in-cell neighbour.
+// Output: one byte per aligned group of 4 pixels; bits 0..3 = survivor at minThFAST, bits 4..7 =
+// survivor at iniThFAST.  Same register-streaming shape as k_blur (3-row window, packed 16-bit).
+constexpr int NB_ROWS = 30;  // output rows per strip (multiple of 3: the 3-row ring unrolls evenly)
 
-__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ smap, size_t frame_pyr,
-                                                  const LevelGeom *__restrict__ geom,
-                                                  const CellDesc *__restrict__ cells, int ncells_total,
-                                                  uint32_t *__restrict__ slots, size_t frame_slots,
-                                                  int *__restrict__ cell_cnt, int ini_th, int min_th)
+struct NmsRow {
+    pk16 E, O;    // scores of (px0,px2) and (px1,px3)
+    pk16 HE, HO;  // max of their masked left/right neighbours
+    pk16 VE, VO;  // max(H, own): what this row contributes to the rows above / below
+};
+
+__device__ __forceinline__ void nms_row(const uint32_t d0, const uint32_t d1, const uint32_t d2, const uint4 cm,
+                                        NmsRow &r)
 {
-    __shared__ __align__(16) uint8_t tiles[4][NT_PITCH * (MAX_CELL + 2)];
+    // window bytes 0..11 = padded columns 4c-4 .. 4c+7; px p at byte 4+p; left of px0 = byte 3, right of px3 = byte 8
+    const pk16 LE = as_pk(__builtin_amdgcn_perm(d1, d0, ORBGPU_SEL_EVEN(3)));  // (b3, b5)
+    r.E = as_pk(__builtin_amdgcn_perm(d2, d1, ORBGPU_SEL_EVEN(0)));            // (b4, b6)
+    r.O = as_pk(__builtin_amdgcn_perm(d2, d1, ORBGPU_SEL_ODD(0)));             // (b5, b7)
+    const pk16 RO = as_pk(__builtin_amdgcn_perm(d2, d1, ORBGPU_SEL_EVEN(2)));  // (b6, b8)
+    r.HE = pkmax(as_pk(as_u32(LE) & cm.x), as_pk(as_u32(r.O) & cm.y));
+    r.HO = pkmax(as_pk(as_u32(r.E) & cm.z), as_pk(as_u32(RO) & cm.w));
+    r.VE = pkmax(r.HE, r.E);
+    r.VO = pkmax(r.HO, r.O);
+}
+
+__device__ __forceinline__ uint32_t nms_bits(const NmsRow &u, const NmsRow &c, const NmsRow &d, uint32_t rf,
+                                             pk16 tmin, pk16 tini)
+{
+    const uint32_t um = (rf & 1u) ? 0xFFFFFFFFu : 0u, dm = (rf & 2u) ? 0xFFFFFFFFu : 0u;
+    const pk16 nbE = pkmax(c.HE, pkmax(as_pk(as_u32(u.VE) & um), as_pk(as_u32(d.VE) & dm)));
+    const pk16 nbO = pkmax(c.HO, pkmax(as_pk(as_u32(u.VO) & um), as_pk(as_u32(d.VO) & dm)));
+    // x > y  <=>  sign(y - x); all values are in [0,255]
+    const uint32_t sE = as_u32(nbE - c.E), sO = as_u32(nbO - c.O);
+    const uint32_t minE = sE & as_u32(tmin - c.E), minO = sO & as_u32(tmin - c.O);
+    const uint32_t iniE = sE & as_u32(tini - c.E), iniO = sO & as_u32(tini - c.O);
+    // px0 = E.lo (bit 15), px1 = O.lo, px2 = E.hi (bit 31), px3 = O.hi
+    return ((minE >> 15) & 1u) | ((minO >> 14) & 2u) | ((minE >> 29) & 4u) | ((minO >> 28) & 8u) |
+           ((iniE >> 11) & 16u) | ((iniO >> 10) & 32u) | ((iniE >> 25) & 64u) | ((iniO >> 24) & 128u);
+}
+
+__global__ __launch_bounds__(256) void k_fast_nmsbits(const uint8_t *__restrict__ smap, uint8_t *__restrict__ bits,
+                                                      size_t frame_pyr, const LevelGeom *__restrict__ geom,
+                                                      StripGeom sg, const uint4 *__restrict__ colmask,
+                                                      const uint8_t *__restrict__ rowflag, int ini_th, int min_th)
+{
+    const int strip = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (strip >= sg.first[sg.nlevels])
+        return;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < ORBGPU_MAX_LEVELS; l++)
+        level += (l < sg.nlevels && strip >= sg.first[l]) ? 1 : 0;
+    const LevelGeom g = geom[level];
+    const int local = strip - sg.first[level];
+    const int sy = local / sg.nsx[level], sx = local - sy * sg.nsx[level];
+    const int dwc = 9 + sx;  // padded dword column (detection region starts in dword 9)
+    const int col = dwc * 4;
+    const int y0 = EDGE + sy * NB_ROWS;
+    const int rows = min(NB_ROWS, g.h - EDGE - y0);
+    const size_t plane = (size_t)f * frame_pyr + g.plane_off;
+    const uint8_t *src = smap + plane + (size_t)(y0 + EDGE - 1) * g.pitch + (col - 4);
+    uint8_t *dst = bits + (plane >> 2) + (size_t)(y0 + EDGE) * (g.pitch >> 2) + dwc;
+    const uint4 cm = colmask[g.cm_off + dwc];
+    const uint8_t *rf = rowflag + g.rf_off + y0;
+    const short t1 = (short)max(min_th, 1), t2 = (short)max(ini_th, 1);
+    const pk16 tmin = {t1, t1}, tini = {t2, t2};
+
+    NmsRow a, b, c;
+#define NB_LOAD(R, row)                                                                                      \
+    {                                                                                                        \
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);               \
+        nms_row(q[0], q[1], q[2], cm, R);                                                                    \
+    }
+#define NB_STEP(U, C, D, k)                                                                                  \
+    if ((k) < rows) {                                                                                        \
+        NB_LOAD(D, (k) + 2)                                                                                  \
+        dst[(size_t)(k) * (g.pitch >> 2)] = (uint8_t)nms_bits(U, C, D, rf[k], tmin, tini);                   \
+    }
+    NB_LOAD(a, 0) NB_LOAD(b, 1)
+#pragma unroll 1
+    for (int k = 0; k < NB_ROWS; k += 3) {
+        NB_STEP(a, b, c, k)
+        NB_STEP(b, c, a, k + 1)
+        NB_STEP(c, a, b, k + 2)
+    }
+#undef NB_STEP
+#undef NB_LOAD
+}
+
+// k_fast_cells: one wave per (cell, frame), one lane per interior row.  A lane gathers its row's
+// survivor bits (<= 66 pixels) into two 64-bit masks, the wave decides iniThFAST vs minThFAST
+// (ORBextractor.cc:809-816: the fallback applies when the iniThFAST pass leaves the cell empty),
+// a wave prefix sum of the per-row counts gives every row its output offset, and each lane emits its
+// survivors left to right -- row-major order, cv::FAST's output order.
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ smap,
+                                                    const uint8_t *__restrict__ bits, size_t frame_pyr,
+                                                    const LevelGeom *__restrict__ geom,
+                                                    const CellDesc *__restrict__ cells, int ncells_total,
+                                                    uint32_t *__restrict__ slots, size_t frame_slots,
+                                                    int *__restrict__ cell_cnt)
+{
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci = blockIdx.x * 4 + wave;
     const int f = blockIdx.y;
@@ -423,79 +520,94 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ sm
             *out_cnt = 0;
         return;
     }
-    uint8_t *tile = tiles[wave];
-    // interior = padded columns [xs, xe), padded rows [ys, ys+ih); tile column 0 <-> padded column xa-4
-    const int xs = cd.x0 + 3 + EDGE, xe = xs + iw, ys = cd.y0 + 3 + EDGE;
-    const int xa = xs & ~3;
-    const int toff = xs - xa + 4;  // tile column of interior pixel ix = 0
-    const uint8_t *src = smap + (size_t)f * frame_pyr + g.plane_off;
-    {
-        const int lr = lane / NT_DW, dc = lane - lr * NT_DW;  // 3 rows x 20 dwords per step (lanes 60..63 idle)
-        const int col = xa - 4 + dc * 4;                      // padded column of this dword
-        // byte mask of the interior columns inside this dword
-        const int lo = min(max(xs - col, 0), 4), hi = min(max(xe - col, 0), 4);
-        uint32_t mask = 0;
-        if (hi > lo)
-            mask = (0xFFFFFFFFu >> (8 * (4 - hi))) & (0xFFFFFFFFu << (8 * lo));
-        const int th = ih + 2;
-#pragma unroll 4
-        for (int ty0 = 0; ty0 < MAX_CELL + 2; ty0 += 3) {
-            const int ty = ty0 + lr;
-            if (ty0 >= th)
-                break;
-            if (lr < 3 && ty < th) {
-                uint32_t v = 0;
-                if (mask != 0 && ty >= 1 && ty <= ih)
-                    v = *reinterpret_cast<const uint32_t *>(src + (size_t)(ys + ty - 1) * g.pitch + col) & mask;
-                *reinterpret_cast<uint32_t *>(tile + ty * NT_PITCH + dc * 4) = v;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
+    const int xs = cd.x0 + 3 + EDGE, ys = cd.y0 + 3 + EDGE;  // padded coordinates of the interior origin
+    const int s0 = xs >> 2, o0 = xs & 3;                     // first strip, pixel offset inside it
+    const int nstrip = ((xs + iw - 1) >> 2) - s0 + 1;        // <= 18
+    const size_t plane = (size_t)f * frame_pyr + g.plane_off;
+    const uint8_t *bplane = bits + (plane >> 2);
+    const int bpitch = g.pitch >> 2;
     uint32_t *out = slots + (size_t)f * frame_slots + cd.slot_off;
-    const int npix = iw * ih;
-    const float inv_iw = 1.0f / (float)iw;
-    int total = 0;
-    for (int pass = 0; pass < 2; pass++) {
-        const int thr = pass == 0 ? ini_th : min_th;
-        total = 0;
-        for (int chunk = 0; chunk < npix; chunk += 64) {
-            const int p = chunk + lane;
-            bool keep = false;
-            int ix = 0, iy = 0, sc = 0;
-            if (p < npix) {
-                iy = (int)(((float)p + 0.5f) * inv_iw);
-                ix = p - iy * iw;
-                const uint8_t *sm = &tile[(iy + 1) * NT_PITCH + ix + toff];
-                sc = sm[0];
-                if (sc > thr) {
-                    const int r = sc - 1;
-                    keep = true;
-#define NB(off)                                                                                              \
-    {                                                                                                        \
-        const int sn = sm[off];                                                                              \
-        const int vn = sn > thr ? sn - 1 : 0;                                                                \
-        keep = keep && (r > vn);                                                                             \
-    }
-                    NB(-NT_PITCH - 1) NB(-NT_PITCH) NB(-NT_PITCH + 1) NB(-1) NB(1) NB(NT_PITCH - 1) NB(NT_PITCH)
-                        NB(NT_PITCH + 1)
-#undef NB
+
+    // rows iy = lane (group 0) and iy = 64 + lane (group 1; cells are at most 66 rows tall)
+    unsigned long long mmin[2][2] = {{0ull, 0ull}, {0ull, 0ull}}, mini[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
+    const unsigned long long keep0 = iw >= 64 ? ~0ull : (1ull << iw) - 1ull;
+    const unsigned long long keep1 = iw <= 64 ? 0ull : (1ull << (iw - 64)) - 1ull;
+    int n_ini = 0;
+#pragma unroll
+    for (int grp = 0; grp < 2; grp++) {
+        const int iy = grp * 64 + lane;
+        if (iy < ih) {
+            const uint8_t *bp = bplane + (size_t)(ys + iy) * bpitch + s0;
+            unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            for (int k = 0; k < nstrip; k++) {
+                const unsigned v = bp[k];
+                const int bit = 4 * k - o0;  // pixel index of the strip's px0 inside the row (-3 .. 68)
+                const unsigned long long lo = (unsigned long long)(v & 15u), hi = (unsigned long long)(v >> 4);
+                if (bit < 0) {
+                    a0 |= lo >> (-bit);
+                    b0 |= hi >> (-bit);
+                } else if (bit < 64) {
+                    a0 |= lo << bit;
+                    b0 |= hi << bit;
+                    if (bit > 60) {  // straddles the 64-bit boundary
+                        a1 |= lo >> (64 - bit);
+                        b1 |= hi >> (64 - bit);
+                    }
+                } else {
+                    a1 |= lo << (bit - 64);
+                    b1 |= hi << (bit - 64);
                 }
             }
-            const unsigned long long bal = __ballot(keep);
-            const int off = total + __popcll(bal & ((1ull << lane) - 1ull));
-            if (keep && off < cd.cap)
-                out[off] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, sc - 1);
-            total += __popcll(bal);
+            mmin[grp][0] = a0 & keep0;
+            mmin[grp][1] = a1 & keep1;
+            mini[grp][0] = b0 & keep0;
+            mini[grp][1] = b1 & keep1;
+            n_ini += __popcll(mini[grp][0]) + __popcll(mini[grp][1]);
         }
-        if (total > 0)
+    }
+    n_ini = wave_reduce_add(n_ini);
+    n_ini = __shfl(n_ini, 0, 64);
+    const bool use_ini = n_ini > 0;
+
+    int base = 0;
+#pragma unroll
+    for (int grp = 0; grp < 2; grp++) {
+        if (grp * 64 >= ih)
             break;
+        const int iy = grp * 64 + lane;
+        const unsigned long long m0 = use_ini ? mini[grp][0] : mmin[grp][0];
+        const unsigned long long m1 = use_ini ? mini[grp][1] : mmin[grp][1];
+        const int c = __popcll(m0) + __popcll(m1);
+        int inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off, 64);
+            if (lane >= off)
+                inc += t;
+        }
+        int pos = base + inc - c;
+        base += __shfl(inc, 63, 64);
+        if (c > 0) {
+            const uint8_t *srow = smap + plane + (size_t)(ys + iy) * g.pitch + xs;
+            unsigned long long m = m0;
+            int xb = 0;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                while (m) {
+                    const int ix = xb + __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    const int sc = srow[ix];
+                    if (pos < cd.cap)
+                        out[pos] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, sc - 1);
+                    pos++;
+                }
+                m = m1;
+                xb = 64;
+            }
+        }
     }
     if (lane == 0)
-        *out_cnt = total;
+        *out_cnt = base;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -616,20 +728,24 @@ __global__ __launch_bounds__(512) void k_quadtree(const LevelGeom *__restrict__ 
     uint16_t *dnode = dense_node + (size_t)f * frame_slots + g.slot_off;
     const int *ccounts = cell_cnt + (size_t)f * ncells_total + g.cell_first;
 
-    // ---- step 0: compact this level's cell slots into vToDistributeKeys order
-    for (int c = tid; c < g.ncells; c += nt)
+    // ---- step 0: compact this level's cell slots into vToDistributeKeys order.  One thread per key:
+    //      the owning cell is found by binary search in the scanned cell counts (LDS).
+    for (int c = tid; c < g.ncells; c += nt) {
         S.ccnt[c] = ccounts[c];
+        S.ccnt_next[c] = cells[g.cell_first + c].slot_off;
+    }
     __syncthreads();
-    const int nkeys = block_excl_scan(S.ccnt, g.ncells, s_tmp);
-    {
-        const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-        for (int c = wave; c < g.ncells; c += nw) {
-            const int cnt = ccounts[c];
-            const int off = S.ccnt[c];
-            const uint32_t *srcp = fslots + cells[g.cell_first + c].slot_off;
-            for (int k = lane; k < cnt; k += 64)
-                dkey[off + k] = srcp[k];
+    const int nkeys = block_excl_scan(S.ccnt, g.ncells, s_tmp);  // ccnt[c] = first dense index of cell c
+    for (int i = tid; i < nkeys; i += nt) {
+        int lo = 0, hi = g.ncells - 1;  // last cell with start <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (S.ccnt[mid] <= i)
+                lo = mid;
+            else
+                hi = mid - 1;
         }
+        dkey[i] = fslots[S.ccnt_next[lo] + (i - S.ccnt[lo])];
     }
     __syncthreads();  // dkey written by this workgroup only; visible after the barrier (same CU)
     if (tid == 0)
@@ -1216,12 +1332,12 @@ struct orbgpu_extractor {
     int cfg_w = 0, cfg_h = 0, cfg_batch = 0;
     std::vector<LevelGeom> geom;
     std::vector<CellDesc> cells;
-    StripGeom blur_geom, fast_geom;
+    StripGeom blur_geom, fast_geom, nms_geom;
     size_t frame_pyr = 0, frame_slots = 0;
     int sel_cap_total = 0, ncap = 0, max_kp = 0;
     size_t qt_lds = 0;
     // device state
-    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt;
+    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt, d_colmask, d_rowflag, d_bits;
     DevBuf d_pyr, d_blur, d_smap, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
     DevBuf d_in, d_kps, d_desc, d_nout;  // staging for the host entry points
     DevBuf d_dbg;
@@ -1289,7 +1405,8 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     std::vector<XTab> xtab;
     std::vector<YTab> ytab;
     std::vector<ResizeStrip> rstrip;
-    std::vector<uint4> rsel, rwt;
+    std::vector<uint4> rsel, rwt, colmask;
+    std::vector<uint8_t> rowflag;
     size_t plane_off = 0;
     int slot_off = 0, sel_off = 0, max_cells_level = 0, ncap = 0;
     for (int l = 0; l < nl; l++) {
@@ -1360,6 +1477,33 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         g.sel_off = sel_off;
         sel_off += g.sel_cap;
         ncap = std::max(ncap, g.sel_cap);
+        // NMS tables: a neighbour counts only if it lies in the same cell interior.  Interiors tile
+        // [19, w-19) x [19, h-19) in steps of wCell x hCell (:769-808).
+        g.cm_off = (int)colmask.size();
+        g.rf_off = (int)rowflag.size();
+        {
+            auto hasL = [&](int x) { return x >= EDGE && x < g.w - EDGE && (x - EDGE) % g.wcell != 0; };
+            auto hasR = [&](int x) {
+                return x >= EDGE && x < g.w - EDGE && (x - EDGE) % g.wcell != g.wcell - 1 && x != g.w - EDGE - 1;
+            };
+            for (int dwc = 0; dwc < g.pitch / 4; dwc++) {
+                const int x0 = 4 * dwc - EDGE;  // image column of px0
+                uint4 m;
+                m.x = (hasL(x0) ? 0xFFFFu : 0u) | (hasL(x0 + 2) ? 0xFFFF0000u : 0u);
+                m.y = (hasR(x0) ? 0xFFFFu : 0u) | (hasR(x0 + 2) ? 0xFFFF0000u : 0u);
+                m.z = (hasL(x0 + 1) ? 0xFFFFu : 0u) | (hasL(x0 + 3) ? 0xFFFF0000u : 0u);
+                m.w = (hasR(x0 + 1) ? 0xFFFFu : 0u) | (hasR(x0 + 3) ? 0xFFFF0000u : 0u);
+                colmask.push_back(m);
+            }
+            for (int y = 0; y < g.h; y++) {
+                const bool in = y >= EDGE && y < g.h - EDGE;
+                const bool up = in && (y - EDGE) % g.hcell != 0;
+                const bool dn = in && (y - EDGE) % g.hcell != g.hcell - 1 && y != g.h - EDGE - 1;
+                rowflag.push_back((uint8_t)((up ? 1 : 0) | (dn ? 2 : 0)));
+            }
+            while (rowflag.size() % 4)
+                rowflag.push_back(0);
+        }
         // resize tables (cv::resize INTER_LINEAR 8U, A2)
         g.xtab_off = (int)xtab.size();
         g.ytab_off = (int)ytab.size();
@@ -1468,6 +1612,17 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         }
         for (int l = nl; l <= ORBGPU_MAX_LEVELS; l++)
             fg.first[l] = acc;
+        StripGeom &ng = e->nms_geom;
+        memset(&ng, 0, sizeof(ng));
+        ng.nlevels = nl;
+        acc = 0;
+        for (int l = 0; l < nl; l++) {
+            ng.first[l] = acc;
+            ng.nsx[l] = fg.nsx[l];
+            acc += fg.nsx[l] * ((geom[l].h - 2 * EDGE + NB_ROWS - 1) / NB_ROWS);
+        }
+        for (int l = nl; l <= ORBGPU_MAX_LEVELS; l++)
+            ng.first[l] = acc;
     }
     e->frame_pyr = plane_off;
     e->frame_slots = (size_t)slot_off;
@@ -1493,6 +1648,9 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_pyr, e->frame_pyr * B);
     RSV(e->d_blur, e->frame_pyr * B);
     RSV(e->d_smap, e->frame_pyr * B);
+    RSV(e->d_bits, e->frame_pyr / 4 * B);
+    RSV(e->d_colmask, sizeof(uint4) * colmask.size());
+    RSV(e->d_rowflag, rowflag.size());
     RSV(e->d_slots, sizeof(uint32_t) * e->frame_slots * B);
     RSV(e->d_cellcnt, sizeof(int) * cells.size() * B);
     RSV(e->d_dkey, sizeof(uint32_t) * e->frame_slots * B);
@@ -1511,6 +1669,8 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         ORBGPU_HIP_TRY(hipMemcpy(e->d_rwt.p, rwt.data(), sizeof(uint4) * rwt.size(), hipMemcpyHostToDevice));
     }
     ORBGPU_HIP_TRY(hipMemcpy(e->d_pattern.p, k_pattern_host, 1024, hipMemcpyHostToDevice));
+    ORBGPU_HIP_TRY(hipMemcpy(e->d_colmask.p, colmask.data(), sizeof(uint4) * colmask.size(), hipMemcpyHostToDevice));
+    ORBGPU_HIP_TRY(hipMemcpy(e->d_rowflag.p, rowflag.data(), rowflag.size(), hipMemcpyHostToDevice));
     // the blurred planes are only written inside the image; define the rest once
     ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
     ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree),
@@ -1565,10 +1725,12 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->fast_geom);
     END(ST_FAST_SCORE, st);
     BEGIN(ST_FAST_NMS, st);
-    hipLaunchKernelGGL(k_fast_nms, dim3(((unsigned)e->cells.size() + 3) / 4, batch), dim3(256), 0, st,
-                       e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->d_cells.as<CellDesc>(), (int)e->cells.size(),
-                       e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(), e->prm.ini_th_fast,
-                       e->prm.min_th_fast);
+    hipLaunchKernelGGL(k_fast_nmsbits, dim3((e->nms_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st,
+                       e->d_smap.as<uint8_t>(), e->d_bits.as<uint8_t>(), e->frame_pyr, dg, e->nms_geom,
+                       e->d_colmask.as<uint4>(), e->d_rowflag.as<uint8_t>(), e->prm.ini_th_fast, e->prm.min_th_fast);
+    hipLaunchKernelGGL(k_fast_cells, dim3(((unsigned)e->cells.size() + 3) / 4, batch), dim3(256), 0, st,
+                       e->d_smap.as<uint8_t>(), e->d_bits.as<uint8_t>(), e->frame_pyr, dg, e->d_cells.as<CellDesc>(),
+                       (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>());
     END(ST_FAST_NMS, st);
     BEGIN(ST_QUADTREE, st);
     hipLaunchKernelGGL(k_quadtree, dim3(nl, batch), dim3(512), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
@@ -1650,7 +1812,7 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
     (void)hipSetDevice(e->prm.device_id);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_rstrip, &e->d_rsel,
-                      &e->d_rwt, &e->d_pyr,
+                      &e->d_rwt, &e->d_colmask, &e->d_rowflag, &e->d_bits, &e->d_pyr,
                       &e->d_blur, &e->d_smap, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
                       &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
     for (DevBuf *b : bufs)
