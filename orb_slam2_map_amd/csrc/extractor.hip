@@ -528,35 +528,44 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int bpitch = g.pitch >> 2;
     uint32_t *out = slots + (size_t)f * frame_slots + cd.slot_off;
 
-    // rows iy = lane (group 0) and iy = 64 + lane (group 1; cells are at most 66 rows tall)
+    // rows iy = lane (group 0) and iy = 64 + lane (group 1; cells are at most 66 rows tall).
+    // A row's <= 18 strip bytes are fetched as 6 aligned dwords (24 strips from strip sa = s0 & ~3),
+    // each dword's nibbles are compressed to 16 pixel bits, and the 96-bit strings are shifted so that
+    // bit 0 = the row's first interior pixel.
     unsigned long long mmin[2][2] = {{0ull, 0ull}, {0ull, 0ull}}, mini[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
     const unsigned long long keep0 = iw >= 64 ? ~0ull : (1ull << iw) - 1ull;
     const unsigned long long keep1 = iw <= 64 ? 0ull : (1ull << (iw - 64)) - 1ull;
+    const int sa = s0 & ~3;
+    const int shift = 4 * (s0 - sa) + o0;  // 0..15 pixel bits to drop at the front
+    const int ndw = min(6, (bpitch - sa) >> 2);  // dwords available in the row from sa on
     int n_ini = 0;
 #pragma unroll
     for (int grp = 0; grp < 2; grp++) {
         const int iy = grp * 64 + lane;
         if (iy < ih) {
-            const uint8_t *bp = bplane + (size_t)(ys + iy) * bpitch + s0;
-            unsigned long long a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-            for (int k = 0; k < nstrip; k++) {
-                const unsigned v = bp[k];
-                const int bit = 4 * k - o0;  // pixel index of the strip's px0 inside the row (-3 .. 68)
-                const unsigned long long lo = (unsigned long long)(v & 15u), hi = (unsigned long long)(v >> 4);
-                if (bit < 0) {
-                    a0 |= lo >> (-bit);
-                    b0 |= hi >> (-bit);
-                } else if (bit < 64) {
-                    a0 |= lo << bit;
-                    b0 |= hi << bit;
-                    if (bit > 60) {  // straddles the 64-bit boundary
-                        a1 |= lo >> (64 - bit);
-                        b1 |= hi >> (64 - bit);
-                    }
-                } else {
-                    a1 |= lo << (bit - 64);
-                    b1 |= hi << (bit - 64);
-                }
+            const uint32_t *bp = reinterpret_cast<const uint32_t *>(bplane + (size_t)(ys + iy) * bpitch + sa);
+            uint32_t lo16[6], hi16[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const uint32_t d = k < ndw ? bp[k] : 0u;
+                uint32_t x = d & 0x0F0F0F0Fu, y = (d >> 4) & 0x0F0F0F0Fu;
+                x = (x | (x >> 4)) & 0x00FF00FFu;
+                y = (y | (y >> 4)) & 0x00FF00FFu;
+                lo16[k] = (x | (x >> 8)) & 0xFFFFu;
+                hi16[k] = (y | (y >> 8)) & 0xFFFFu;
+            }
+            // 96 pixel bits -> (w0: bits 0..63, w1: bits 64..95), then drop `shift` leading bits
+            unsigned long long a0 = (unsigned long long)lo16[0] | ((unsigned long long)lo16[1] << 16) |
+                                    ((unsigned long long)lo16[2] << 32) | ((unsigned long long)lo16[3] << 48);
+            unsigned long long a1 = (unsigned long long)lo16[4] | ((unsigned long long)lo16[5] << 16);
+            unsigned long long b0 = (unsigned long long)hi16[0] | ((unsigned long long)hi16[1] << 16) |
+                                    ((unsigned long long)hi16[2] << 32) | ((unsigned long long)hi16[3] << 48);
+            unsigned long long b1 = (unsigned long long)hi16[4] | ((unsigned long long)hi16[5] << 16);
+            if (shift) {
+                a0 = (a0 >> shift) | (a1 << (64 - shift));
+                a1 >>= shift;
+                b0 = (b0 >> shift) | (b1 << (64 - shift));
+                b1 >>= shift;
             }
             mmin[grp][0] = a0 & keep0;
             mmin[grp][1] = a1 & keep1;
