@@ -21,8 +21,6 @@
 
 namespace orbgpu {
 
-constexpr int BF_ROWS_PER_WAVE = 8;
-constexpr int BF_ROWS_PER_BLOCK = 4 * BF_ROWS_PER_WAVE;
 constexpr int BF_TOPK = 4;
 constexpr uint32_t BF_KEY_NONE = 0xFFFFFFFFu;  // "no further candidate"
 
@@ -66,72 +64,36 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 }
 
 // Pass 1: for every A row the BF_TOPK best B rows over ALL B rows (claims are applied in pass 2).
-// grid = (ceil(cap / BF_ROWS_PER_BLOCK), pairs).  Dynamic LDS: B descriptors as four u64 planes
-// (conflict-free ds_read_b64 per lane).  Register blocking: a wave carries BF_RB A rows at once, so
-// every B descriptor fetched from LDS (32 B per lane) is used for BF_RB distances.
-constexpr int BF_RB = 4;
-
+// One LANE per A row (its 256-bit descriptor lives in 8 VGPRs) looping over the B rows; the B row is
+// the same for the whole wave, so it arrives through the scalar cache (s_load_dwordx8) and the XORs
+// take SGPR operands: 8 v_xor + 8 v_bcnt (with accumulate) per distance, no LDS, no cross-lane merge.
+// grid = (ceil(cap / 256), pairs).
 __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
                                                  const int *__restrict__ nb_p, uint32_t *__restrict__ topk)
 {
-    extern __shared__ __align__(16) uint8_t smem[];
     const int pair = blockIdx.y;
     const int na = min(na_p[pair], cap), nb = min(nb_p[pair], cap);
-    const int row0 = blockIdx.x * BF_ROWS_PER_BLOCK;
-    if (row0 >= na)
+    if ((int)(blockIdx.x * 256) >= na)
         return;
-    uint64_t *bplane = reinterpret_cast<uint64_t *>(smem);  // [4][nbp]
-    const int nbp = (nb + 63) & ~63;
-    const uint64_t *gb = reinterpret_cast<const uint64_t *>(desc_b + (size_t)pair * cap * 32);
-    for (int i = threadIdx.x; i < nb * 4; i += 256) {
-        const int j = i >> 2, w = i & 3;
-        bplane[w * nbp + j] = gb[i];
+    const int i = min((int)(blockIdx.x * 256 + threadIdx.x), na - 1);  // tail lanes repeat the last row
+    const uint32_t *ga = reinterpret_cast<const uint32_t *>(desc_a + ((size_t)pair * cap + i) * 32);
+    uint32_t a[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+        a[w] = ga[w];
+    const uint32_t *gb = reinterpret_cast<const uint32_t *>(desc_b + (size_t)pair * cap * 32);
+    uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
+    for (int j = 0; j < nb; j++) {
+        const uint32_t *b = gb + (size_t)j * 8;  // wave-uniform address -> scalar loads
+        uint32_t d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+            d += __popc(a[w] ^ b[w]);
+        top4_insert(t, bf_key((int)d, j));
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t *ga = reinterpret_cast<const uint64_t *>(desc_a + (size_t)pair * cap * 32);
-    uint32_t *tk = topk + (size_t)pair * cap * BF_TOPK;
-    for (int r = 0; r < BF_ROWS_PER_WAVE; r += BF_RB) {
-        const int i0 = row0 + wave * BF_ROWS_PER_WAVE + r;
-        if (i0 >= na)
-            break;
-        uint64_t a[BF_RB][4];
-        uint32_t t[BF_RB][4];
-#pragma unroll
-        for (int q = 0; q < BF_RB; q++) {
-            const int i = min(i0 + q, na - 1);  // rows past the end repeat the last row (results discarded)
-#pragma unroll
-            for (int w = 0; w < 4; w++)
-                a[q][w] = ga[(size_t)i * 4 + w];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                t[q][k] = BF_KEY_NONE;
-        }
-        for (int j = lane; j < nb; j += 64) {
-            const uint64_t b0 = bplane[j], b1 = bplane[nbp + j], b2 = bplane[2 * nbp + j], b3 = bplane[3 * nbp + j];
-#pragma unroll
-            for (int q = 0; q < BF_RB; q++) {
-                const int d = __popcll(a[q][0] ^ b0) + __popcll(a[q][1] ^ b1) + __popcll(a[q][2] ^ b2) +
-                              __popcll(a[q][3] ^ b3);
-                top4_insert(t[q], bf_key(d, j));
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < BF_RB; q++) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                uint32_t o[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    o[k] = (uint32_t)__shfl_xor((int)t[q][k], off, 64);
-                top4_merge(t[q], o);
-            }
-            if (lane < 4 && i0 + q < na)
-                tk[(size_t)(i0 + q) * BF_TOPK + lane] =
-                    lane == 0 ? t[q][0] : lane == 1 ? t[q][1] : lane == 2 ? t[q][2] : t[q][3];
-        }
-    }
+    if ((int)(blockIdx.x * 256 + threadIdx.x) < na)
+        *reinterpret_cast<uint4 *>(topk + ((size_t)pair * cap + i) * BF_TOPK) = make_uint4(t[0], t[1], t[2], t[3]);
 }
 
 // Exact best/second over the B rows visible to A row i: full scan by one wave (lanes stride over the
@@ -397,10 +359,7 @@ int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orb
         orbgpu_matcher_destroy(m);
         return rc;
     }
-    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_topk),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 4096 + 256);
-    if (he == hipSuccess)
-        he = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_resolve),
+    hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_resolve),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096 + 256);
     if (he != hipSuccess) {
         set_error("hipFuncSetAttribute: %s", hipGetErrorString(he));
@@ -439,9 +398,8 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
         return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     uint32_t *topk = m->d_topk.as<uint32_t>();
-    const int nbp = (cap + 63) & ~63;
-    const dim3 grid((cap + BF_ROWS_PER_BLOCK - 1) / BF_ROWS_PER_BLOCK, pairs);
-    hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), (size_t)32 * nbp, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk);
+    const dim3 grid((cap + 255) / 256, pairs);
+    hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk);
     hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), (size_t)16 * cap, st, cap, d_desc_a, d_valid_a, d_na,
                        d_desc_b, d_nb, topk, th_low, nnratio, reinterpret_cast<const uint8_t *>(d_angle_a),
                        reinterpret_cast<const uint8_t *>(d_angle_b), angle_stride, check_orientation, d_match_b,
