@@ -67,13 +67,17 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 // One LANE per A row (its 256-bit descriptor lives in 8 VGPRs) looping over the B rows; the B row is
 // the same for the whole wave, so it arrives through the scalar cache (s_load_dwordx8) and the XORs
 // take SGPR operands: 8 v_xor + 8 v_bcnt (with accumulate) per distance, no LDS, no cross-lane merge.
-// grid = (ceil(cap / 256), pairs).
+// grid = (ceil(cap / 256), pairs, BF_SPLIT): the B rows are split into BF_SPLIT contiguous ranges to double
+// the number of waves in flight; k_bf_resolve merges the partial lists (4 smallest of their union).
+constexpr int BF_SPLIT = 2;
+
 __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
                                                  const int *__restrict__ nb_p, uint32_t *__restrict__ topk)
 {
     const int pair = blockIdx.y;
-    const int na = min(na_p[pair], cap), nb = min(nb_p[pair], cap);
+    const int na = min(na_p[pair], cap);
+    int nb = min(nb_p[pair], cap);
     if ((int)(blockIdx.x * 256) >= na)
         return;
     const int i = min((int)(blockIdx.x * 256 + threadIdx.x), na - 1);  // tail lanes repeat the last row
@@ -84,8 +88,28 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
         a[w] = ga[w];
     const uint32_t *gb = reinterpret_cast<const uint32_t *>(desc_b + (size_t)pair * cap * 32);
     uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
-    for (int j = 0; j < nb; j++) {
-        const uint32_t *b = gb + (size_t)j * 8;  // wave-uniform address -> scalar loads
+    const int per = (nb + BF_SPLIT - 1) / BF_SPLIT;
+    int j = (int)blockIdx.z * per;
+    nb = min(nb, j + per);
+    for (; j + 4 <= nb; j += 4) {  // 4 B rows per step: their scalar loads are issued together
+        const uint32_t *b = gb + (size_t)j * 8;  // wave-uniform address -> s_load_dwordx8
+        uint32_t bb[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int w = 0; w < 8; w++)
+                bb[u][w] = b[u * 8 + w];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++)
+                d += __popc(a[w] ^ bb[u][w]);
+            top4_insert(t, bf_key((int)d, j + u));
+        }
+    }
+    for (; j < nb; j++) {
+        const uint32_t *b = gb + (size_t)j * 8;
         uint32_t d = 0;
 #pragma unroll
         for (int w = 0; w < 8; w++)
@@ -93,7 +117,8 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
         top4_insert(t, bf_key((int)d, j));
     }
     if ((int)(blockIdx.x * 256 + threadIdx.x) < na)
-        *reinterpret_cast<uint4 *>(topk + ((size_t)pair * cap + i) * BF_TOPK) = make_uint4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<uint4 *>(topk + (((size_t)pair * cap + i) * BF_SPLIT + blockIdx.z) * BF_TOPK) =
+            make_uint4(t[0], t[1], t[2], t[3]);
 }
 
 // Exact best/second over the B rows visible to A row i: full scan by one wave (lanes stride over the
@@ -161,7 +186,7 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
     int *slow = match + cap;                      // [cap] rows whose cached list cannot decide
     const uint64_t *ga = reinterpret_cast<const uint64_t *>(desc_a + (size_t)pair * cap * 32);
     const uint64_t *gb = reinterpret_cast<const uint64_t *>(desc_b + (size_t)pair * cap * 32);
-    const uint32_t *tk = topk + (size_t)pair * cap * BF_TOPK;
+    const uint32_t *tk = topk + (size_t)pair * cap * BF_SPLIT * BF_TOPK;
     const uint8_t *va = valid_a ? valid_a + (size_t)pair * cap : nullptr;
     int *mb = match_b + (size_t)pair * cap;
 
@@ -185,8 +210,14 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
             int result = -1;
             bool decided = true;
             if (!va || va[i]) {
-                const uint4 k4 = *reinterpret_cast<const uint4 *>(tk + (size_t)i * BF_TOPK);
-                const uint32_t key[4] = {k4.x, k4.y, k4.z, k4.w};
+                const uint4 k4 = *reinterpret_cast<const uint4 *>(tk + (size_t)i * BF_SPLIT * BF_TOPK);
+                uint32_t key[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int sp = 1; sp < BF_SPLIT; sp++) {
+                    const uint4 o4 = *reinterpret_cast<const uint4 *>(tk + ((size_t)i * BF_SPLIT + sp) * BF_TOPK);
+                    const uint32_t o[4] = {o4.x, o4.y, o4.z, o4.w};
+                    top4_merge(key, o);
+                }
                 int b1 = 256, i1 = -1, b2 = 256, found = 0;
                 bool complete = false;  // list exhausted: every B row has been considered
 #pragma unroll
@@ -354,7 +385,7 @@ int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orb
     m->max_pairs = max_pairs;
     m->cap = cap;
     const size_t P = (size_t)max_pairs;
-    if ((rc = m->d_topk.reserve(sizeof(uint32_t) * P * cap * BF_TOPK)) != ORBGPU_OK ||
+    if ((rc = m->d_topk.reserve(sizeof(uint32_t) * P * cap * BF_TOPK * BF_SPLIT)) != ORBGPU_OK ||
         (rc = m->d_sweeps.reserve(sizeof(int) * P)) != ORBGPU_OK) {
         orbgpu_matcher_destroy(m);
         return rc;
@@ -398,7 +429,7 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
         return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     uint32_t *topk = m->d_topk.as<uint32_t>();
-    const dim3 grid((cap + 255) / 256, pairs);
+    const dim3 grid((cap + 255) / 256, pairs, BF_SPLIT);
     hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk);
     hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), (size_t)16 * cap, st, cap, d_desc_a, d_valid_a, d_na,
                        d_desc_b, d_nb, topk, th_low, nnratio, reinterpret_cast<const uint8_t *>(d_angle_a),
