@@ -8,9 +8,10 @@
 // (map point) whose MapPoint::Observations()>0 is skipped by every later row (:87-89, :1403-1405).
 // As in the brute-force matcher the GPU evaluates all rows in parallel and iterates to the unique
 // triangular fixpoint ("row i sees the claims of rows < i"), which equals the sequential result.
-// One wave per row: lanes take the grid cells of the search window (ix outer, iy inner -- the
-// reference's candidate order, which decides ties), each lane keeps its two best candidates as
-// 64-bit keys (distance, order, index) and a wave butterfly merges them.
+// Pass 1 (k_proj_topk): one wave per row walks the grid window ONCE -- lanes take the window's cells
+// (ix outer, iy inner: the reference's candidate order, which decides ties) -- and caches the 4 best
+// candidates as 64-bit keys (distance, order, index).  Pass 2 (k_proj_resolve): one workgroup runs the
+// sweeps from the cached lists with the claim tables in LDS.
 #include "common.h"
 #include "matcher_common.h"
 
@@ -21,7 +22,6 @@
 
 namespace orbgpu {
 
-constexpr int PJ_MAX_SWEEPS = 16;
 constexpr int GC = ORBGPU_GRID_COLS, GR = ORBGPU_GRID_ROWS;
 
 struct Query {  // one row of the matcher: a projected map point
@@ -43,6 +43,7 @@ struct FrameDev {
 };
 
 constexpr uint64_t KEY_NONE = ((uint64_t)256 << 44) | 0xFFFFFFFFFFFull;
+constexpr int PJ_TOPK = 4;
 
 __device__ __forceinline__ void keep2(uint64_t &k1, uint64_t &k2, uint64_t k)
 {
@@ -54,227 +55,266 @@ __device__ __forceinline__ void keep2(uint64_t &k1, uint64_t &k2, uint64_t k)
     }
 }
 
-// mode 0: SearchByProjection(F, MapPoints)  -- best + second, ratio test only on equal levels
-// mode 1: SearchByProjection(Cur, Last)     -- best only
-template <int MODE>
-__global__ __launch_bounds__(256) void k_proj_sweep(int sweep, int m, const Query *__restrict__ q,
-                                                    const uint8_t *__restrict__ row_desc, FrameDev F,
-                                                    float nnratio, const int *__restrict__ claim_init,
-                                                    int *__restrict__ match, int *__restrict__ claim3,
-                                                    int *__restrict__ changed)
+__device__ __forceinline__ void cswap64(uint64_t &a, uint64_t &b)
 {
-    if (sweep > 0 && changed[sweep - 1] == 0)
-        return;
-    const int n = F.n;
-    int *c_rd = claim3 + (size_t)(sweep % 3) * n;
-    int *c_wr = claim3 + (size_t)((sweep + 1) % 3) * n;
-    int *c_cl = claim3 + (size_t)((sweep + 2) % 3) * n;
-    // reset the table sweep+1 will write to its initial state (pre-existing associations)
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < n; j += gridDim.x * 256)
-        c_cl[j] = claim_init[j];
+    const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo;
+    b = hi;
+}
+__device__ __forceinline__ void top4_insert64(uint64_t t[4], uint64_t k)
+{
+    if (k < t[3]) {
+        t[3] = k;
+        cswap64(t[2], t[3]);
+        cswap64(t[1], t[2]);
+        cswap64(t[0], t[1]);
+    }
+}
 
+// Walks the grid window of one row (Frame::GetFeaturesInArea, Frame.cc:327-380, and the candidate
+// filters of ORBmatcher.cc:82-97 / 1399-1412) with one wave: lanes take the window's cells in the
+// reference's visiting order (ix outer, iy inner), and every surviving candidate becomes a key
+//   distance << 44 | cell sequence << 32 | position in cell << 20 | key point index,
+// whose ascending order is exactly the order in which the sequential loop would prefer candidates.
+// `claim` == nullptr: no claim filtering (pass 1); otherwise key points with claim[idx] < i are hidden.
+// Returns (per lane) the 4 smallest keys of the lane's cells in t[]; the caller merges across lanes.
+__device__ __forceinline__ void proj_walk(const Query &Q, const uint64_t a[4], const FrameDev &F, const int *claim,
+                                          int i, uint64_t t[4])
+{
+    const int lane = threadIdx.x & 63;
+    t[0] = t[1] = t[2] = t[3] = KEY_NONE;
+    const int c0 = (int)floorf((Q.x - F.min_x - Q.r) * F.inv_w);
+    const int c1 = (int)ceilf((Q.x - F.min_x + Q.r) * F.inv_w);
+    const int r0 = (int)floorf((Q.y - F.min_y - Q.r) * F.inv_h);
+    const int r1 = (int)ceilf((Q.y - F.min_y + Q.r) * F.inv_h);
+    const int minCx = max(0, c0), maxCx = min(GC - 1, c1);
+    const int minCy = max(0, r0), maxCy = min(GR - 1, r1);
+    if (minCx >= GC || maxCx < 0 || minCy >= GR || maxCy < 0)
+        return;
+    const int ny = maxCy - minCy + 1;
+    const int ncell = (maxCx - minCx + 1) * ny;
+    const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
+    for (int seq = lane; seq < ncell; seq += 64) {
+        const int ix = minCx + seq / ny, iy = minCy + seq % ny;
+        const int cell = ix * GR + iy;
+        const int beg = F.cell_start[cell], end = F.cell_start[cell + 1];
+        for (int p = beg; p < end; p++) {
+            const int idx = F.cell_items[p];
+            if (check_levels) {
+                const int oct = F.kp_octave[idx];
+                if (oct < Q.min_level)
+                    continue;
+                if (Q.max_level >= 0 && oct > Q.max_level)
+                    continue;
+            }
+            const float dx = F.kp_x[idx] - Q.x, dy = F.kp_y[idx] - Q.y;
+            if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r))
+                continue;
+            if (claim && claim[idx] < i)
+                continue;  // held by an earlier row / a pre-existing association
+            const float ur = F.u_right[idx];
+            if (ur > 0) {
+                const float er = fabsf(Q.ur - ur);
+                if (er > Q.r)
+                    continue;
+            }
+            const uint64_t *db = reinterpret_cast<const uint64_t *>(F.desc) + (size_t)idx * 4;
+            uint64_t b[4] = {db[0], db[1], db[2], db[3]};
+            const uint64_t d = (uint64_t)hamming256(a, b);
+            top4_insert64(t, (d << 44) | ((uint64_t)seq << 32) | ((uint64_t)(p - beg) << 20) | (uint64_t)idx);
+        }
+    }
+}
+
+// wave merge of per-lane sorted 4-lists -> every lane holds the 4 smallest keys of the wave
+__device__ __forceinline__ void top4_wave_merge64(uint64_t t[4])
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        uint64_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = __shfl_xor(t[k], off, 64);
+        uint64_t c0 = t[0] < o[3] ? t[0] : o[3], c1 = t[1] < o[2] ? t[1] : o[2];
+        uint64_t c2 = t[2] < o[1] ? t[2] : o[1], c3 = t[3] < o[0] ? t[3] : o[0];
+        cswap64(c0, c2);
+        cswap64(c1, c3);
+        cswap64(c0, c1);
+        cswap64(c2, c3);
+        cswap64(c1, c2);
+        t[0] = c0;
+        t[1] = c1;
+        t[2] = c2;
+        t[3] = c3;
+    }
+}
+
+// Pass 1: one wave per row, the PJ_TOPK best candidates of every row ignoring claims.
+__global__ __launch_bounds__(256) void k_proj_topk(int m, const Query *__restrict__ q,
+                                                   const uint8_t *__restrict__ row_desc, FrameDev F,
+                                                   uint64_t *__restrict__ topk)
+{
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= m)
         return;
     const Query Q = q[i];
-    int result = -1;
+    uint64_t t[4] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
     if (Q.active) {
-        // Frame::GetFeaturesInArea, Frame.cc:332-346
-        const int c0 = (int)floorf((Q.x - F.min_x - Q.r) * F.inv_w);
-        const int c1 = (int)ceilf((Q.x - F.min_x + Q.r) * F.inv_w);
-        const int r0 = (int)floorf((Q.y - F.min_y - Q.r) * F.inv_h);
-        const int r1 = (int)ceilf((Q.y - F.min_y + Q.r) * F.inv_h);
-        const int minCx = max(0, c0), maxCx = min(GC - 1, c1);
-        const int minCy = max(0, r0), maxCy = min(GR - 1, r1);
-        if (!(minCx >= GC || maxCx < 0 || minCy >= GR || maxCy < 0)) {
-            const int ny = maxCy - minCy + 1;
-            const int ncell = (maxCx - minCx + 1) * ny;
-            const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
-            uint64_t a[4];
-            const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
-#pragma unroll
-            for (int w = 0; w < 4; w++)
-                a[w] = da[w];
-            uint64_t k1 = KEY_NONE, k2 = KEY_NONE;
-            for (int seq = lane; seq < ncell; seq += 64) {
-                const int ix = minCx + seq / ny, iy = minCy + seq % ny;
-                const int cell = ix * GR + iy;
-                const int beg = F.cell_start[cell], end = F.cell_start[cell + 1];
-                for (int t = beg; t < end; t++) {
-                    const int idx = F.cell_items[t];
-                    if (check_levels) {
-                        const int oct = F.kp_octave[idx];
-                        if (oct < Q.min_level)
-                            continue;
-                        if (Q.max_level >= 0 && oct > Q.max_level)
-                            continue;
-                    }
-                    const float dx = F.kp_x[idx] - Q.x, dy = F.kp_y[idx] - Q.y;
-                    if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r))
-                        continue;
-                    if (c_rd[idx] < i)
-                        continue;  // held by an earlier row / a pre-existing association
-                    const float ur = F.u_right[idx];
-                    if (ur > 0) {
-                        const float er = fabsf(Q.ur - ur);
-                        if (er > Q.r)
-                            continue;
-                    }
-                    const uint64_t *db = reinterpret_cast<const uint64_t *>(F.desc) + (size_t)idx * 4;
-                    uint64_t b[4] = {db[0], db[1], db[2], db[3]};
-                    const uint64_t d = (uint64_t)hamming256(a, b);
-                    const uint64_t key = (d << 44) | ((uint64_t)seq << 32) | ((uint64_t)(t - beg) << 20) | (uint64_t)idx;
-                    keep2(k1, k2, key);
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint64_t o1 = __shfl_xor(k1, off, 64), o2 = __shfl_xor(k2, off, 64);
-                keep2(k1, k2, o1);
-                keep2(k1, k2, o2);
-            }
-            const int bestDist = (int)(k1 >> 44);
-            if (bestDist <= ORBGPU_TH_HIGH) {
-                const int bestIdx = (int)(k1 & 0xFFFFF);
-                bool accept = true;
-                if (MODE == 0) {
-                    const int bestDist2 = (int)(k2 >> 44);
-                    const int bestLevel = F.kp_octave[bestIdx];
-                    const int bestLevel2 = bestDist2 < 256 ? F.kp_octave[(int)(k2 & 0xFFFFF)] : -1;
-                    if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)
-                        accept = false;  // ORBmatcher.cc:118-121
-                }
-                if (accept)
-                    result = bestIdx;
-            }
-        }
+        const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
+        const uint64_t a[4] = {da[0], da[1], da[2], da[3]};
+        proj_walk(Q, a, F, nullptr, i, t);
+        top4_wave_merge64(t);
     }
-    if (lane == 0) {
-        if (sweep == 0 || match[i] != result)
-            atomicAdd(&changed[sweep], 1);
-        match[i] = result;
-        if (result >= 0 && Q.blocking)
-            atomicMin(&c_wr[result], i);
-    }
+    if (lane < 4)
+        topk[(size_t)i * PJ_TOPK + lane] = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : t[3];
 }
 
-// NB on distance ties inside k_proj_sweep: the sequential loop keeps the first candidate with the
-// smallest distance and, as second, the next one in (distance, visiting order) -- exactly the two
-// smallest keys, because the visiting order (cell sequence, position in cell) is part of the key.
-
-// Exact serial fallback (one wave), used only if PJ_MAX_SWEEPS sweeps did not converge.
+// accept rule.  mode 0: ORBmatcher.cc:114-125 (TH_HIGH, ratio test only on equal levels);
+//               mode 1: ORBmatcher.cc:1424-1430 (TH_HIGH only)
 template <int MODE>
-__global__ __launch_bounds__(64) void k_proj_serial(int m, const Query *__restrict__ q,
-                                                    const uint8_t *__restrict__ row_desc, FrameDev F,
-                                                    float nnratio, const int *__restrict__ claim_init,
-                                                    int *__restrict__ match, int *__restrict__ claim3,
-                                                    int *__restrict__ changed)
+__device__ __forceinline__ int proj_accept(uint64_t k1, uint64_t k2, const FrameDev &F, float nnratio)
 {
-    if (changed[PJ_MAX_SWEEPS - 1] == 0)
-        return;
-    const int lane = threadIdx.x;
-    int *held = claim3;  // 1 = held
-    for (int j = lane; j < F.n; j += 64)
-        held[j] = claim_init[j] < 0 ? 1 : 0;
-    __syncthreads();
-    for (int i = 0; i < m; i++) {
-        const Query Q = q[i];
-        int result = -1;
-        if (Q.active) {
-            const int c0 = (int)floorf((Q.x - F.min_x - Q.r) * F.inv_w);
-            const int c1 = (int)ceilf((Q.x - F.min_x + Q.r) * F.inv_w);
-            const int r0 = (int)floorf((Q.y - F.min_y - Q.r) * F.inv_h);
-            const int r1 = (int)ceilf((Q.y - F.min_y + Q.r) * F.inv_h);
-            const int minCx = max(0, c0), maxCx = min(GC - 1, c1);
-            const int minCy = max(0, r0), maxCy = min(GR - 1, r1);
-            if (!(minCx >= GC || maxCx < 0 || minCy >= GR || maxCy < 0)) {
-                const int ny = maxCy - minCy + 1;
-                const int ncell = (maxCx - minCx + 1) * ny;
-                const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
-                uint64_t a[4];
-                const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
-                for (int w = 0; w < 4; w++)
-                    a[w] = da[w];
-                uint64_t k1 = KEY_NONE, k2 = KEY_NONE;
-                for (int seq = lane; seq < ncell; seq += 64) {
-                    const int ix = minCx + seq / ny, iy = minCy + seq % ny;
-                    const int cell = ix * GR + iy;
-                    const int beg = F.cell_start[cell], end = F.cell_start[cell + 1];
-                    for (int t = beg; t < end; t++) {
-                        const int idx = F.cell_items[t];
-                        if (check_levels) {
-                            const int oct = F.kp_octave[idx];
-                            if (oct < Q.min_level)
-                                continue;
-                            if (Q.max_level >= 0 && oct > Q.max_level)
-                                continue;
-                        }
-                        const float dx = F.kp_x[idx] - Q.x, dy = F.kp_y[idx] - Q.y;
-                        if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r))
-                            continue;
-                        if (held[idx])
-                            continue;
-                        const float ur = F.u_right[idx];
-                        if (ur > 0 && fabsf(Q.ur - ur) > Q.r)
-                            continue;
-                        const uint64_t *db = reinterpret_cast<const uint64_t *>(F.desc) + (size_t)idx * 4;
-                        uint64_t b[4] = {db[0], db[1], db[2], db[3]};
-                        const uint64_t d = (uint64_t)hamming256(a, b);
-                        keep2(k1, k2, (d << 44) | ((uint64_t)seq << 32) | ((uint64_t)(t - beg) << 20) | (uint64_t)idx);
-                    }
-                }
-                for (int off = 32; off > 0; off >>= 1) {
-                    const uint64_t o1 = __shfl_xor(k1, off, 64), o2 = __shfl_xor(k2, off, 64);
-                    keep2(k1, k2, o1);
-                    keep2(k1, k2, o2);
-                }
-                const int bestDist = (int)(k1 >> 44);
-                if (bestDist <= ORBGPU_TH_HIGH) {
-                    const int bestIdx = (int)(k1 & 0xFFFFF);
-                    bool accept = true;
-                    if (MODE == 0) {
-                        const int bestDist2 = (int)(k2 >> 44);
-                        const int bestLevel = F.kp_octave[bestIdx];
-                        const int bestLevel2 = bestDist2 < 256 ? F.kp_octave[(int)(k2 & 0xFFFFF)] : -1;
-                        if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)
-                            accept = false;
-                    }
-                    if (accept)
-                        result = bestIdx;
-                }
-            }
-        }
-        if (lane == 0) {
-            match[i] = result;
-            if (result >= 0 && Q.blocking)
-                held[result] = 1;
-        }
-        __syncthreads();
+    const int bestDist = (int)(k1 >> 44);
+    if (bestDist > ORBGPU_TH_HIGH)
+        return -1;
+    const int bestIdx = (int)(k1 & 0xFFFFF);
+    if (MODE == 0) {
+        const int bestDist2 = (int)(k2 >> 44);
+        const int bestLevel = F.kp_octave[bestIdx];
+        const int bestLevel2 = bestDist2 < 256 ? F.kp_octave[(int)(k2 & 0xFFFFF)] : -1;
+        if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)
+            return -1;
     }
+    return bestIdx;
 }
 
-// Write F.mvpMapPoints: the LAST claimant of a key point wins (rows are visited in order and a
-// non-blocking claimant can be overwritten, :123 / :1428); then the rotation consistency of
-// :1448-1467: every accepted row whose bin is not among the three maxima clears its key point.
-__global__ __launch_bounds__(256) void k_proj_finish(int m, int n, const int *__restrict__ match,
-                                                     const float *__restrict__ row_angle,
-                                                     const float *__restrict__ kp_angle, int check_orientation,
-                                                     int *__restrict__ last_claim /*scratch [n]*/,
-                                                     int *__restrict__ kp_to_mp, int *__restrict__ nmatches)
+// Pass 2: the greedy claim order as a fixpoint, ONE workgroup.  Claim tables (two, ping-pong) live in
+// LDS.  A sweep re-decides every row from its cached candidate list, hiding key points that rows < i
+// with Observations()>0 claimed in the previous sweep; rows whose list cannot decide are re-walked by a
+// whole wave with the claim filter.  A sweep without changes is the sequential result; the loop is
+// bounded by m+1.  Then F.mvpMapPoints is written: the LAST claimant of a key point wins (a
+// non-blocking claimant can be overwritten, :123 / :1428) and, for mode 1, every accepted row whose
+// rotation bin is not among the three maxima clears its key point (:1448-1467).
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__restrict__ q,
+                                                       const uint8_t *__restrict__ row_desc, FrameDev F,
+                                                       float nnratio, const int *__restrict__ claim_init,
+                                                       const uint64_t *__restrict__ topk, int *__restrict__ match,
+                                                       int *__restrict__ slow, const float *__restrict__ row_angle,
+                                                       const float *__restrict__ kp_angle, int check_orientation,
+                                                       int *__restrict__ kp_to_mp, int *__restrict__ nmatches,
+                                                       int *__restrict__ sweeps_out)
 {
+    extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int histo[ORBGPU_HISTO_LENGTH];
     __shared__ int s_keep[3];
-    __shared__ int s_count;
-    if (threadIdx.x < ORBGPU_HISTO_LENGTH)
-        histo[threadIdx.x] = 0;
-    if (threadIdx.x == 0)
-        s_count = 0;
-    for (int j = threadIdx.x; j < n; j += 256)
+    __shared__ int s_count, s_changed, s_nslow;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n = F.n;
+    int *claimA = reinterpret_cast<int *>(smem);
+    int *claimB = claimA + n;
+    for (int j = tid; j < n; j += nt)
+        claimA[j] = claim_init[j];
+    for (int i = tid; i < m; i += nt)
+        match[i] = -2;
+    __syncthreads();
+    int sweeps = 0;
+    for (int iter = 0; iter <= m + 1; iter++) {
+        for (int j = tid; j < n; j += nt)
+            claimB[j] = claim_init[j];
+        if (tid == 0) {
+            s_changed = 0;
+            s_nslow = 0;
+        }
+        __syncthreads();
+        bool changed = false;
+        for (int i = tid; i < m; i += nt) {
+            int result = -1;
+            bool decided = true;
+            if (q[i].active) {
+                const uint64_t *tk = topk + (size_t)i * PJ_TOPK;
+                uint64_t k1 = KEY_NONE, k2 = KEY_NONE;
+                int found = 0;
+                bool complete = false;
+#pragma unroll
+                for (int k = 0; k < PJ_TOPK; k++) {
+                    const uint64_t key = tk[k];
+                    if (key == KEY_NONE) {
+                        complete = true;
+                    } else if (found < 2 && !(claimA[(int)(key & 0xFFFFF)] < i)) {
+                        if (found == 0)
+                            k1 = key;
+                        else
+                            k2 = key;
+                        found++;
+                    }
+                }
+                const int need = MODE == 0 ? 2 : 1;
+                decided = found >= need || complete || (found == 1 && (int)(k1 >> 44) > ORBGPU_TH_HIGH);
+                if (decided && found > 0)
+                    result = proj_accept<MODE>(k1, k2, F, nnratio);
+            }
+            if (!decided) {
+                slow[atomicAdd(&s_nslow, 1)] = i;
+                continue;
+            }
+            if (match[i] != result) {
+                changed = true;
+                match[i] = result;
+            }
+            if (result >= 0 && q[i].blocking)
+                atomicMin(&claimB[result], i);
+        }
+        __syncthreads();
+        {
+            const int nslow = s_nslow;
+            const int wave = tid >> 6, nw = nt >> 6;
+            for (int r = wave; r < nslow; r += nw) {
+                const int i = slow[r];
+                const Query Q = q[i];
+                const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
+                const uint64_t a[4] = {da[0], da[1], da[2], da[3]};
+                uint64_t t[4];
+                proj_walk(Q, a, F, claimA, i, t);
+                top4_wave_merge64(t);
+                if ((tid & 63) == 0) {
+                    int result = -1;
+                    if (t[0] != KEY_NONE)
+                        result = proj_accept<MODE>(t[0], t[1], F, nnratio);
+                    if (match[i] != result) {
+                        changed = true;
+                        match[i] = result;
+                    }
+                    if (result >= 0 && Q.blocking)
+                        atomicMin(&claimB[result], i);
+                }
+            }
+        }
+        if (changed)
+            s_changed = 1;
+        __syncthreads();
+        sweeps++;
+        const bool again = s_changed != 0;
+        __syncthreads();
+        if (!again)
+            break;
+        int *tmp = claimA;
+        claimA = claimB;
+        claimB = tmp;
+    }
+
+    // ---- finish
+    int *last_claim = claimA;  // reuse
+    for (int j = tid; j < n; j += nt)
         last_claim[j] = -1;
+    if (tid < ORBGPU_HISTO_LENGTH)
+        histo[tid] = 0;
+    if (tid == 0)
+        s_count = 0;
     __syncthreads();
     int cnt = 0;
-    for (int i = threadIdx.x; i < m; i += 256) {
+    for (int i = tid; i < m; i += nt) {
         const int j = match[i];
         if (j < 0)
             continue;
@@ -284,12 +324,12 @@ __global__ __launch_bounds__(256) void k_proj_finish(int m, int n, const int *__
             atomicAdd(&histo[rot_bin(row_angle[i], kp_angle[j])], 1);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < n; j += 256)
+    for (int j = tid; j < n; j += nt)
         if (last_claim[j] >= 0)
             kp_to_mp[j] = last_claim[j];  // any claim overrides a previous (non-blocking) association
     __syncthreads();
     if (check_orientation) {
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             int i1, i2, i3;
             three_maxima(histo, ORBGPU_HISTO_LENGTH, i1, i2, i3);
             s_keep[0] = i1;
@@ -297,7 +337,7 @@ __global__ __launch_bounds__(256) void k_proj_finish(int m, int n, const int *__
             s_keep[2] = i3;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < m; i += 256) {
+        for (int i = tid; i < m; i += nt) {
             const int j = match[i];
             if (j < 0)
                 continue;
@@ -309,47 +349,61 @@ __global__ __launch_bounds__(256) void k_proj_finish(int m, int n, const int *__
         }
     }
     cnt = wave_reduce_add(cnt);
-    if ((threadIdx.x & 63) == 0)
+    if ((tid & 63) == 0)
         atomicAdd(&s_count, cnt);
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (tid == 0) {
         *nmatches = s_count;
+        *sweeps_out = sweeps;
+    }
 }
 
-// ---- host helpers ---------------------------------------------------------------------------
-struct Uploader {
-    std::vector<DevBuf> bufs;
-    int rc = ORBGPU_OK;
-    ~Uploader()
+// ---- host side -----------------------------------------------------------------------------
+// Per-thread workspace: device buffers that grow on demand and are reused by every call of this host
+// thread (the reference constructs an ORBmatcher on the stack per call site; allocation per call would
+// dominate the kernel time).
+struct ProjWorkspace {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    DevBuf kp_x, kp_y, kp_octave, u_right, desc, cell_start, cell_items, kp_angle;
+    DevBuf queries, row_desc, row_angle, claim_init, topk, match, slow, k2m, out;
+    ~ProjWorkspace()
     {
-        for (auto &b : bufs)
-            b.release();
+        // device memory is released with the process; the HIP runtime may already be gone here
     }
-    void *put(const void *src, size_t bytes)
-    {
-        bufs.emplace_back();
-        DevBuf &b = bufs.back();
-        if (rc != ORBGPU_OK)
-            return nullptr;
-        rc = b.reserve(std::max<size_t>(bytes, 16));
-        if (rc != ORBGPU_OK)
-            return nullptr;
-        if (src && bytes) {
-            hipError_t e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                set_error("hipMemcpy H2D: %s", hipGetErrorString(e));
-                rc = ORBGPU_EHIP;
-            }
-        }
-        return b.p;
-    }
-    void *alloc(size_t bytes) { return put(nullptr, bytes); }
 };
+
+static int workspace(int device_id, ProjWorkspace **out)
+{
+    static thread_local ProjWorkspace ws;
+    if (ws.device != device_id) {
+        ws = ProjWorkspace();
+        ws.device = device_id;
+        hipError_t e = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            ws.device = -1;
+            set_error("hipStreamCreate: %s", hipGetErrorString(e));
+            return ORBGPU_EHIP;
+        }
+    }
+    *out = &ws;
+    return ORBGPU_OK;
+}
+
+static int put(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
+{
+    int rc = b.reserve(std::max<size_t>(bytes, 16));
+    if (rc != ORBGPU_OK)
+        return rc;
+    if (src && bytes)
+        ORBGPU_HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+    return ORBGPU_OK;
+}
 
 static int validate_frame(const orbgpu_frame_view *f)
 {
     ORBGPU_REQUIRE(f, "null frame view");
-    ORBGPU_REQUIRE(f->n >= 0 && f->n < (1 << 20), "frame key point count out of range");
+    ORBGPU_REQUIRE(f->n >= 0 && f->n <= 16384, "frame key point count out of range (max 16384)");
     ORBGPU_REQUIRE(f->nlevels >= 1 && f->nlevels <= ORBGPU_MAX_LEVELS && f->scale_factors, "bad scale factors");
     ORBGPU_REQUIRE(f->cell_start && f->cell_items, "null grid");
     if (f->n > 0)
@@ -365,28 +419,42 @@ static int validate_frame(const orbgpu_frame_view *f)
     return ORBGPU_OK;
 }
 
-static FrameDev upload_frame(Uploader &up, const orbgpu_frame_view *f)
+#define PJ_TRY(x)                                                                                            \
+    do {                                                                                                     \
+        int rc__ = (x);                                                                                      \
+        if (rc__ != ORBGPU_OK)                                                                               \
+            return rc__;                                                                                     \
+    } while (0)
+
+static int upload_frame(ProjWorkspace &ws, const orbgpu_frame_view *f, FrameDev &F)
 {
-    FrameDev F;
     const size_t n = (size_t)f->n;
+    hipStream_t st = ws.stream;
+    PJ_TRY(put(ws.kp_x, f->kp_x, n * 4, st));
+    PJ_TRY(put(ws.kp_y, f->kp_y, n * 4, st));
+    PJ_TRY(put(ws.kp_octave, f->kp_octave, n * 4, st));
+    PJ_TRY(put(ws.u_right, f->u_right, n * 4, st));
+    PJ_TRY(put(ws.desc, f->desc, n * 32, st));
+    PJ_TRY(put(ws.cell_start, f->cell_start, (size_t)(GC * GR + 1) * 4, st));
+    PJ_TRY(put(ws.cell_items, f->cell_items, std::max<size_t>((size_t)f->cell_start[GC * GR], 1) * 4, st));
     F.n = f->n;
-    F.kp_x = (const float *)up.put(f->kp_x, n * 4);
-    F.kp_y = (const float *)up.put(f->kp_y, n * 4);
-    F.kp_octave = (const int *)up.put(f->kp_octave, n * 4);
-    F.u_right = (const float *)up.put(f->u_right, n * 4);
-    F.desc = (const uint8_t *)up.put(f->desc, n * 32);
+    F.kp_x = ws.kp_x.as<float>();
+    F.kp_y = ws.kp_y.as<float>();
+    F.kp_octave = ws.kp_octave.as<int>();
+    F.u_right = ws.u_right.as<float>();
+    F.desc = ws.desc.as<uint8_t>();
     F.min_x = f->min_x;
     F.min_y = f->min_y;
     F.inv_w = f->grid_inv_w;
     F.inv_h = f->grid_inv_h;
-    F.cell_start = (const int *)up.put(f->cell_start, (size_t)(GC * GR + 1) * 4);
-    F.cell_items = (const int *)up.put(f->cell_items, std::max<size_t>((size_t)f->cell_start[GC * GR], 1) * 4);
-    return F;
+    F.cell_start = ws.cell_start.as<int>();
+    F.cell_items = ws.cell_items.as<int>();
+    return ORBGPU_OK;
 }
 
-// Runs sweeps + fallback + finish for prepared queries. kp_to_mp (host, in/out).
+// Runs pass 1 + pass 2 for prepared queries. kp_to_mp (host, in/out).
 template <int MODE>
-static int run_projection(Uploader &up, const FrameDev &F, const std::vector<Query> &queries,
+static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vector<Query> &queries,
                           const uint8_t *row_desc_host, const float *row_angle_host, const float *kp_angle_host,
                           const std::vector<int> &claim_init, float nnratio, int check_orientation,
                           int32_t *kp_to_mp, int32_t *nmatches)
@@ -396,37 +464,37 @@ static int run_projection(Uploader &up, const FrameDev &F, const std::vector<Que
         *nmatches = 0;
         return ORBGPU_OK;
     }
-    Query *dq = (Query *)up.put(queries.data(), sizeof(Query) * m);
-    uint8_t *ddesc = (uint8_t *)up.put(row_desc_host, (size_t)m * 32);
-    int *dinit = (int *)up.put(claim_init.data(), sizeof(int) * n);
-    int *dmatch = (int *)up.alloc(sizeof(int) * m);
-    int *dclaim = (int *)up.alloc(sizeof(int) * 3 * (size_t)n);
-    int *dchanged = (int *)up.alloc(sizeof(int) * (PJ_MAX_SWEEPS + 1));
-    int *dk2m = (int *)up.put(kp_to_mp, sizeof(int) * n);
-    int *dnm = (int *)up.alloc(sizeof(int));
-    float *drang = nullptr, *dkang = nullptr;
+    hipStream_t st = ws.stream;
+    PJ_TRY(put(ws.queries, queries.data(), sizeof(Query) * m, st));
+    PJ_TRY(put(ws.row_desc, row_desc_host, (size_t)m * 32, st));
+    PJ_TRY(put(ws.claim_init, claim_init.data(), sizeof(int) * n, st));
+    PJ_TRY(put(ws.k2m, kp_to_mp, sizeof(int) * n, st));
+    PJ_TRY(ws.topk.reserve(sizeof(uint64_t) * PJ_TOPK * (size_t)m));
+    PJ_TRY(ws.match.reserve(sizeof(int) * m));
+    PJ_TRY(ws.slow.reserve(sizeof(int) * m));
+    PJ_TRY(ws.out.reserve(2 * sizeof(int)));
     if (check_orientation) {
-        drang = (float *)up.put(row_angle_host, sizeof(float) * m);
-        dkang = (float *)up.put(kp_angle_host, sizeof(float) * n);
+        PJ_TRY(put(ws.row_angle, row_angle_host, sizeof(float) * m, st));
+        PJ_TRY(put(ws.kp_angle, kp_angle_host, sizeof(float) * n, st));
     }
-    if (up.rc != ORBGPU_OK)
-        return up.rc;
-    // tables 0 and 1 start at the initial state
-    ORBGPU_HIP_TRY(hipMemcpy(dclaim, dinit, sizeof(int) * n, hipMemcpyDeviceToDevice));
-    ORBGPU_HIP_TRY(hipMemcpy(dclaim + n, dinit, sizeof(int) * n, hipMemcpyDeviceToDevice));
-    ORBGPU_HIP_TRY(hipMemset(dchanged, 0, sizeof(int) * (PJ_MAX_SWEEPS + 1)));
-    const dim3 grid((m + 3) / 4);
-    for (int s = 0; s < PJ_MAX_SWEEPS; s++)
-        hipLaunchKernelGGL(k_proj_sweep<MODE>, grid, dim3(256), 0, 0, s, m, dq, ddesc, F, nnratio, dinit, dmatch, dclaim,
-                           dchanged);
-    hipLaunchKernelGGL(k_proj_serial<MODE>, dim3(1), dim3(64), 0, 0, m, dq, ddesc, F, nnratio, dinit, dmatch, dclaim,
-                       dchanged);
-    hipLaunchKernelGGL(k_proj_finish, dim3(1), dim3(256), 0, 0, m, n, dmatch, drang, dkang, check_orientation,
-                       dclaim + n, dk2m, dnm);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+        ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_proj_topk, dim3((m + 3) / 4), dim3(256), 0, st, m, ws.queries.as<Query>(),
+                       ws.row_desc.as<uint8_t>(), F, ws.topk.as<uint64_t>());
+    hipLaunchKernelGGL(k_proj_resolve<MODE>, dim3(1), dim3(1024), (size_t)8 * n, st, m, ws.queries.as<Query>(),
+                       ws.row_desc.as<uint8_t>(), F, nnratio, ws.claim_init.as<int>(), ws.topk.as<uint64_t>(),
+                       ws.match.as<int>(), ws.slow.as<int>(), ws.row_angle.as<float>(), ws.kp_angle.as<float>(),
+                       check_orientation, ws.k2m.as<int>(), ws.out.as<int>(), ws.out.as<int>() + 1);
     ORBGPU_HIP_TRY(hipGetLastError());
-    ORBGPU_HIP_TRY(hipDeviceSynchronize());
-    ORBGPU_HIP_TRY(hipMemcpy(kp_to_mp, dk2m, sizeof(int) * n, hipMemcpyDeviceToHost));
-    ORBGPU_HIP_TRY(hipMemcpy(nmatches, dnm, sizeof(int), hipMemcpyDeviceToHost));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(kp_to_mp, ws.k2m.p, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(nmatches, ws.out.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipStreamSynchronize(st));
     return ORBGPU_OK;
 }
 
@@ -534,9 +602,13 @@ int orbgpu_search_by_projection(const orbgpu_frame_view *f, const orbgpu_mappoin
         const bool held = v == -2 || (v >= 0 && (mp->obs_pos ? mp->obs_pos[v] != 0 : true));
         init[j] = held ? -1 : INT_MAX;
     }
-    Uploader up;
-    FrameDev F = upload_frame(up, f);
-    return run_projection<0>(up, F, q, mp->desc, nullptr, nullptr, init, nnratio, 0, kp_to_mp, nmatches);
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    FrameDev F;
+    if ((rc = upload_frame(*ws, f, F)) != ORBGPU_OK)
+        return rc;
+    return run_projection<0>(*ws, F, q, mp->desc, nullptr, nullptr, init, nnratio, 0, kp_to_mp, nmatches);
 }
 
 int orbgpu_search_by_projection_last(const orbgpu_frame_view *cur, const float *cur_Tcw, float fx, float fy,
@@ -614,9 +686,13 @@ int orbgpu_search_by_projection_last(const orbgpu_frame_view *cur, const float *
         const bool held = v == -2 || (v >= 0 && (last->obs_pos ? last->obs_pos[v] != 0 : true));
         init[j] = held ? -1 : INT_MAX;
     }
-    Uploader up;
-    FrameDev F = upload_frame(up, cur);
-    return run_projection<1>(up, F, q, last->desc, last->kp_angle, cur->kp_angle, init, 0.f, check_orientation, kp_to_mp,
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    FrameDev F;
+    if ((rc = upload_frame(*ws, cur, F)) != ORBGPU_OK)
+        return rc;
+    return run_projection<1>(*ws, F, q, last->desc, last->kp_angle, cur->kp_angle, init, 0.f, check_orientation, kp_to_mp,
                              nmatches);
 }
 

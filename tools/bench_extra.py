@@ -1,0 +1,105 @@
+"""Secondary measurements (not the contract line): C3 projection matcher and C4 dense-map update.
+
+    python tools/bench_extra.py [c3] [c4]
+Prints one JSON object per configuration.  Inputs are generated with the oracle-side scenario helper
+of the tests (tests/scenario.py) BEFORE timing; only calls through the C ABI are timed.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def c3():
+    from oracle import oracle_py as O
+    from orb_slam2_map_amd import lib as G
+    from orb_slam2_map_amd.synth import Stream
+    import scenario
+    rng = np.random.default_rng(5678)
+    st = Stream(1280, 960, 1234)
+    nprev = 5
+    ge = G.ORBextractor(2000, max_batch=nprev + 1)
+    t_cur = 12
+    ts = [t_cur - 1 - i for i in range(nprev)] + [t_cur]
+    frames = [st.frame(t) for t in ts]
+    imgs = np.stack([f[0] for f in frames])
+    ks, ds = ge.extract_batch(imgs)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ge.extract_batch(imgs[-1:])
+    t_ext = (time.perf_counter() - t0) / 5
+    sf = ge.GetScaleFactors()
+    Tcw = scenario.rigid()
+    gf = scenario.make_frame(G, ks[-1], ds[-1], frames[-1][2], st, sf)
+    ox, oy = st.offset(t_cur)
+    wp, dsc, octv = [], [], []
+    for i, t in enumerate(ts[:-1]):
+        px, py = st.offset(t)
+        P, _ = scenario.world_points_from_prev(ks[i], frames[i][2], (ox - px, oy - py), st, Tcw, rng)
+        wp.append(P), dsc.append(ds[i]), octv.append(ks[i]["octave"])
+    wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
+    mp = scenario.local_map(O, st, Tcw, wp, dsc, octv, sf, rng)
+    k0 = np.full(gf.n, -1, np.int32)
+    m = G.ORBmatcher(0.8)
+    n, _ = m.SearchByProjection(gf, mp, 3.0, k0)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.SearchByProjection(gf, mp, 3.0, k0)
+    t_proj = (time.perf_counter() - t0) / reps
+    of = scenario.make_frame(O, ks[-1], ds[-1], frames[-1][2], st, sf)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.search_by_projection(of, mp, 3.0, 0.8, k0)
+    t_cpu = (time.perf_counter() - t0) / reps
+    print(json.dumps({"config": "C3: 1280x960, 2000 features, SearchByProjection vs %d map points (%d in view)" % (
+        len(wp), int(mp["in_view"].sum())), "matches": n, "gpu_host_api_ms_per_call": t_proj * 1e3,
+        "extract_single_frame_host_api_ms": t_ext * 1e3, "oracle_cpu_ms_per_call": t_cpu * 1e3}))
+
+
+def c4():
+    from oracle import oracle_py as O
+    from orb_slam2_map_amd import lib as G
+    from orb_slam2_map_amd.synth import Stream
+    import scenario
+    st = Stream(640, 480, 1234)
+    nkf = 20
+    frames = [st.frame(7 * i) for i in range(nkf)]
+    poses = [scenario.rigid(0.004 * i, -0.006 * i, 0.002 * i, (0.04 * i, 0.01 * i, 0.015 * i)) for i in range(nkf)]
+    cam = (float(st.fx), float(st.fy), float(st.cx), float(st.cy))
+    cloud = G.PointCloudMapping(0.01)
+    cloud.insertKeyFrame(frames[0][2], frames[0][1], *cam, poses[0])
+    per = []
+    for i in range(1, nkf):
+        t0 = time.perf_counter()
+        cloud.insertKeyFrame(frames[i][2], frames[i][1], *cam, poses[i])
+        per.append(time.perf_counter() - t0)
+    size = cloud.size()
+    # oracle timing for the same sequence (first 6 key frames only: it re-sorts the whole map each time)
+    omap = np.zeros(0, O.POINT_DTYPE)
+    tcpu = []
+    for i in range(6):
+        t0 = time.perf_counter()
+        R, t = O.pose_inverse(poses[i])
+        new = O.transform_points(O.backproject(frames[i][2], frames[i][1], *cam), R, t)
+        omap, _ = O.voxel_filter(np.concatenate([omap, new]), 0.01)
+        tcpu.append(time.perf_counter() - t0)
+    print(json.dumps({"config": "C4: 640x480 key frames, stride-3 back-projection + transform + voxel filter (0.01 m) "
+                                "of the whole accumulated map per key frame", "keyframes": nkf, "final_map_points": size,
+                      "gpu_ms_per_keyframe_first": per[0] * 1e3, "gpu_ms_per_keyframe_last": per[-1] * 1e3,
+                      "gpu_ms_per_keyframe_mean": float(np.mean(per)) * 1e3,
+                      "oracle_cpu_ms_per_keyframe_6th": tcpu[-1] * 1e3}))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c3", "c4"]
+    if "c3" in which:
+        c3()
+    if "c4" in which:
+        c4()
