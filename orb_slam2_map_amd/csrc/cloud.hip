@@ -211,13 +211,36 @@ __global__ __launch_bounds__(256) void k_vox_minmax(const Point *__restrict__ pt
         }
         nf += __shfl_xor(nf, off, 64);
     }
-    if ((threadIdx.x & 63) == 0 && nf) {
+    // one set of atomics per workgroup (all workgroups hit the same 7 words: keep them few)
+    __shared__ unsigned s_mn[4][3], s_mx[4][3];
+    __shared__ int s_nf[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            atomicMin(&st->mn[a], mn[a]);
-            atomicMax(&st->mx[a], mx[a]);
+            s_mn[wave][a] = mn[a];
+            s_mx[wave][a] = mx[a];
         }
-        atomicAdd(&st->nfinite, nf);
+        s_nf[wave] = nf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 4; w++)
+            tot += s_nf[w];
+        if (tot) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                unsigned lo = 0xFFFFFFFFu, hi = 0u;
+                for (int w = 0; w < 4; w++) {
+                    lo = min(lo, s_mn[w][a]);
+                    hi = max(hi, s_mx[w][a]);
+                }
+                atomicMin(&st->mn[a], lo);
+                atomicMax(&st->mx[a], hi);
+            }
+            atomicAdd(&st->nfinite, tot);
+        }
     }
 }
 
@@ -560,7 +583,7 @@ static int voxel_filter_device(VoxelWorkspace &ws, const Point *in, long long n,
     if (n == 0)
         return ORBGPU_OK;
     const int nb256 = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(k_vox_minmax, dim3(std::min(nb256, 2048)), dim3(256), 0, st, in, n, S);
+    hipLaunchKernelGGL(k_vox_minmax, dim3(std::min(nb256, 256)), dim3(256), 0, st, in, n, S);
     hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(1), 0, st, S, inv);
     uint32_t *k0 = ws.keys[0].as<uint32_t>(), *k1 = ws.keys[1].as<uint32_t>();
     uint32_t *v0 = ws.vals[0].as<uint32_t>(), *v1 = ws.vals[1].as<uint32_t>();
