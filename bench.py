@@ -59,7 +59,7 @@ def algorithmic_bytes(stage, n_kp, n_cand):
 
 
 STAGE_KERNELS = {"pyramid": ["k_border0"] + ["k_resize_fast"] * 7, "fast_score": ["k_fast_score"],
-                 "fast_nms": ["k_fast_nms"], "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
+                 "fast_nms": ["k_fast_nmsbits", "k_fast_cells"], "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
                  "blur": ["k_blur"], "describe": ["k_describe"]}
 
 
