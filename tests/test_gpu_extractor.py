@@ -60,6 +60,34 @@ def test_extract_matches_oracle_stage_by_stage(gpu, oracle, w, h, nfeat, batch):
         assert len(gk[f]) <= ge.max_keypoints(w, h)
 
 
+@pytest.mark.parametrize("nfeat,sf,nl,ini,mn", [(500, 1.5, 5, 20, 7), (1500, 1.1, 12, 20, 7), (1000, 1.2, 8, 30, 10),
+                                                 (800, 2.0, 3, 12, 12), (1000, 1.2, 8, 7, 20), (300, 1.3, 6, 40, 0),
+                                                 (1000, 2.5, 3, 20, 7)])
+def test_non_default_parameters(gpu, oracle, stream640, nfeat, sf, nl, ini, mn):
+    """Other YAML settings (Tracking.cc:193-197): scale factors (2.5 takes the generic resize kernel),
+    level counts, thresholds -- including iniThFAST < minThFAST and a zero threshold."""
+    img = stream640.frame(9)[0]
+    ge = gpu.ORBextractor(nfeat, sf, nl, ini, mn)
+    oe = oracle.Extractor(nfeat, sf, nl, ini, mn)
+    gk, gd = ge(img)
+    ok, od = oe.extract(img)
+    check_stages(gpu, ge, oe, 0, nl, "params %s" % ((nfeat, sf, nl, ini, mn),))
+    assert_same_keypoints(gk, gd, ok, od, "params %s" % ((nfeat, sf, nl, ini, mn),))
+
+
+def test_reconfigure_between_sizes(gpu, oracle):
+    """One handle, images of different sizes in sequence (the geometry tables are rebuilt)."""
+    from orb_slam2_map_amd.synth import Stream
+    ge = gpu.ORBextractor(1000, max_batch=2)
+    oe = oracle.Extractor(1000)
+    for (w, h, seed) in ((640, 480, 5), (400, 300, 6), (752, 480, 7), (640, 480, 8)):
+        imgs = Stream(w, h, seed).gray_batch(0, 2)
+        gk, gd = ge.extract_batch(imgs)
+        for f in range(2):
+            ok, od = oe.extract(imgs[f])
+            assert_same_keypoints(gk[f], gd[f], ok, od, "%dx%d seed %d frame %d" % (w, h, seed, f))
+
+
 def test_getters_match_oracle(gpu, oracle):
     for nfeat, sf, nl in ((1000, 1.2, 8), (2000, 1.2, 8), (500, 1.5, 5), (1500, 1.1, 12)):
         ge = gpu.ORBextractor(nfeat, sf, nl)
