@@ -469,46 +469,56 @@ int orbgpu_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *
         *nmatches = 0;
         return ORBGPU_OK;
     }
-    const int cap = std::max(na, nb);
-    orbgpu_matcher *m = nullptr;
-    int rc = orbgpu_matcher_create(device_id, 1, cap, &m);
+    // per-thread workspace (matcher handle + staging buffers) reused across calls: the reference builds an
+    // ORBmatcher on the stack per call site, so allocating per call would dominate the kernel time
+    struct Ws {
+        int device = -1, cap = 0;
+        orbgpu_matcher *m = nullptr;
+        hipStream_t st = nullptr;
+        DevBuf da, db, aa, ab, va, cnt, mb, nm;
+    };
+    static thread_local Ws ws;
+    int rc = select_device(device_id);
     if (rc != ORBGPU_OK)
         return rc;
-    DevBuf da, db, aa, ab, va, cnt, mb, nm;
-    auto cleanup = [&]() {
-        for (DevBuf *b : {&da, &db, &aa, &ab, &va, &cnt, &mb, &nm})
-            b->release();
-        orbgpu_matcher_destroy(m);
-    };
-#define TRY_RC(x) if ((rc = (x)) != ORBGPU_OK) { cleanup(); return rc; }
-#define TRY_HIP(x) { hipError_t e__ = (x); if (e__ != hipSuccess) { set_error("%s: %s", #x, hipGetErrorString(e__)); cleanup(); return ORBGPU_EHIP; } }
-    TRY_RC(da.reserve((size_t)cap * 32));
-    TRY_RC(db.reserve((size_t)cap * 32));
-    TRY_RC(aa.reserve((size_t)cap * 4));
-    TRY_RC(ab.reserve((size_t)cap * 4));
-    TRY_RC(va.reserve((size_t)cap));
-    TRY_RC(cnt.reserve(8));
-    TRY_RC(mb.reserve((size_t)cap * 4));
-    TRY_RC(nm.reserve(4));
-    TRY_HIP(hipMemcpy(da.p, desc_a, (size_t)na * 32, hipMemcpyHostToDevice));
-    TRY_HIP(hipMemcpy(db.p, desc_b, (size_t)nb * 32, hipMemcpyHostToDevice));
+    const int need = std::max(na, nb);
+    if (ws.device != device_id || ws.cap < need) {
+        if (ws.m)
+            orbgpu_matcher_destroy(ws.m);
+        ws.m = nullptr;
+        const int cap = std::min(4096, std::max(need, 1024));
+        if ((rc = orbgpu_matcher_create(device_id, 1, cap, &ws.m)) != ORBGPU_OK)
+            return rc;
+        if (!ws.st)
+            ORBGPU_HIP_TRY(hipStreamCreateWithFlags(&ws.st, hipStreamNonBlocking));
+        if ((rc = ws.da.reserve((size_t)cap * 32)) != ORBGPU_OK || (rc = ws.db.reserve((size_t)cap * 32)) != ORBGPU_OK ||
+            (rc = ws.aa.reserve((size_t)cap * 4)) != ORBGPU_OK || (rc = ws.ab.reserve((size_t)cap * 4)) != ORBGPU_OK ||
+            (rc = ws.va.reserve((size_t)cap)) != ORBGPU_OK || (rc = ws.cnt.reserve(8)) != ORBGPU_OK ||
+            (rc = ws.mb.reserve((size_t)cap * 4)) != ORBGPU_OK || (rc = ws.nm.reserve(4)) != ORBGPU_OK)
+            return rc;
+        ws.device = device_id;
+        ws.cap = cap;
+    }
+    const int cap = ws.cap;
+    hipStream_t st = ws.st;
+    ORBGPU_HIP_TRY(hipMemcpyAsync(ws.da.p, desc_a, (size_t)na * 32, hipMemcpyHostToDevice, st));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(ws.db.p, desc_b, (size_t)nb * 32, hipMemcpyHostToDevice, st));
     if (check_orientation) {
-        TRY_HIP(hipMemcpy(aa.p, angle_a, (size_t)na * 4, hipMemcpyHostToDevice));
-        TRY_HIP(hipMemcpy(ab.p, angle_b, (size_t)nb * 4, hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(ws.aa.p, angle_a, (size_t)na * 4, hipMemcpyHostToDevice, st));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(ws.ab.p, angle_b, (size_t)nb * 4, hipMemcpyHostToDevice, st));
     }
     if (valid_a)
-        TRY_HIP(hipMemcpy(va.p, valid_a, (size_t)na, hipMemcpyHostToDevice));
-    int counts[2] = {na, nb};
-    TRY_HIP(hipMemcpy(cnt.p, counts, 8, hipMemcpyHostToDevice));
-    TRY_RC(orbgpu_match_bf_batch_device(m, 1, cap, da.as<uint8_t>(), aa.p, valid_a ? va.as<uint8_t>() : nullptr,
-                                        cnt.as<int>(), db.as<uint8_t>(), ab.p, cnt.as<int>() + 1, 4, th_low, nnratio,
-                                        check_orientation, mb.as<int>(), nm.as<int>(), nullptr));
-    TRY_HIP(hipDeviceSynchronize());
-    TRY_HIP(hipMemcpy(match_b, mb.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
-    TRY_HIP(hipMemcpy(nmatches, nm.p, 4, hipMemcpyDeviceToHost));
-#undef TRY_RC
-#undef TRY_HIP
-    cleanup();
+        ORBGPU_HIP_TRY(hipMemcpyAsync(ws.va.p, valid_a, (size_t)na, hipMemcpyHostToDevice, st));
+    const int counts[2] = {na, nb};
+    ORBGPU_HIP_TRY(hipMemcpyAsync(ws.cnt.p, counts, 8, hipMemcpyHostToDevice, st));
+    if ((rc = orbgpu_match_bf_batch_device(ws.m, 1, cap, ws.da.as<uint8_t>(), ws.aa.p,
+                                           valid_a ? ws.va.as<uint8_t>() : nullptr, ws.cnt.as<int>(),
+                                           ws.db.as<uint8_t>(), ws.ab.p, ws.cnt.as<int>() + 1, 4, th_low, nnratio,
+                                           check_orientation, ws.mb.as<int>(), ws.nm.as<int>(), st)) != ORBGPU_OK)
+        return rc;
+    ORBGPU_HIP_TRY(hipMemcpyAsync(match_b, ws.mb.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(nmatches, ws.nm.p, 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipStreamSynchronize(st));
     return ORBGPU_OK;
 }
 

@@ -97,8 +97,43 @@ def c4():
                       "oracle_cpu_ms_per_keyframe_6th": tcpu[-1] * 1e3}))
 
 
+def c1():
+    """Single-stream real-time use (one Tracking thread): per-frame latency of the host entry points."""
+    from orb_slam2_map_amd import lib as G
+    from orb_slam2_map_amd.synth import Stream
+    st = Stream(640, 480, 1234)
+    imgs = [st.frame(t)[0] for t in range(60)]
+    ge = G.ORBextractor(1000)
+    m = G.ORBmatcher(0.7, True)
+    k0, d0 = ge(imgs[0])
+    for im in imgs[:10]:
+        ge(im)
+    lat_e, lat_m = [], []
+    pk, pd = k0, d0
+    for im in imgs[10:]:
+        t0 = time.perf_counter()
+        k, d = ge(im)
+        t1 = time.perf_counter()
+        m.MatchBruteForce(pd, pk["angle"], d, k["angle"])
+        t2 = time.perf_counter()
+        lat_e.append(t1 - t0), lat_m.append(t2 - t1)
+        pk, pd = k, d
+    ge.set_profiling(True)
+    for im in imgs[:20]:
+        ge(im)
+    stages = ge.stage_times()
+    print(json.dumps({"config": "C1-like: one 640x480 frame at a time through orbgpu_extract / orbgpu_match_bf "
+                                "(host buffers, synchronous; includes ctypes + numpy wrapper overhead)",
+                      "extract_ms_median": float(np.median(lat_e)) * 1e3, "extract_ms_p95": float(np.percentile(lat_e, 95)) * 1e3,
+                      "match_ms_median": float(np.median(lat_m)) * 1e3,
+                      "device_ms_per_stage_batch1": {k: round(v, 4) for k, v in stages.items()},
+                      "device_ms_sum_batch1": round(sum(stages.values()), 4)}))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c3", "c4"]
+    which = sys.argv[1:] or ["c1", "c3", "c4"]
+    if "c1" in which:
+        c1()
     if "c3" in which:
         c3()
     if "c4" in which:
