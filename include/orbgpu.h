@@ -242,6 +242,29 @@ int orbgpu_search_by_projection_last(const orbgpu_frame_view *cur, const float *
                                      float th, int32_t mono, int32_t check_orientation, int32_t *kp_to_mp,
                                      int32_t *nmatches, int32_t device_id);
 
+/* pKF->GetMapPointMatches() members read by the relocalisation matcher. */
+typedef struct {
+    int32_t n;
+    const uint8_t *has_mp;        /* vpMPs[i] != NULL */
+    const uint8_t *bad;           /* isBad(); may be NULL */
+    const uint8_t *already_found; /* sAlreadyFound.count(pMP); may be NULL */
+    const float *world_pos;       /* n x 3 */
+    const float *min_dist;        /* mfMinDistance (GetMinDistanceInvariance() = 0.8f * this, MapPoint.cc:373-377) */
+    const float *max_dist;        /* mfMaxDistance (GetMaxDistanceInvariance() = 1.2f * this, MapPoint.cc:379-383) */
+    const uint8_t *desc;          /* GetDescriptor(), n x 32 */
+    const float *kp_angle;        /* pKF->mvKeysUn[i].angle */
+} orbgpu_keyframe_view;
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound,
+ * th, ORBdist) (ORBmatcher.h:56, ORBmatcher.cc:1472-1599; Tracking::Relocalization, Tracking.cc:1756,1770).
+ * log_scale_factor = CurrentFrame.mfLogScaleFactor.  kp_to_mp in: -1 = free, anything else = occupied
+ * (any association hides the key point, :1540-1541); out: index of the key-frame map point. */
+int orbgpu_search_by_projection_keyframe(const orbgpu_frame_view *cur, const float *cur_Tcw, float fx, float fy,
+                                         float cx, float cy, float log_scale_factor,
+                                         const orbgpu_keyframe_view *kf, float th, int32_t orb_dist,
+                                         int32_t check_orientation, int32_t *kp_to_mp, int32_t *nmatches,
+                                         int32_t device_id);
+
 /* ======================================================================================
  * PointCloudMapping  (reference include/PointCloudMap.h:41-88, src/PointCloudMap.cc)
  * ====================================================================================== */

@@ -37,6 +37,12 @@ class MapPointView(C.Structure):
                 ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p), ("desc", C.c_void_p)]
 
 
+class KeyFrameView(C.Structure):
+    _fields_ = [("n", C.c_int), ("has_mp", C.c_void_p), ("bad", C.c_void_p), ("already_found", C.c_void_p),
+                ("world_pos", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p),
+                ("desc", C.c_void_p), ("kp_angle", C.c_void_p)]
+
+
 class LastFrameView(C.Structure):
     _fields_ = [("n", C.c_int), ("has_mp", C.c_void_p), ("outlier", C.c_void_p), ("obs_pos", C.c_void_p),
                 ("world_pos", C.c_void_p), ("desc", C.c_void_p), ("kp_octave", C.c_void_p),
@@ -96,6 +102,7 @@ def lib(path=None):
     L.ora_get_features_in_area.argtypes = [vp, cf, cf, cf, ci, ci, vp]
     L.ora_search_by_projection.argtypes = [vp, vp, cf, cf, vp]
     L.ora_search_by_projection_last.argtypes = [vp, vp, cf, cf, cf, cf, cf, cf, vp, cf, ci, ci, vp]
+    L.ora_search_by_projection_keyframe.argtypes = [vp, vp, cf, cf, cf, cf, cf, vp, cf, ci, ci, vp]
     L.ora_is_in_frustum.argtypes = [vp, cf, cf, cf, cf, cf, cf, cf, cf, cf, vp, vp, cf, cf, cf, ci, cf,
                                     vp, vp, vp, vp, vp]
     L.ora_compute_stereo_from_rgbd.argtypes = [ci, vp, vp, vp, vp, C.c_size_t, cf, vp, vp]
@@ -329,6 +336,25 @@ def search_by_projection_last(cur, cur_Tcw, fx, fy, cx, cy, mbf, mb, last, th, m
     out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
     n = lib().ora_search_by_projection_last(C.byref(fv), _p(T), fx, fy, cx, cy, mbf, mb, C.byref(v), th, int(mono),
                                             int(check_ori), _p(out))
+    return n, out
+
+
+KF_FIELDS = (("has_mp", np.uint8), ("bad", np.uint8), ("already_found", np.uint8), ("world_pos", np.float32),
+             ("min_dist", np.float32), ("max_dist", np.float32), ("desc", np.uint8), ("kp_angle", np.float32))
+
+
+def search_by_projection_keyframe(cur, cur_Tcw, fx, fy, cx, cy, log_sf, kf, th, orb_dist, check_ori, kp_to_mp):
+    """kf: dict of arrays has_mp,bad,already_found,world_pos,min_dist,max_dist,desc,kp_angle."""
+    keep = {k: np.ascontiguousarray(kf[k], dt) for k, dt in KF_FIELDS}
+    v = KeyFrameView()
+    v.n = len(keep["has_mp"])
+    for k in keep:
+        setattr(v, k, _p(keep[k]))
+    fv = cur.view()
+    T = np.ascontiguousarray(cur_Tcw, np.float32)
+    out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
+    n = lib().ora_search_by_projection_keyframe(C.byref(fv), _p(T), fx, fy, cx, cy, log_sf, C.byref(v), th, int(orb_dist),
+                                                int(check_ori), _p(out))
     return n, out
 
 

@@ -173,6 +173,26 @@ int ora_search_by_projection_last(const ora_frame_view *cur, const float *cur_Tc
                                   float cy, float mbf, float mb, const ora_lastframe_view *last, float th,
                                   int mono, int check_orientation, int32_t *kp_to_mp);
 
+/* ---- M5a: SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound,
+ * th, ORBdist), ORBmatcher.cc:1472-1599 (Tracking::Relocalization, Tracking.cc:1756,1770) ---- */
+typedef struct {
+    int n;                        /* pKF->GetMapPointMatches().size() */
+    const uint8_t *has_mp;        /* vpMPs[i] != NULL */
+    const uint8_t *bad;           /* isBad() */
+    const uint8_t *already_found; /* sAlreadyFound.count(pMP) */
+    const float *world_pos;       /* n x 3 */
+    const float *min_dist;        /* mfMinDistance (GetMinDistanceInvariance() = 0.8f * this) */
+    const float *max_dist;        /* mfMaxDistance (GetMaxDistanceInvariance() = 1.2f * this) */
+    const uint8_t *desc;          /* n x 32 */
+    const float *kp_angle;        /* pKF->mvKeysUn[i].angle */
+} ora_keyframe_view;
+
+/* kp_to_mp in: -1 = CurrentFrame.mvpMapPoints[j] is NULL, anything else = occupied; out: index of the
+ * key-frame map point written there.  Returns nmatches, -1 on a level outside [0,nlevels). */
+int ora_search_by_projection_keyframe(const ora_frame_view *cur, const float *cur_Tcw, float fx, float fy, float cx,
+                                      float cy, float log_scale_factor, const ora_keyframe_view *kf, float th,
+                                      int orb_dist, int check_orientation, int32_t *kp_to_mp);
+
 /* ---- M8: Frame::isInFrustum, Frame.cc:269-325 (+ MapPoint::PredictScale, MapPoint.cc:385-394) ---- */
 int ora_is_in_frustum(const float *Tcw, float fx, float fy, float cx, float cy, float mbf, float min_x,
                       float max_x, float min_y, float max_y, const float *P, const float *normal, float min_dist,

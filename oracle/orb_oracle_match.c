@@ -394,6 +394,94 @@ done:
     return nmatches;
 }
 
+/* ------------------------------------------------------------------ M5a */
+/* ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, th, ORBdist), :1472-1599 */
+int ora_search_by_projection_keyframe(const ora_frame_view *cur, const float *cur_Tcw, float fx, float fy, float cx,
+                                      float cy, float log_scale_factor, const ora_keyframe_view *kf, float th,
+                                      int orb_dist, int check_orientation, int32_t *kp_to_mp)
+{
+    int nmatches = 0;
+    int histo[ORA_HISTO_LENGTH];
+    memset(histo, 0, sizeof(histo));
+    int *push_idx = (int *)malloc(sizeof(int) * (size_t)(kf->n > 0 ? kf->n : 1));
+    int *push_bin = (int *)malloc(sizeof(int) * (size_t)(kf->n > 0 ? kf->n : 1));
+    int npush = 0;
+    int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cur->n > 0 ? cur->n : 1));
+    float Ow[3];
+    minus_rt_t(cur_Tcw, Ow);
+    for (int i = 0; i < kf->n; i++) {
+        if (!kf->has_mp[i])
+            continue;
+        if ((kf->bad && kf->bad[i]) || (kf->already_found && kf->already_found[i]))
+            continue;
+        const float *Pw = kf->world_pos + 3 * (size_t)i;
+        float xc3[3];
+        rt_apply(cur_Tcw, Pw, xc3);
+        const float xc = xc3[0], yc = xc3[1];
+        const float invzc = (float)(1.0 / (double)xc3[2]);
+        const float u = fx * xc * invzc + cx;
+        const float v = fy * yc * invzc + cy;
+        if (u < cur->min_x || u > cur->max_x)
+            continue;
+        if (v < cur->min_y || v > cur->max_y)
+            continue;
+        float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
+        float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        const float maxDistance = 1.2f * kf->max_dist[i];
+        const float minDistance = 0.8f * kf->min_dist[i];
+        if (dist3D < minDistance || dist3D > maxDistance)
+            continue;
+        float ratio = kf->max_dist[i] / dist3D;
+        int lvl = (int)ceilf(logf(ratio) / log_scale_factor); /* MapPoint::PredictScale */
+        if (lvl < 0 || lvl >= cur->nlevels) {
+            nmatches = -1;
+            goto done;
+        }
+        const float radius = th * cur->scale_factors[lvl];
+        int nc = ora_get_features_in_area(cur, u, v, radius, lvl - 1, lvl + 1, vIndices);
+        if (nc == 0)
+            continue;
+        const uint8_t *dmp = kf->desc + (size_t)i * 32;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = vIndices[c];
+            if (kp_to_mp[i2] != -1)
+                continue; /* :1540-1541 any association blocks */
+            const int dist = ora_descriptor_distance(dmp, cur->desc + (size_t)i2 * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        if (bestDist <= orb_dist) {
+            kp_to_mp[bestIdx2] = i;
+            nmatches++;
+            if (check_orientation) {
+                int bin = rot_bin(kf->kp_angle[i], cur->kp_angle[bestIdx2]);
+                push_idx[npush] = bestIdx2;
+                push_bin[npush++] = bin;
+                histo[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        three_maxima(histo, ORA_HISTO_LENGTH, &i1, &i2, &i3);
+        for (int k = 0; k < npush; k++) {
+            int b = push_bin[k];
+            if (b == i1 || b == i2 || b == i3)
+                continue;
+            kp_to_mp[push_idx[k]] = -1;
+            nmatches--;
+        }
+    }
+done:
+    free(vIndices);
+    free(push_idx);
+    free(push_bin);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------ M8 */
 /* Frame::isInFrustum, Frame.cc:269-325; MapPoint::PredictScale, MapPoint.cc:385-394 */
 int ora_is_in_frustum(const float *Tcw, float fx, float fy, float cx, float cy, float mbf, float min_x,

@@ -29,7 +29,9 @@ struct Query {  // one row of the matcher: a projected map point
     float ur;           // predicted right coordinate (mTrackProjXR / u - mbf*invz)
     int min_level, max_level;
     int active;         // 0: the reference `continue`s before the candidate loop
-    int blocking;       // MapPoint::Observations() > 0
+    int blocking;       // a claim by this row hides the key point from later rows
+    int check_ur;       // apply the mvuRight gate (ORBmatcher.cc:91-96 / 1407-1413); off for :1472-1599
+    int pad;
 };
 
 struct FrameDev {
@@ -113,7 +115,7 @@ __device__ __forceinline__ void proj_walk(const Query &Q, const uint64_t a[4], c
             if (claim && claim[idx] < i)
                 continue;  // held by an earlier row / a pre-existing association
             const float ur = F.u_right[idx];
-            if (ur > 0) {
+            if (Q.check_ur && ur > 0) {
                 const float er = fabsf(Q.ur - ur);
                 if (er > Q.r)
                     continue;
@@ -171,12 +173,12 @@ __global__ __launch_bounds__(256) void k_proj_topk(int m, const Query *__restric
 }
 
 // accept rule.  mode 0: ORBmatcher.cc:114-125 (TH_HIGH, ratio test only on equal levels);
-//               mode 1: ORBmatcher.cc:1424-1430 (TH_HIGH only)
+//               mode 1: ORBmatcher.cc:1424-1430 (TH_HIGH only) and :1554 (ORBdist only)
 template <int MODE>
-__device__ __forceinline__ int proj_accept(uint64_t k1, uint64_t k2, const FrameDev &F, float nnratio)
+__device__ __forceinline__ int proj_accept(uint64_t k1, uint64_t k2, const FrameDev &F, float nnratio, int th_dist)
 {
     const int bestDist = (int)(k1 >> 44);
-    if (bestDist > ORBGPU_TH_HIGH)
+    if (bestDist > th_dist)
         return -1;
     const int bestIdx = (int)(k1 & 0xFFFFF);
     if (MODE == 0) {
@@ -199,7 +201,8 @@ __device__ __forceinline__ int proj_accept(uint64_t k1, uint64_t k2, const Frame
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__restrict__ q,
                                                        const uint8_t *__restrict__ row_desc, FrameDev F,
-                                                       float nnratio, const int *__restrict__ claim_init,
+                                                       float nnratio, int th_dist,
+                                                       const int *__restrict__ claim_init,
                                                        const uint64_t *__restrict__ topk, int *__restrict__ match,
                                                        int *__restrict__ slow, const float *__restrict__ row_angle,
                                                        const float *__restrict__ kp_angle, int check_orientation,
@@ -251,9 +254,9 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
                     }
                 }
                 const int need = MODE == 0 ? 2 : 1;
-                decided = found >= need || complete || (found == 1 && (int)(k1 >> 44) > ORBGPU_TH_HIGH);
+                decided = found >= need || complete || (found == 1 && (int)(k1 >> 44) > th_dist);
                 if (decided && found > 0)
-                    result = proj_accept<MODE>(k1, k2, F, nnratio);
+                    result = proj_accept<MODE>(k1, k2, F, nnratio, th_dist);
             }
             if (!decided) {
                 slow[atomicAdd(&s_nslow, 1)] = i;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
                 if ((tid & 63) == 0) {
                     int result = -1;
                     if (t[0] != KEY_NONE)
-                        result = proj_accept<MODE>(t[0], t[1], F, nnratio);
+                        result = proj_accept<MODE>(t[0], t[1], F, nnratio, th_dist);
                     if (match[i] != result) {
                         changed = true;
                         match[i] = result;
@@ -456,7 +459,7 @@ static int upload_frame(ProjWorkspace &ws, const orbgpu_frame_view *f, FrameDev 
 template <int MODE>
 static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vector<Query> &queries,
                           const uint8_t *row_desc_host, const float *row_angle_host, const float *kp_angle_host,
-                          const std::vector<int> &claim_init, float nnratio, int check_orientation,
+                          const std::vector<int> &claim_init, float nnratio, int th_dist, int check_orientation,
                           int32_t *kp_to_mp, int32_t *nmatches)
 {
     const int m = (int)queries.size(), n = F.n;
@@ -488,7 +491,7 @@ static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vecto
     hipLaunchKernelGGL(k_proj_topk, dim3((m + 3) / 4), dim3(256), 0, st, m, ws.queries.as<Query>(),
                        ws.row_desc.as<uint8_t>(), F, ws.topk.as<uint64_t>());
     hipLaunchKernelGGL(k_proj_resolve<MODE>, dim3(1), dim3(1024), (size_t)8 * n, st, m, ws.queries.as<Query>(),
-                       ws.row_desc.as<uint8_t>(), F, nnratio, ws.claim_init.as<int>(), ws.topk.as<uint64_t>(),
+                       ws.row_desc.as<uint8_t>(), F, nnratio, th_dist, ws.claim_init.as<int>(), ws.topk.as<uint64_t>(),
                        ws.match.as<int>(), ws.slow.as<int>(), ws.row_angle.as<float>(), ws.kp_angle.as<float>(),
                        check_orientation, ws.k2m.as<int>(), ws.out.as<int>(), ws.out.as<int>() + 1);
     ORBGPU_HIP_TRY(hipGetLastError());
@@ -593,6 +596,7 @@ int orbgpu_search_by_projection(const orbgpu_frame_view *f, const orbgpu_mappoin
         Q.ur = mp->proj_xr[i];
         Q.min_level = lvl - 1;
         Q.max_level = lvl;
+        Q.check_ur = 1;
         Q.active = 1;
     }
     std::vector<int> init((size_t)std::max(f->n, 1));
@@ -608,7 +612,7 @@ int orbgpu_search_by_projection(const orbgpu_frame_view *f, const orbgpu_mappoin
     FrameDev F;
     if ((rc = upload_frame(*ws, f, F)) != ORBGPU_OK)
         return rc;
-    return run_projection<0>(*ws, F, q, mp->desc, nullptr, nullptr, init, nnratio, 0, kp_to_mp, nmatches);
+    return run_projection<0>(*ws, F, q, mp->desc, nullptr, nullptr, init, nnratio, ORBGPU_TH_HIGH, 0, kp_to_mp, nmatches);
 }
 
 int orbgpu_search_by_projection_last(const orbgpu_frame_view *cur, const float *cur_Tcw, float fx, float fy,
@@ -677,6 +681,7 @@ int orbgpu_search_by_projection_last(const orbgpu_frame_view *cur, const float *
             Q.min_level = oct - 1;
             Q.max_level = oct + 1;
         }
+        Q.check_ur = 1;
         Q.active = 1;
     }
     std::vector<int> init((size_t)std::max(cur->n, 1));
@@ -692,8 +697,84 @@ int orbgpu_search_by_projection_last(const orbgpu_frame_view *cur, const float *
     FrameDev F;
     if ((rc = upload_frame(*ws, cur, F)) != ORBGPU_OK)
         return rc;
-    return run_projection<1>(*ws, F, q, last->desc, last->kp_angle, cur->kp_angle, init, 0.f, check_orientation, kp_to_mp,
-                             nmatches);
+    return run_projection<1>(*ws, F, q, last->desc, last->kp_angle, cur->kp_angle, init, 0.f, ORBGPU_TH_HIGH,
+                             check_orientation, kp_to_mp, nmatches);
+}
+
+int orbgpu_search_by_projection_keyframe(const orbgpu_frame_view *cur, const float *cur_Tcw, float fx, float fy,
+                                         float cx, float cy, float log_scale_factor,
+                                         const orbgpu_keyframe_view *kf, float th, int32_t orb_dist,
+                                         int32_t check_orientation, int32_t *kp_to_mp, int32_t *nmatches,
+                                         int32_t device_id)
+{
+    ORBGPU_REQUIRE(kf && cur_Tcw && kp_to_mp && nmatches, "null argument");
+    int rc = validate_frame(cur);
+    if (rc != ORBGPU_OK)
+        return rc;
+    ORBGPU_REQUIRE(kf->n >= 0, "bad key frame");
+    if (kf->n > 0)
+        ORBGPU_REQUIRE(kf->has_mp && kf->world_pos && kf->min_dist && kf->max_dist && kf->desc, "null key-frame arrays");
+    ORBGPU_REQUIRE(!check_orientation || ((kf->n == 0 || kf->kp_angle) && (cur->n == 0 || cur->kp_angle)),
+                   "orientation check needs angles");
+    ORBGPU_REQUIRE(log_scale_factor > 0, "log_scale_factor must be positive");
+    rc = select_device(device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    float Ow[3];
+    minus_rt_t(cur_Tcw, Ow);  // :1478
+    std::vector<Query> q((size_t)kf->n);
+    for (int i = 0; i < kf->n; i++) {
+        Query &Q = q[i];
+        Q = Query{};
+        Q.blocking = 1;  // :1540-1541: any association hides the key point
+        if (!kf->has_mp[i] || (kf->bad && kf->bad[i]) || (kf->already_found && kf->already_found[i]))
+            continue;
+        const float *Pw = kf->world_pos + 3 * (size_t)i;
+        float xc3[3];
+        rt_apply(cur_Tcw, Pw, xc3);
+        const float invzc = (float)(1.0 / (double)xc3[2]);
+        volatile float ux = fx * xc3[0];
+        volatile float ux2 = ux * invzc;
+        const float u = ux2 + cx;
+        volatile float vy = fy * xc3[1];
+        volatile float vy2 = vy * invzc;
+        const float v = vy2 + cy;
+        if (u < cur->min_x || u > cur->max_x)
+            continue;
+        if (v < cur->min_y || v > cur->max_y)
+            continue;
+        const float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
+        // cv::norm accumulates in double
+        const float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        const float maxDistance = 1.2f * kf->max_dist[i], minDistance = 0.8f * kf->min_dist[i];
+        if (dist3D < minDistance || dist3D > maxDistance)
+            continue;
+        const float ratio = kf->max_dist[i] / dist3D;
+        const int lvl = (int)ceilf(logf(ratio) / log_scale_factor);  // MapPoint::PredictScale
+        if (lvl < 0 || lvl >= cur->nlevels) {
+            set_error("key-frame map point %d: predicted level %d outside [0,%d)", i, lvl, cur->nlevels);
+            return ORBGPU_ELEVEL;
+        }
+        Q.r = th * cur->scale_factors[lvl];
+        Q.x = u;
+        Q.y = v;
+        Q.min_level = lvl - 1;
+        Q.max_level = lvl + 1;
+        Q.check_ur = 0;
+        Q.active = 1;
+    }
+    std::vector<int> init((size_t)std::max(cur->n, 1));
+    for (int j = 0; j < cur->n; j++)
+        init[j] = kp_to_mp[j] == -1 ? INT_MAX : -1;
+    // the matcher writes indices of `kf` rows; occupied key points keep their value
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    FrameDev F;
+    if ((rc = upload_frame(*ws, cur, F)) != ORBGPU_OK)
+        return rc;
+    return run_projection<1>(*ws, F, q, kf->desc, kf->kp_angle, cur->kp_angle, init, 0.f, orb_dist, check_orientation,
+                             kp_to_mp, nmatches);
 }
 
 } // extern "C"

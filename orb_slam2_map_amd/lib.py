@@ -51,6 +51,12 @@ class MapPointView(C.Structure):
                 ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p), ("desc", C.c_void_p)]
 
 
+class KeyFrameView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("has_mp", C.c_void_p), ("bad", C.c_void_p), ("already_found", C.c_void_p),
+                ("world_pos", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p),
+                ("desc", C.c_void_p), ("kp_angle", C.c_void_p)]
+
+
 class LastFrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("has_mp", C.c_void_p), ("outlier", C.c_void_p), ("obs_pos", C.c_void_p),
                 ("world_pos", C.c_void_p), ("desc", C.c_void_p), ("kp_octave", C.c_void_p),
@@ -71,7 +77,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
-    "orbgpu_search_by_projection", "orbgpu_search_by_projection_last",
+    "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
     "orbgpu_voxel_filter",
@@ -126,6 +132,7 @@ def lib():
         "orbgpu_assign_features_to_grid": [i32, vp, vp, f32, f32, f32, f32, vp, vp],
         "orbgpu_search_by_projection": [vp, vp, f32, f32, vp, vp, i32],
         "orbgpu_search_by_projection_last": [vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
+        "orbgpu_search_by_projection_keyframe": [vp, vp, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
         "orbgpu_cloud_create": [C.c_double, i32, vp],
         "orbgpu_cloud_destroy": [vp],
         "orbgpu_cloud_insert": [vp, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
@@ -377,6 +384,26 @@ class ORBmatcher:
         check(self.L.orbgpu_search_by_projection_last(C.byref(fv), _p(T), fx, fy, cx, cy, mbf, mb, C.byref(v), th,
                                                       int(mono), int(self.check_ori), _p(out), C.byref(n),
                                                       self.device_id))
+        return n.value, out
+
+
+    def SearchByProjectionKeyFrame(self, cur, cur_Tcw, fx, fy, cx, cy, log_sf, kf, th, orb_dist, kp_to_mp):
+        """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1472-1599).
+        kf: dict of arrays has_mp,bad,already_found,world_pos,min_dist,max_dist,desc,kp_angle."""
+        keep = {k: np.ascontiguousarray(kf[k], dt) for k, dt in
+                (("has_mp", np.uint8), ("bad", np.uint8), ("already_found", np.uint8), ("world_pos", np.float32),
+                 ("min_dist", np.float32), ("max_dist", np.float32), ("desc", np.uint8), ("kp_angle", np.float32))}
+        v = KeyFrameView()
+        v.n = len(keep["has_mp"])
+        for k in keep:
+            setattr(v, k, _p(keep[k]))
+        fv = cur.view()
+        T = np.ascontiguousarray(cur_Tcw, np.float32)
+        out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
+        n = C.c_int32()
+        check(self.L.orbgpu_search_by_projection_keyframe(C.byref(fv), _p(T), fx, fy, cx, cy, log_sf, C.byref(v), th,
+                                                          int(orb_dist), int(self.check_ori), _p(out), C.byref(n),
+                                                          self.device_id))
         return n.value, out
 
 

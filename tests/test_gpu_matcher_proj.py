@@ -112,6 +112,42 @@ def test_search_by_projection_last_frame(gpu, oracle, th, mono, obs_zero, motion
     assert ng == no and np.array_equal(kg, ko), "%d vs %d, %d differ" % (ng, no, int((kg != ko).sum()))
 
 
+@pytest.mark.parametrize("th,orb_dist,found_frac", [(10.0, 100, 0.0), (3.0, 64, 0.3)])
+def test_search_by_projection_keyframe(gpu, oracle, th, orb_dist, found_frac):
+    """Tracking::Relocalization (Tracking.cc:1756 th=10/ORBdist=100, :1770 th=3/ORBdist=64): a key frame's
+    map points projected into the current frame; any existing association blocks a key point."""
+    from orb_slam2_map_amd.synth import Stream
+    rng = np.random.default_rng(int(th))
+    st = Stream(640, 480, 1234)
+    ge = gpu.ORBextractor(1000, max_batch=2)
+    fr = [st.frame(40), st.frame(42)]
+    ks, ds = ge.extract_batch(np.stack([f[0] for f in fr]))
+    sf = ge.GetScaleFactors()
+    Tcw = scenario.rigid()
+    gcur = scenario.make_frame(gpu, ks[1], ds[1], fr[1][2], st, sf)
+    ocur = scenario.make_frame(oracle, ks[1], ds[1], fr[1][2], st, sf)
+    (px, py), (ox, oy) = st.offset(40), st.offset(42)
+    P, _ = scenario.world_points_from_prev(ks[0], fr[0][2], (ox - px, oy - py), st, Tcw, rng)
+    n = len(ks[0])
+    T = Tcw.astype(np.float64)
+    Ow = -T[:3, :3].T @ T[:3, 3]
+    dist = np.linalg.norm(P.astype(np.float64) - Ow, axis=1)
+    maxd = (dist * sf[ks[0]["octave"]]).astype(np.float32)  # MapPoint::UpdateNormalAndDepth (MapPoint.cc:352-371)
+    mind = (maxd / sf[-1]).astype(np.float32)
+    kf = {"has_mp": (rng.random(n) < 0.85).astype(np.uint8), "bad": (rng.random(n) < 0.03).astype(np.uint8),
+          "already_found": (rng.random(n) < found_frac).astype(np.uint8), "world_pos": P, "min_dist": mind,
+          "max_dist": maxd, "desc": ds[0], "kp_angle": ks[0]["angle"]}
+    fx, fy, cx, cy = (float(v) for v in (st.fx, st.fy, st.cx, st.cy))
+    log_sf = float(np.log(np.float32(sf[1])))
+    k0 = np.full(gcur.n, -1, np.int32)
+    k0[rng.choice(gcur.n, 100, replace=False)] = -2  # already associated key points
+    ng, kg = gpu.ORBmatcher(0.9, True).SearchByProjectionKeyFrame(gcur, Tcw, fx, fy, cx, cy, log_sf, kf, th, orb_dist, k0)
+    no, ko = oracle.search_by_projection_keyframe(ocur, Tcw, fx, fy, cx, cy, log_sf, kf, th, orb_dist, True, k0)
+    assert no > 100, no
+    assert ng == no and np.array_equal(kg, ko), "%d vs %d, %d differ" % (ng, no, int((kg != ko).sum()))
+    assert np.all(kg[k0 == -2] == -2)
+
+
 def test_assign_features_to_grid(gpu, oracle, stream640):
     rng = np.random.default_rng(0)
     x = (rng.random(2000) * 660 - 10).astype(np.float32)
