@@ -249,8 +249,9 @@ typedef struct {
     const uint8_t *bad;           /* isBad(); may be NULL */
     const uint8_t *already_found; /* sAlreadyFound.count(pMP); may be NULL */
     const float *world_pos;       /* n x 3 */
-    const float *min_dist;        /* mfMinDistance (GetMinDistanceInvariance() = 0.8f * this, MapPoint.cc:373-377) */
-    const float *max_dist;        /* mfMaxDistance (GetMaxDistanceInvariance() = 1.2f * this, MapPoint.cc:379-383) */
+    const float *min_dist_inv;    /* GetMinDistanceInvariance() (MapPoint.cc:373-377) */
+    const float *max_dist_inv;    /* GetMaxDistanceInvariance() (MapPoint.cc:379-383) */
+    const float *max_dist;        /* mfMaxDistance, the numerator of MapPoint::PredictScale (MapPoint.cc:385-394) */
     const uint8_t *desc;          /* GetDescriptor(), n x 32 */
     const float *kp_angle;        /* pKF->mvKeysUn[i].angle */
 } orbgpu_keyframe_view;

@@ -39,8 +39,8 @@ class MapPointView(C.Structure):
 
 class KeyFrameView(C.Structure):
     _fields_ = [("n", C.c_int), ("has_mp", C.c_void_p), ("bad", C.c_void_p), ("already_found", C.c_void_p),
-                ("world_pos", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p),
-                ("desc", C.c_void_p), ("kp_angle", C.c_void_p)]
+                ("world_pos", C.c_void_p), ("min_dist_inv", C.c_void_p), ("max_dist_inv", C.c_void_p),
+                ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("kp_angle", C.c_void_p)]
 
 
 class LastFrameView(C.Structure):
@@ -340,11 +340,12 @@ def search_by_projection_last(cur, cur_Tcw, fx, fy, cx, cy, mbf, mb, last, th, m
 
 
 KF_FIELDS = (("has_mp", np.uint8), ("bad", np.uint8), ("already_found", np.uint8), ("world_pos", np.float32),
-             ("min_dist", np.float32), ("max_dist", np.float32), ("desc", np.uint8), ("kp_angle", np.float32))
+             ("min_dist_inv", np.float32), ("max_dist_inv", np.float32), ("max_dist", np.float32), ("desc", np.uint8),
+             ("kp_angle", np.float32))
 
 
 def search_by_projection_keyframe(cur, cur_Tcw, fx, fy, cx, cy, log_sf, kf, th, orb_dist, check_ori, kp_to_mp):
-    """kf: dict of arrays has_mp,bad,already_found,world_pos,min_dist,max_dist,desc,kp_angle."""
+    """kf: dict of arrays has_mp,bad,already_found,world_pos,min_dist_inv,max_dist_inv,max_dist,desc,kp_angle."""
     keep = {k: np.ascontiguousarray(kf[k], dt) for k, dt in KF_FIELDS}
     v = KeyFrameView()
     v.n = len(keep["has_mp"])

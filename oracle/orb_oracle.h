@@ -181,8 +181,9 @@ typedef struct {
     const uint8_t *bad;           /* isBad() */
     const uint8_t *already_found; /* sAlreadyFound.count(pMP) */
     const float *world_pos;       /* n x 3 */
-    const float *min_dist;        /* mfMinDistance (GetMinDistanceInvariance() = 0.8f * this) */
-    const float *max_dist;        /* mfMaxDistance (GetMaxDistanceInvariance() = 1.2f * this) */
+    const float *min_dist_inv;    /* GetMinDistanceInvariance() = 0.8f * mfMinDistance */
+    const float *max_dist_inv;    /* GetMaxDistanceInvariance() = 1.2f * mfMaxDistance */
+    const float *max_dist;        /* mfMaxDistance, used by PredictScale */
     const uint8_t *desc;          /* n x 32 */
     const float *kp_angle;        /* pKF->mvKeysUn[i].angle */
 } ora_keyframe_view;

@@ -427,8 +427,8 @@ int ora_search_by_projection_keyframe(const ora_frame_view *cur, const float *cu
             continue;
         float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
         float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
-        const float maxDistance = 1.2f * kf->max_dist[i];
-        const float minDistance = 0.8f * kf->min_dist[i];
+        const float maxDistance = kf->max_dist_inv[i];
+        const float minDistance = kf->min_dist_inv[i];
         if (dist3D < minDistance || dist3D > maxDistance)
             continue;
         float ratio = kf->max_dist[i] / dist3D;

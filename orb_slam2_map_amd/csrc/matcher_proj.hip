@@ -713,7 +713,7 @@ int orbgpu_search_by_projection_keyframe(const orbgpu_frame_view *cur, const flo
         return rc;
     ORBGPU_REQUIRE(kf->n >= 0, "bad key frame");
     if (kf->n > 0)
-        ORBGPU_REQUIRE(kf->has_mp && kf->world_pos && kf->min_dist && kf->max_dist && kf->desc, "null key-frame arrays");
+        ORBGPU_REQUIRE(kf->has_mp && kf->world_pos && kf->min_dist_inv && kf->max_dist_inv && kf->max_dist && kf->desc, "null key-frame arrays");
     ORBGPU_REQUIRE(!check_orientation || ((kf->n == 0 || kf->kp_angle) && (cur->n == 0 || cur->kp_angle)),
                    "orientation check needs angles");
     ORBGPU_REQUIRE(log_scale_factor > 0, "log_scale_factor must be positive");
@@ -746,7 +746,7 @@ int orbgpu_search_by_projection_keyframe(const orbgpu_frame_view *cur, const flo
         const float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
         // cv::norm accumulates in double
         const float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
-        const float maxDistance = 1.2f * kf->max_dist[i], minDistance = 0.8f * kf->min_dist[i];
+        const float maxDistance = kf->max_dist_inv[i], minDistance = kf->min_dist_inv[i];
         if (dist3D < minDistance || dist3D > maxDistance)
             continue;
         const float ratio = kf->max_dist[i] / dist3D;

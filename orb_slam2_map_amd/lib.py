@@ -53,8 +53,8 @@ class MapPointView(C.Structure):
 
 class KeyFrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("has_mp", C.c_void_p), ("bad", C.c_void_p), ("already_found", C.c_void_p),
-                ("world_pos", C.c_void_p), ("min_dist", C.c_void_p), ("max_dist", C.c_void_p),
-                ("desc", C.c_void_p), ("kp_angle", C.c_void_p)]
+                ("world_pos", C.c_void_p), ("min_dist_inv", C.c_void_p), ("max_dist_inv", C.c_void_p),
+                ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("kp_angle", C.c_void_p)]
 
 
 class LastFrameView(C.Structure):
@@ -389,10 +389,11 @@ class ORBmatcher:
 
     def SearchByProjectionKeyFrame(self, cur, cur_Tcw, fx, fy, cx, cy, log_sf, kf, th, orb_dist, kp_to_mp):
         """SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1472-1599).
-        kf: dict of arrays has_mp,bad,already_found,world_pos,min_dist,max_dist,desc,kp_angle."""
+        kf: dict of arrays has_mp,bad,already_found,world_pos,min_dist_inv,max_dist_inv,max_dist,desc,kp_angle."""
         keep = {k: np.ascontiguousarray(kf[k], dt) for k, dt in
                 (("has_mp", np.uint8), ("bad", np.uint8), ("already_found", np.uint8), ("world_pos", np.float32),
-                 ("min_dist", np.float32), ("max_dist", np.float32), ("desc", np.uint8), ("kp_angle", np.float32))}
+                 ("min_dist_inv", np.float32), ("max_dist_inv", np.float32), ("max_dist", np.float32),
+                 ("desc", np.uint8), ("kp_angle", np.float32))}
         v = KeyFrameView()
         v.n = len(keep["has_mp"])
         for k in keep:

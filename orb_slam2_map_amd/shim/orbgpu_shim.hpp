@@ -268,18 +268,18 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
     // int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint*> &sAlreadyFound,
     //                        const float th, const int ORBdist)   (ORBmatcher.h:56, ORBmatcher.cc:1472-1599)
     // KeyFrameT needs GetMapPointMatches() and mvKeysUn; found(pMP) tells whether pMP is in sAlreadyFound;
-    // min_dist(pMP)/max_dist(pMP) return mfMinDistance/mfMaxDistance (= Get*DistanceInvariance()/0.8f, /1.2f).
+    // max_dist(pMP) returns mfMaxDistance (the numerator of MapPoint::PredictScale, a protected member:
+    // add an accessor or a friend declaration to MapPoint.h).
     template <typename KeyFrameT, typename DescRow, typename MpDesc, typename TcwOf, typename WorldPos, typename Found,
-              typename MinDist, typename MaxDist>
+              typename MaxDist>
     int SearchByProjection(FrameT &CurrentFrame, KeyFrameT *pKF, Found found, const float th, const int ORBdist,
-                           DescRow desc_row, MpDesc mp_desc, TcwOf Tcw, WorldPos world_pos, MinDist min_dist,
-                           MaxDist max_dist)
+                           DescRow desc_row, MpDesc mp_desc, TcwOf Tcw, WorldPos world_pos, MaxDist max_dist)
     {
         FrameSoA<FrameT> cur(CurrentFrame, desc_row);
         const std::vector<MapPointT *> vpMPs = pKF->GetMapPointMatches();
         const int n = (int)vpMPs.size();
         std::vector<uint8_t> has(n), bad(n), fnd(n), desc((size_t)std::max(n, 1) * 32);
-        std::vector<float> wp((size_t)std::max(n, 1) * 3), mind(n), maxd(n), ang(n);
+        std::vector<float> wp((size_t)std::max(n, 1) * 3), mininv(n), maxinv(n), maxd(n), ang(n);
         for (int i = 0; i < n; i++) {
             MapPointT *p = vpMPs[i];
             has[i] = p != nullptr;
@@ -288,13 +288,14 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
                 continue;
             bad[i] = p->isBad();
             fnd[i] = found(p);
-            mind[i] = min_dist(p), maxd[i] = max_dist(p);
+            mininv[i] = p->GetMinDistanceInvariance(), maxinv[i] = p->GetMaxDistanceInvariance();
+            maxd[i] = max_dist(p);
             const float *w = world_pos(p);
             wp[3 * i] = w[0], wp[3 * i + 1] = w[1], wp[3 * i + 2] = w[2];
             std::memcpy(&desc[(size_t)i * 32], mp_desc(p), 32);
         }
-        orbgpu_keyframe_view kv{n, has.data(), bad.data(), fnd.data(), wp.data(), mind.data(), maxd.data(), desc.data(),
-                                ang.data()};
+        orbgpu_keyframe_view kv{n, has.data(), bad.data(), fnd.data(), wp.data(), mininv.data(), maxinv.data(), maxd.data(),
+                                desc.data(), ang.data()};
         std::vector<int32_t> k2m(CurrentFrame.N, -1);
         for (int j = 0; j < CurrentFrame.N; j++)
             if (CurrentFrame.mvpMapPoints[j])

@@ -135,8 +135,9 @@ def test_search_by_projection_keyframe(gpu, oracle, th, orb_dist, found_frac):
     maxd = (dist * sf[ks[0]["octave"]]).astype(np.float32)  # MapPoint::UpdateNormalAndDepth (MapPoint.cc:352-371)
     mind = (maxd / sf[-1]).astype(np.float32)
     kf = {"has_mp": (rng.random(n) < 0.85).astype(np.uint8), "bad": (rng.random(n) < 0.03).astype(np.uint8),
-          "already_found": (rng.random(n) < found_frac).astype(np.uint8), "world_pos": P, "min_dist": mind,
-          "max_dist": maxd, "desc": ds[0], "kp_angle": ks[0]["angle"]}
+          "already_found": (rng.random(n) < found_frac).astype(np.uint8), "world_pos": P,
+          "min_dist_inv": np.float32(0.8) * mind, "max_dist_inv": np.float32(1.2) * maxd, "max_dist": maxd,
+          "desc": ds[0], "kp_angle": ks[0]["angle"]}
     fx, fy, cx, cy = (float(v) for v in (st.fx, st.fy, st.cx, st.cy))
     log_sf = float(np.log(np.float32(sf[1])))
     k0 = np.full(gcur.n, -1, np.int32)
