@@ -238,47 +238,50 @@ __device__ __forceinline__ uint32_t as_u32(pk16 v) { return __builtin_bit_cast(u
 __device__ __forceinline__ pk16 pkmin(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ pk16 pkmax(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
 
-// score of two pixels at once from their 16 packed ring differences d[k] = centre - ring[k].
+// score of two pixels at once from their centre c and 16 packed ring values p[k] (all zero-extended
+// bytes).  With d = c - p:  max over arcs of min(d) = c - min over arcs of max(p)  (dark arcs) and
+// max over arcs of min(-d) = max over arcs of min(p) - c  (bright arcs), so the networks run on the raw
+// ring values and the 16 subtractions disappear.
 // The 16 circular windows of 9 are evaluated with block prefix/suffix extrema (van Herk): the ring is
 // split into two blocks of 8; window [k, k+8] = suffix of k's block from k  +  prefix of the next block
-// up to k+8, so min9[k] = min(S[k], P[(k+8) & 15]).  59 packed ops per polarity instead of 79.
-__device__ __forceinline__ pk16 fast_score_pk(const pk16 d[16])
+// up to k+8, so ext9[k] = ext(S[k], P[(k+8) & 15]).  59 packed ops per polarity instead of 79.
+__device__ __forceinline__ pk16 fast_score_pk(pk16 c, const pk16 p[16])
 {
     pk16 P[16], S[16];
-    // ---- dark arcs: max over windows of the minimum
+    // ---- dark arcs: A = min over windows of the window maximum
 #pragma unroll
     for (int b = 0; b < 16; b += 8) {
-        P[b] = d[b];
+        P[b] = p[b];
 #pragma unroll
         for (int i = 1; i < 8; i++)
-            P[b + i] = pkmin(P[b + i - 1], d[b + i]);
-        S[b + 7] = d[b + 7];
+            P[b + i] = pkmax(P[b + i - 1], p[b + i]);
+        S[b + 7] = p[b + 7];
 #pragma unroll
         for (int i = 6; i >= 0; i--)
-            S[b + i] = pkmin(S[b + i + 1], d[b + i]);
+            S[b + i] = pkmax(S[b + i + 1], p[b + i]);
     }
-    pk16 dark = pkmin(S[0], P[8]);
+    pk16 A = pkmax(S[0], P[8]);
 #pragma unroll
     for (int k = 1; k < 16; k++)
-        dark = pkmax(dark, pkmin(S[k], P[(k + 8) & 15]));
-    // ---- bright arcs: min over windows of the maximum (negated afterwards)
+        A = pkmin(A, pkmax(S[k], P[(k + 8) & 15]));
+    // ---- bright arcs: B = max over windows of the window minimum
 #pragma unroll
     for (int b = 0; b < 16; b += 8) {
-        P[b] = d[b];
+        P[b] = p[b];
 #pragma unroll
         for (int i = 1; i < 8; i++)
-            P[b + i] = pkmax(P[b + i - 1], d[b + i]);
-        S[b + 7] = d[b + 7];
+            P[b + i] = pkmin(P[b + i - 1], p[b + i]);
+        S[b + 7] = p[b + 7];
 #pragma unroll
         for (int i = 6; i >= 0; i--)
-            S[b + i] = pkmax(S[b + i + 1], d[b + i]);
+            S[b + i] = pkmin(S[b + i + 1], p[b + i]);
     }
-    pk16 bright = pkmax(S[0], P[8]);
+    pk16 B = pkmin(S[0], P[8]);
 #pragma unroll
     for (int k = 1; k < 16; k++)
-        bright = pkmin(bright, pkmax(S[k], P[(k + 8) & 15]));
+        B = pkmax(B, pkmin(S[k], P[(k + 8) & 15]));
     const pk16 zero = {0, 0};
-    return pkmax(pkmax(dark, zero - bright), zero);  // values are in [0,255]
+    return pkmax(pkmax(c - A, B - c), zero);  // values are in [0,255]
 }
 
 // v_perm selectors that zero-extend bytes (o, o+2) resp. (o+1, o+3) of the 8-byte pair {lo,hi}
@@ -289,43 +292,49 @@ struct Row3 {
     uint32_t d[3];  // 12 bytes of one padded row: columns 4c-4 .. 4c+7
 };
 
-// ring byte of output pixel p in row window R at horizontal offset dx: window byte 4 + p + dx
-template <int DX> __device__ __forceinline__ void ring_pair(const Row3 &R, pk16 &even, pk16 &odd)
+// ring bytes of the even (px0,px2) or odd (px1,px3) pixel pair in row window R at horizontal offset dx:
+// window byte 4 + p + dx, zero-extended into packed 16-bit lanes by one v_perm_b32
+template <int DX, int ODD> __device__ __forceinline__ pk16 ring_half(const Row3 &R)
 {
     constexpr int s = 4 + DX, q = s >> 2, o = s & 3;
-    even = as_pk(__builtin_amdgcn_perm(R.d[q + 1], R.d[q], ORBGPU_SEL_EVEN(o)));
-    odd = as_pk(__builtin_amdgcn_perm(R.d[q + 1], R.d[q], ORBGPU_SEL_ODD(o)));
+    return as_pk(__builtin_amdgcn_perm(R.d[q + 1], R.d[q], ODD ? ORBGPU_SEL_ODD(o) : ORBGPU_SEL_EVEN(o)));
 }
 
-// scores of the 4 pixels of the strip in the row whose window is r3 (r0..r6 = rows y-3..y+3)
+// score of one pixel pair of the strip in the row whose window is r3 (r0..r6 = rows y-3..y+3)
+template <int ODD>
+__device__ __forceinline__ pk16 fast_score_half(const Row3 &r0, const Row3 &r1, const Row3 &r2, const Row3 &r3,
+                                                const Row3 &r4, const Row3 &r5, const Row3 &r6)
+{
+    pk16 p[16];
+    const pk16 c = ring_half<0, ODD>(r3);
+    // ring order A4: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
+    p[0] = ring_half<0, ODD>(r6);
+    p[1] = ring_half<1, ODD>(r6);
+    p[2] = ring_half<2, ODD>(r5);
+    p[3] = ring_half<3, ODD>(r4);
+    p[4] = ring_half<3, ODD>(r3);
+    p[5] = ring_half<3, ODD>(r2);
+    p[6] = ring_half<2, ODD>(r1);
+    p[7] = ring_half<1, ODD>(r0);
+    p[8] = ring_half<0, ODD>(r0);
+    p[9] = ring_half<-1, ODD>(r0);
+    p[10] = ring_half<-2, ODD>(r1);
+    p[11] = ring_half<-3, ODD>(r2);
+    p[12] = ring_half<-3, ODD>(r3);
+    p[13] = ring_half<-3, ODD>(r4);
+    p[14] = ring_half<-2, ODD>(r5);
+    p[15] = ring_half<-1, ODD>(r6);
+    return fast_score_pk(c, p);
+}
+
+// scores of the 4 pixels of the strip; the two pixel pairs are evaluated one after the other (the
+// scheduling barrier keeps their 48-register working sets from being live at the same time)
 __device__ __forceinline__ uint32_t fast_score_row(const Row3 &r0, const Row3 &r1, const Row3 &r2, const Row3 &r3,
                                                    const Row3 &r4, const Row3 &r5, const Row3 &r6)
 {
-    pk16 ce, co, e[16], o[16];
-    ring_pair<0>(r3, ce, co);
-    // ring order A4: (0,3)(1,3)(2,2)(3,1)(3,0)(3,-1)(2,-2)(1,-3)(0,-3)(-1,-3)(-2,-2)(-3,-1)(-3,0)(-3,1)(-2,2)(-1,3)
-    ring_pair<0>(r6, e[0], o[0]);
-    ring_pair<1>(r6, e[1], o[1]);
-    ring_pair<2>(r5, e[2], o[2]);
-    ring_pair<3>(r4, e[3], o[3]);
-    ring_pair<3>(r3, e[4], o[4]);
-    ring_pair<3>(r2, e[5], o[5]);
-    ring_pair<2>(r1, e[6], o[6]);
-    ring_pair<1>(r0, e[7], o[7]);
-    ring_pair<0>(r0, e[8], o[8]);
-    ring_pair<-1>(r0, e[9], o[9]);
-    ring_pair<-2>(r1, e[10], o[10]);
-    ring_pair<-3>(r2, e[11], o[11]);
-    ring_pair<-3>(r3, e[12], o[12]);
-    ring_pair<-3>(r4, e[13], o[13]);
-    ring_pair<-2>(r5, e[14], o[14]);
-    ring_pair<-1>(r6, e[15], o[15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        e[k] = ce - e[k];
-        o[k] = co - o[k];
-    }
-    const pk16 se = fast_score_pk(e), so = fast_score_pk(o);
+    const pk16 se = fast_score_half<0>(r0, r1, r2, r3, r4, r5, r6);
+    __builtin_amdgcn_sched_barrier(0);
+    const pk16 so = fast_score_half<1>(r0, r1, r2, r3, r4, r5, r6);
     // bytes: px0 = se.lo, px1 = so.lo, px2 = se.hi, px3 = so.hi
     return __builtin_amdgcn_perm(as_u32(so), as_u32(se), 0x06020400u);
 }
