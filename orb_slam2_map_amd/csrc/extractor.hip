@@ -88,15 +88,20 @@ __global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src
                                                  size_t frame_pyr, const LevelGeom *__restrict__ geom)
 {
     const LevelGeom g = geom[0];
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int f = blockIdx.z;
-    if (x4 >= g.pitch)
+    // work item = (group of PYR_ROWS padded rows, aligned dword of the row), flattened so that every lane
+    // of a workgroup has work whatever the row length
+    const int ndw = g.pitch >> 2;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int rg = item / ndw;
+    const int x4 = (item - rg * ndw) * 4;
+    const int f = blockIdx.y;
+    if (rg * PYR_ROWS >= g.h + 2 * EDGE)
         return;
     const int sx0 = x4 - EDGE;  // source column of the first of the 4 output pixels
     const bool interior = sx0 >= 0 && sx0 + 7 < g.w;
 #pragma unroll 4
     for (int rr = 0; rr < PYR_ROWS; rr++) {
-        const int py = blockIdx.y * PYR_ROWS + rr;
+        const int py = rg * PYR_ROWS + rr;
         if (py >= g.h + 2 * EDGE)
             break;
         const int sy = reflect101(py - EDGE, g.h);
@@ -174,9 +179,12 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
 {
     const LevelGeom g = geom[level];
     const LevelGeom gs = geom[level - 1];
-    const int sdw = blockIdx.x * 256 + threadIdx.x;  // output dword column
-    const int f = blockIdx.z;
-    if (sdw * 4 >= g.pitch)
+    const int ndw = g.pitch >> 2;
+    const int item = blockIdx.x * 256 + threadIdx.x;  // (row group, output dword column), flattened
+    const int rg = item / ndw;
+    const int sdw = item - rg * ndw;
+    const int f = blockIdx.y;
+    if (rg * PYR_ROWS >= g.h + 2 * EDGE)
         return;
     const uint32_t bq = strips[strip_off + sdw].base_q;
     const uint4 sel = sels[strip_off + sdw], wt = wts[strip_off + sdw];
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     uint8_t *dst = pyr + (size_t)f * frame_pyr + g.plane_off + sdw * 4;
 #pragma unroll 2
     for (int rr = 0; rr < PYR_ROWS; rr++) {
-        const int py = blockIdx.y * PYR_ROWS + rr;
+        const int py = rg * PYR_ROWS + rr;
         if (py >= g.h + 2 * EDGE)
             break;
         const int dy = reflect101(py - EDGE, g.h);
@@ -1722,12 +1730,12 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     BEGIN(ST_PYRAMID, st);
     {
         const LevelGeom &g = e->geom[0];
-        dim3 grid((g.pitch / 4 + 255) / 256, (g.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
+        dim3 grid(((g.pitch / 4) * ((g.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS) + 255) / 256, batch);
         hipLaunchKernelGGL(k_border0, grid, dim3(256), 0, st, d_gray, stride, frame_stride, pyr, e->frame_pyr, dg);
         for (int l = 1; l < nl; l++) {
             const LevelGeom &gl = e->geom[l];
             dim3 gr((gl.pitch / 4 + 255) / 256, gl.h + 2 * EDGE, batch);
-            dim3 grf((gl.pitch / 4 + 255) / 256, (gl.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS, batch);
+            dim3 grf(((gl.pitch / 4) * ((gl.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS) + 255) / 256, batch);
             if (gl.rs_fast)
                 hipLaunchKernelGGL(k_resize_fast, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
                                    e->d_rstrip.as<ResizeStrip>(), e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(),

@@ -157,6 +157,19 @@ __device__ void bf_full_scan_wave(const uint64_t *__restrict__ ga, const uint64_
     b2 = v2;
 }
 
+// merged candidate list of row i: the 4 smallest keys over the BF_SPLIT partial lists
+__device__ __forceinline__ void bf_load_keys(const uint32_t *__restrict__ tk, int i, uint32_t key[4])
+{
+    const uint4 k4 = *reinterpret_cast<const uint4 *>(tk + (size_t)i * BF_SPLIT * BF_TOPK);
+    key[0] = k4.x, key[1] = k4.y, key[2] = k4.z, key[3] = k4.w;
+#pragma unroll
+    for (int sp = 1; sp < BF_SPLIT; sp++) {
+        const uint4 o4 = *reinterpret_cast<const uint4 *>(tk + ((size_t)i * BF_SPLIT + sp) * BF_TOPK);
+        const uint32_t o[4] = {o4.x, o4.y, o4.z, o4.w};
+        top4_merge(key, o);
+    }
+}
+
 // Pass 2: the greedy claim order of the reference as a fixpoint, one workgroup per pair.  Every sweep
 // re-decides every A row in parallel from its cached candidate list, hiding the B rows that rows < i
 // claimed in the previous sweep (two claim tables in LDS).  Row i is final after at most i+1 sweeps and
@@ -194,6 +207,13 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
         claimA[j] = INT_MAX;
         match[j] = -2;  // "undecided": differs from every possible result
     }
+    // the candidate list of row `tid` (the only row of this thread unless na > blockDim) stays in registers
+    uint32_t key0[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
+    uint8_t valid0 = 0;
+    if (tid < na) {
+        bf_load_keys(tk, tid, key0);
+        valid0 = (!va || va[tid]) ? 1 : 0;
+    }
     __syncthreads();
     int sweeps = 0;
     for (int iter = 0; iter <= na + 1; iter++) {
@@ -209,15 +229,10 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
         for (int i = tid; i < na; i += nt) {
             int result = -1;
             bool decided = true;
-            if (!va || va[i]) {
-                const uint4 k4 = *reinterpret_cast<const uint4 *>(tk + (size_t)i * BF_SPLIT * BF_TOPK);
-                uint32_t key[4] = {k4.x, k4.y, k4.z, k4.w};
-#pragma unroll
-                for (int sp = 1; sp < BF_SPLIT; sp++) {
-                    const uint4 o4 = *reinterpret_cast<const uint4 *>(tk + ((size_t)i * BF_SPLIT + sp) * BF_TOPK);
-                    const uint32_t o[4] = {o4.x, o4.y, o4.z, o4.w};
-                    top4_merge(key, o);
-                }
+            if (i == tid ? valid0 != 0 : (!va || va[i])) {
+                uint32_t key[4] = {key0[0], key0[1], key0[2], key0[3]};
+                if (i != tid)
+                    bf_load_keys(tk, i, key);
                 int b1 = 256, i1 = -1, b2 = 256, found = 0;
                 bool complete = false;  // list exhausted: every B row has been considered
 #pragma unroll
