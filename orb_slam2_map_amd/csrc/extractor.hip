@@ -1283,17 +1283,27 @@ struct Pattern {
     int8_t v[1024];
 };
 
+constexpr int DP_R = 18;                  // |rotated pattern offset| <= 18 (radius^2 <= 338, A6)
+constexpr int DP_ROWS = 2 * DP_R + 1;     // 37 rows
+constexpr int DP_DW = 10;                 // 37 bytes + up to 3 bytes of alignment slack = 10 dwords per row
+constexpr int DP_BYTES = DP_ROWS * DP_DW * 4;
+
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, size_t frame_pyr,
                                                   const LevelGeom *__restrict__ geom,
                                                   const KpAux *__restrict__ aux, const int *__restrict__ n_out,
                                                   int cap, const int8_t *__restrict__ pattern,
                                                   uint8_t *__restrict__ desc)
 {
+    // the 37x37 neighbourhood of each key point is staged in LDS with coalesced aligned dword loads
+    // (10 consecutive dwords per row); the 512 rotated samples are then LDS byte reads instead of 512
+    // scattered global byte loads
+    __shared__ __align__(16) uint8_t patch[8][DP_BYTES];
     const int f = blockIdx.y;
     const int n = n_out[f];
-    const int kpi = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int slot = threadIdx.x >> 5;
+    const int kpi = blockIdx.x * 8 + slot;
     if (kpi >= n)
-        return;
+        return;  // whole half-wave leaves together; the other half of the wave is independent
     const int byte = threadIdx.x & 31;
     const KpAux a = aux[(size_t)f * cap + kpi];
     const LevelGeom g = geom[a.level];
@@ -1302,7 +1312,22 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     const uint4 pq1 = reinterpret_cast<const uint4 *>(pattern)[byte * 2 + 1];
     const uint32_t pw[8] = {pq0.x, pq0.y, pq0.z, pq0.w, pq1.x, pq1.y, pq1.z, pq1.w};
     const float ca = a.ca, sb = a.sb;
-    const uint8_t *center = blur + (size_t)f * frame_pyr + g.plane_off + (size_t)(a.y + EDGE) * g.pitch + (a.x + EDGE);
+    const int xl = a.x + EDGE - DP_R;  // leftmost padded column of the patch
+    const int al = xl & 3;
+    const uint8_t *src = blur + (size_t)f * frame_pyr + g.plane_off + (size_t)(a.y + EDGE - DP_R) * g.pitch + (xl - al);
+    uint32_t *pl = reinterpret_cast<uint32_t *>(patch[slot]);
+#pragma unroll
+    for (int k = 0; k < (DP_ROWS * DP_DW + 31) / 32; k++) {
+        const int idx = byte + 32 * k;
+        if (idx < DP_ROWS * DP_DW) {
+            const int r = idx / DP_DW, c = idx - r * DP_DW;
+            pl[idx] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * g.pitch + c * 4);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint8_t *center = patch[slot] + DP_R * (DP_DW * 4) + DP_R + al;
     int val = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -1310,8 +1335,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
         const float x1 = (float)(int8_t)((pw[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pw[k] >> 24);
         const int r0 = __float2int_rn(x0 * sb + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sb);
         const int r1 = __float2int_rn(x1 * sb + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sb);
-        const int t0 = center[r0 * g.pitch + c0];
-        const int t1 = center[r1 * g.pitch + c1];
+        const int t0 = center[r0 * (DP_DW * 4) + c0];
+        const int t1 = center[r1 * (DP_DW * 4) + c1];
         val |= (t0 < t1) << k;
     }
     desc[((size_t)f * cap + kpi) * 32 + byte] = (uint8_t)val;
