@@ -721,7 +721,8 @@ __global__ __launch_bounds__(512) void k_quadtree(const LevelGeom *__restrict__ 
     __shared__ int s_n, s_phase, s_done, s_nexp, s_nE, s_cut;
 
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int level = blockIdx.x, f = blockIdx.y;
+    // grid = (frames, levels): all workgroups of level 0 (the longest) are dispatched first
+    const int level = blockIdx.y, f = blockIdx.x;
     const LevelGeom g = geom[level];
     const int N = g.quota;
 
@@ -1784,7 +1785,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>());
     END(ST_FAST_NMS, st);
     BEGIN(ST_QUADTREE, st);
-    hipLaunchKernelGGL(k_quadtree, dim3(nl, batch), dim3(512), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
+    hipLaunchKernelGGL(k_quadtree, dim3(batch, nl), dim3(512), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
                        e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(), e->d_sel.as<uint32_t>(),
                        e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
