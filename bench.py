@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per step and per GPU")
     ap.add_argument("--pool", type=int, default=1024, help="distinct resident frames cycled through (> Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--rehearse-on-device0", action="store_true",
+                    help="N>1 rehearsal on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
     ap.add_argument("--no-overlap-match", dest="overlap_match", action="store_false",
                     help="serialise the matcher behind the extraction (default: the matcher of step i runs on a "
                          "second stream next to the extraction of step i+1)")
@@ -134,8 +137,10 @@ def main():
     G.lib()  # fail loudly if the HIP extension is missing
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: bench.py measures the HIP path only (no CPU fallback)")
+    if args.rehearse_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    D.init("nccl", rank, world)  # RCCL; carries the barrier and two scalar reductions only
+    D.init(args.backend, rank, world)  # RCCL; carries the barrier and two scalar reductions only
 
     W, H, NFEAT = 640, 480, 1000
     B, POOL = args.batch, max(args.pool, args.batch)
@@ -214,7 +219,8 @@ def main():
     ext.set_profiling(False)
     match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0)
 
-    elapsed_max, total_frames = D.aggregate(elapsed, B * args.steps, world, device="cuda")
+    elapsed_max, total_frames = D.aggregate(elapsed, B * args.steps, world,
+                                            device="cuda" if args.backend == "nccl" else "cpu")
 
     # sanity of the measured work (rank-local): every frame produced key points and matches
     n_host = nout[0].cpu().numpy()
