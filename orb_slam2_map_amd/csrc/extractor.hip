@@ -539,7 +539,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     }
     const int xs = cd.x0 + 3 + EDGE, ys = cd.y0 + 3 + EDGE;  // padded coordinates of the interior origin
     const int s0 = xs >> 2, o0 = xs & 3;                     // first strip, pixel offset inside it
-    const int nstrip = ((xs + iw - 1) >> 2) - s0 + 1;        // <= 18
     const size_t plane = (size_t)f * frame_pyr + g.plane_off;
     const uint8_t *bplane = bits + (plane >> 2);
     const int bpitch = g.pitch >> 2;
@@ -718,7 +717,7 @@ __global__ __launch_bounds__(512) void k_quadtree(const LevelGeom *__restrict__ 
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_tmp[8];
-    __shared__ int s_n, s_phase, s_done, s_nexp, s_nE, s_cut;
+    __shared__ int s_n, s_phase, s_done, s_nexp, s_cut;
 
     const int tid = threadIdx.x, nt = blockDim.x;
     // grid = (frames, levels): all workgroups of level 0 (the longest) are dispatched first
@@ -1280,10 +1279,6 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 // K6: steered BRIEF, 256 bits                         (computeOrbDescriptor, :108-147)
 // 32 lanes per key point, one descriptor byte (8 tests, 16 samples) per lane.
 // ---------------------------------------------------------------------------------------------
-struct Pattern {
-    int8_t v[1024];
-};
-
 constexpr int DP_R = 18;                  // |rotated pattern offset| <= 18 (radius^2 <= 338, A6)
 constexpr int DP_ROWS = 2 * DP_R + 1;     // 37 rows
 constexpr int DP_DW = 10;                 // 37 bytes + up to 3 bytes of alignment slack = 10 dwords per row
