@@ -202,6 +202,17 @@ typedef struct {
 int orbgpu_assign_features_to_grid(int32_t n, const float *kp_x, const float *kp_y, float min_x, float min_y,
                                    float grid_inv_w, float grid_inv_h, int32_t *cell_start, int32_t *cell_items);
 
+/* Device-resident Frame glue for a batch of frames straight out of orbgpu_extract_batch_device:
+ * Frame::ComputeStereoFromRGBD (Frame.cc:641-662: mvuRight = kpUn.x - mbf/d, mvDepth = d where d > 0, else -1)
+ * and Frame::AssignFeaturesToGrid (Frame.cc:230-245) as CSR per frame (cell_start[batch][COLS*ROWS+1],
+ * cell_items[batch][cap], items in insertion order).  mvKeysUn == mvKeys (zero distortion).  d_depth may be
+ * NULL (grid only); depth strides are in floats.  All pointers are device pointers; nothing is synchronised. */
+int orbgpu_frame_glue_batch_device(int32_t device_id, int32_t batch, int32_t cap, const orbgpu_keypoint *d_kps,
+                                   const int32_t *d_n, const float *d_depth, size_t depth_stride,
+                                   size_t depth_frame_stride, float mbf, float min_x, float max_x, float min_y,
+                                   float max_y, float *d_u_right, float *d_kp_depth, int32_t *d_cell_start,
+                                   int32_t *d_cell_items, void *hip_stream);
+
 /* MapPoint tracking scratch filled by Frame::isInFrustum (MapPoint.h:91-96, Frame.cc:317-322)
  * plus the flags and descriptor the matcher reads per point (ORBmatcher.cc:53-63, 77, 88). */
 typedef struct {

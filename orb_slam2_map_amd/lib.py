@@ -77,6 +77,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
+    "orbgpu_frame_glue_batch_device",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
@@ -130,6 +131,7 @@ def lib():
         "orbgpu_match_bf_batch_device": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, i32, f32, i32, vp, vp, vp],
         "orbgpu_matcher_last_sweeps": [vp, vp],
         "orbgpu_assign_features_to_grid": [i32, vp, vp, f32, f32, f32, f32, vp, vp],
+        "orbgpu_frame_glue_batch_device": [i32, i32, i32, vp, vp, vp, sz, sz, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
         "orbgpu_search_by_projection": [vp, vp, f32, f32, vp, vp, i32],
         "orbgpu_search_by_projection_last": [vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
         "orbgpu_search_by_projection_keyframe": [vp, vp, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
@@ -284,6 +286,14 @@ def assign_features_to_grid(kp_x, kp_y, min_x, min_y, inv_w, inv_h):
     check(lib().orbgpu_assign_features_to_grid(len(kp_x), _p(kp_x), _p(kp_y), min_x, min_y, inv_w, inv_h, _p(cs),
                                                _p(items)))
     return cs, items[:cs[-1]].copy()
+
+
+def frame_glue_batch_device(batch, cap, d_kps, d_n, d_depth, depth_stride, depth_frame_stride, mbf, width, height,
+                            d_u_right, d_kp_depth, d_cell_start, d_cell_items, stream=0, device_id=0):
+    """ComputeStereoFromRGBD + AssignFeaturesToGrid on the device (orbgpu_frame_glue_batch_device)."""
+    check(lib().orbgpu_frame_glue_batch_device(device_id, batch, cap, d_kps, d_n, d_depth, depth_stride,
+                                               depth_frame_stride, mbf, 0.0, float(width), 0.0, float(height),
+                                               d_u_right, d_kp_depth, d_cell_start, d_cell_items, stream))
 
 
 class Frame:

@@ -157,3 +157,37 @@ def test_assign_features_to_grid(gpu, oracle, stream640):
     gs, gi = gpu.assign_features_to_grid(x, y, 0.0, 0.0, inv_w, inv_h)
     os_, oi = oracle.assign_grid(x, y, 0.0, 0.0, inv_w, inv_h)
     assert np.array_equal(gs, os_) and np.array_equal(gi, oi)
+
+
+def test_frame_glue_on_device(gpu, oracle, stream640):
+    """ComputeStereoFromRGBD + AssignFeaturesToGrid for a batch straight out of the device extractor."""
+    torch = pytest.importorskip("torch")
+    B = 4
+    fr = [stream640.frame(50 + i) for i in range(B)]
+    imgs = torch.from_numpy(np.stack([f[0] for f in fr])).cuda()
+    depth = torch.from_numpy(np.stack([f[2] for f in fr])).cuda()
+    ge = gpu.ORBextractor(1000, max_batch=B)
+    cap = ge.max_keypoints(640, 480)
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ge.extract_batch_device(imgs.data_ptr(), B, 640, 480, 640, 640 * 480, kps.data_ptr(), desc.data_ptr(), cap,
+                            nout.data_ptr(), st)
+    ur = torch.zeros((B, cap), dtype=torch.float32, device="cuda")
+    dz = torch.zeros((B, cap), dtype=torch.float32, device="cuda")
+    cs = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    items = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    bf = float(stream640.bf)
+    gpu.frame_glue_batch_device(B, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), 640, 640 * 480, bf, 640, 480,
+                                ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), st)
+    torch.cuda.synchronize()
+    n = nout.cpu().numpy()
+    k = kps.cpu().numpy()
+    for f in range(B):
+        x, y = k[f, :n[f], 0], k[f, :n[f], 1]
+        our, od = oracle.compute_stereo_from_rgbd(x, y, x, fr[f][2], bf)
+        assert np.array_equal(ur[f, :n[f]].cpu().numpy(), our) and np.array_equal(dz[f, :n[f]].cpu().numpy(), od)
+        ocs, oit = oracle.assign_grid(x, y, 0.0, 0.0, np.float32(64) / np.float32(640), np.float32(48) / np.float32(480))
+        assert np.array_equal(cs[f].cpu().numpy(), ocs)
+        assert np.array_equal(items[f, :ocs[-1]].cpu().numpy(), oit)
