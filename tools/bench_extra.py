@@ -130,8 +130,77 @@ def c1():
                       "device_ms_sum_batch1": round(sum(stages.values()), 4)}))
 
 
+def pcie():
+    """C2 with the frames starting in (pinned) host memory and all results copied back every step."""
+    import torch
+    from orb_slam2_map_amd import lib as G
+    from orb_slam2_map_amd.synth import Stream
+    W, H, B, POOL = 640, 480, 256, 1024
+    st = Stream(W, H, 1234)
+    host = torch.from_numpy(np.stack([st.frame(t)[0] for t in range(POOL)])).pin_memory()
+    ext = G.ORBextractor(1000, max_batch=B)
+    cap = ext.max_keypoints(W, H)
+    matcher = G.BatchMatcher(B, cap)
+    dev = [torch.zeros((B, H, W), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    kps = torch.zeros((B + 1, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B + 1, dtype=torch.int32, device="cuda")
+    mb = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    nm = torch.zeros(B, dtype=torch.int32, device="cuda")
+    h_kps, h_desc = torch.zeros_like(kps, device="cpu").pin_memory(), torch.zeros_like(desc, device="cpu").pin_memory()
+    h_n, h_mb = torch.zeros_like(nout, device="cpu").pin_memory(), torch.zeros_like(mb, device="cpu").pin_memory()
+    KP, DS = cap * 28, cap * 32
+    s_cmp, s_up, s_down = torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    ev_up = [torch.cuda.Event() for _ in range(2)]
+    ev_free = [torch.cuda.Event() for _ in range(2)]
+    ev_done, ev_down = torch.cuda.Event(), torch.cuda.Event()
+
+    def upload(i):
+        with torch.cuda.stream(s_up):
+            s_up.wait_event(ev_free[i % 2])
+            dev[i % 2].copy_(host[(i * B) % POOL:(i * B) % POOL + B], non_blocking=True)
+            ev_up[i % 2].record(s_up)
+
+    def step(i):
+        upload(i + 1)  # next batch goes up while this one computes
+        s_cmp.wait_event(ev_up[i % 2])
+        s_cmp.wait_event(ev_down)  # previous results have left the output buffers
+        ext.extract_batch_device(dev[i % 2].data_ptr(), B, W, H, W, W * H, kps.data_ptr() + KP, desc.data_ptr() + DS, cap,
+                                 nout.data_ptr() + 4, s_cmp.cuda_stream)
+        ev_free[i % 2].record(s_cmp)
+        matcher.match(B, cap, desc.data_ptr(), kps.data_ptr() + 12, None, nout.data_ptr(), desc.data_ptr() + DS,
+                      kps.data_ptr() + KP + 12, nout.data_ptr() + 4, 28, 50, 0.7, True, mb.data_ptr(), nm.data_ptr(),
+                      s_cmp.cuda_stream)
+        ev_done.record(s_cmp)
+        with torch.cuda.stream(s_down):
+            s_down.wait_event(ev_done)
+            h_kps.copy_(kps, non_blocking=True), h_desc.copy_(desc, non_blocking=True)
+            h_n.copy_(nout, non_blocking=True), h_mb.copy_(mb, non_blocking=True)
+            kps[0].copy_(kps[B], non_blocking=True), desc[0].copy_(desc[B], non_blocking=True)
+            nout[0:1].copy_(nout[B:B + 1], non_blocking=True)
+            ev_down.record(s_down)
+
+    upload(0)
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    K = 20
+    t0 = time.perf_counter()
+    for i in range(3, 3 + K):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    up, down = B * W * H, kps.numel() * 4 + desc.numel() + nout.numel() * 4 + mb.numel() * 4
+    print(json.dumps({"config": "C2 PCIe-inclusive: 256 frames/step uploaded from pinned host memory (double buffered) and all "
+                                "key points, descriptors and matches downloaded every step",
+                      "frames_per_s": B * K / dt, "ms_per_step": dt / K * 1e3, "h2d_MB_per_step": up / 1e6,
+                      "d2h_MB_per_step": down / 1e6, "h2d_GBps_needed": up * K / dt / 1e9}))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c1", "c3", "c4"]
+    if "pcie" in which:
+        pcie()
     if "c1" in which:
         c1()
     if "c3" in which:
