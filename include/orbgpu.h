@@ -213,6 +213,52 @@ int orbgpu_frame_glue_batch_device(int32_t device_id, int32_t batch, int32_t cap
                                    float max_y, float *d_u_right, float *d_kp_depth, int32_t *d_cell_start,
                                    int32_t *d_cell_items, void *hip_stream);
 
+/* ---- Device-resident Tracking::SearchLocalPoints (Tracking.cc:1447-1497) ----------------------------------
+ * = Frame::isInFrustum (Frame.cc:269-325) + MapPoint::PredictScale (MapPoint.cc:385-394) over a MapPoint table
+ * kept in HBM, followed by ORBmatcher::SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:45-137), for a
+ * frame that never left the device (orbgpu_extract_batch_device -> orbgpu_frame_glue_batch_device).  Only the
+ * pose crosses PCIe. */
+typedef struct orbgpu_device_frame_view {
+    int32_t cap;                  /* capacity of the per-frame arrays (upper bound of *n) */
+    const int32_t *n;             /* device: N */
+    const orbgpu_keypoint *kps;   /* device [cap]: mvKeysUn */
+    const uint8_t *desc;          /* device [cap][32]: mDescriptors */
+    const float *u_right;         /* device [cap]: mvuRight */
+    const int32_t *cell_start;    /* device [COLS*ROWS+1]: mGrid as CSR */
+    const int32_t *cell_items;    /* device [cap] */
+    int32_t nlevels;
+    const float *scale_factors;   /* HOST [nlevels]: mvScaleFactors */
+    float min_x, max_x, min_y, max_y; /* mnMinX .. mnMaxY */
+} orbgpu_device_frame_view;
+
+typedef struct orbgpu_device_mappoint_table { /* all device pointers, row i = mvpLocalMapPoints[i] */
+    int32_t m;
+    const float *world_pos;   /* [m][3] GetWorldPos() */
+    const float *normal;      /* [m][3] GetNormal() */
+    const float *min_dist;    /* [m] mfMinDistance (the 0.8 / 1.2 invariance factors are applied inside) */
+    const float *max_dist;    /* [m] mfMaxDistance */
+    const uint8_t *desc;      /* [m][32] GetDescriptor() */
+    const uint8_t *skip;      /* [m] or NULL: isBad() || mnLastFrameSeen == F.mnId (Tracking.cc:1474-1477) */
+    const uint8_t *obs_pos;   /* [m] or NULL (= all 1): Observations() > 0 (ORBmatcher.cc:87-89) */
+} orbgpu_device_mappoint_table;
+
+typedef struct orbgpu_track_scratch { /* optional device outputs: the MapPoint::mTrack* members isInFrustum fills */
+    uint8_t *in_view;  /* [m] mbTrackInView (written for every row; drives IncreaseVisible, Tracking.cc:1481) */
+    float *proj_x, *proj_y, *proj_xr, *view_cos; /* [m] written where in_view */
+    int32_t *level;    /* [m] mnTrackScaleLevel */
+} orbgpu_track_scratch;
+
+/* d_kp_to_mp [cap] in/out (device): -1 free, -2 held by a point outside the table, >= 0 row of the table.
+ * d_counts [2] (device): [0] = return value of SearchByProjection, [1] = map points whose predicted level fell
+ * outside [0, nlevels) (the reference reads mvScaleFactors out of range there; they are left unmatched).
+ * Tcw: HOST, 4x4 row-major float (mTcw).  Asynchronous on hip_stream; calls issued by one host thread share a
+ * workspace and must be ordered on one stream. */
+int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const orbgpu_device_mappoint_table *mp,
+                                      const float *Tcw, float fx, float fy, float cx, float cy, float mbf,
+                                      float log_scale_factor, float cos_limit, float th, float nnratio,
+                                      int32_t *d_kp_to_mp, int32_t *d_counts, const orbgpu_track_scratch *d_track,
+                                      int32_t device_id, void *hip_stream);
+
 /* MapPoint tracking scratch filled by Frame::isInFrustum (MapPoint.h:91-96, Frame.cc:317-322)
  * plus the flags and descriptor the matcher reads per point (ORBmatcher.cc:53-63, 77, 88). */
 typedef struct {

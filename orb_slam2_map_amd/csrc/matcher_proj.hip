@@ -35,7 +35,9 @@ struct Query {  // one row of the matcher: a projected map point
 };
 
 struct FrameDev {
-    int n;
+    int n;             // key point count, or the array capacity when n_dev is set
+    const int *n_dev;  // device-resident count (frames straight out of the extractor); nullptr: use n
+    int kp_stride;     // element stride of kp_x / kp_y / kp_octave: 1 (SoA upload) or 7 (orbgpu_keypoint records)
     const float *kp_x, *kp_y;
     const int *kp_octave;
     const float *u_right;
@@ -103,13 +105,13 @@ __device__ __forceinline__ void proj_walk(const Query &Q, const uint64_t a[4], c
         for (int p = beg; p < end; p++) {
             const int idx = F.cell_items[p];
             if (check_levels) {
-                const int oct = F.kp_octave[idx];
+                const int oct = F.kp_octave[idx * F.kp_stride];
                 if (oct < Q.min_level)
                     continue;
                 if (Q.max_level >= 0 && oct > Q.max_level)
                     continue;
             }
-            const float dx = F.kp_x[idx] - Q.x, dy = F.kp_y[idx] - Q.y;
+            const float dx = F.kp_x[idx * F.kp_stride] - Q.x, dy = F.kp_y[idx * F.kp_stride] - Q.y;
             if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r))
                 continue;
             if (claim && claim[idx] < i)
@@ -183,8 +185,8 @@ __device__ __forceinline__ int proj_accept(uint64_t k1, uint64_t k2, const Frame
     const int bestIdx = (int)(k1 & 0xFFFFF);
     if (MODE == 0) {
         const int bestDist2 = (int)(k2 >> 44);
-        const int bestLevel = F.kp_octave[bestIdx];
-        const int bestLevel2 = bestDist2 < 256 ? F.kp_octave[(int)(k2 & 0xFFFFF)] : -1;
+        const int bestLevel = F.kp_octave[bestIdx * F.kp_stride];
+        const int bestLevel2 = bestDist2 < 256 ? F.kp_octave[(int)(k2 & 0xFFFFF) * F.kp_stride] : -1;
         if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)
             return -1;
     }
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
     __shared__ int s_keep[3];
     __shared__ int s_count, s_changed, s_nslow;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int n = F.n;
+    const int n = F.n_dev ? min(max(*F.n_dev, 0), F.n) : F.n;
+    const int kp_angle_stride = F.kp_stride;
     int *claimA = reinterpret_cast<int *>(smem);
     int *claimB = claimA + n;
     for (int j = tid; j < n; j += nt)
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
         cnt++;
         atomicMax(&last_claim[j], i);
         if (check_orientation)
-            atomicAdd(&histo[rot_bin(row_angle[i], kp_angle[j])], 1);
+            atomicAdd(&histo[rot_bin(row_angle[i], kp_angle[j * kp_angle_stride])], 1);
     }
     __syncthreads();
     for (int j = tid; j < n; j += nt)
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
             const int j = match[i];
             if (j < 0)
                 continue;
-            const int b = rot_bin(row_angle[i], kp_angle[j]);
+            const int b = rot_bin(row_angle[i], kp_angle[j * kp_angle_stride]);
             if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) {
                 kp_to_mp[j] = -1;
                 cnt--;
@@ -441,6 +444,8 @@ static int upload_frame(ProjWorkspace &ws, const orbgpu_frame_view *f, FrameDev 
     PJ_TRY(put(ws.cell_start, f->cell_start, (size_t)(GC * GR + 1) * 4, st));
     PJ_TRY(put(ws.cell_items, f->cell_items, std::max<size_t>((size_t)f->cell_start[GC * GR], 1) * 4, st));
     F.n = f->n;
+    F.n_dev = nullptr;
+    F.kp_stride = 1;
     F.kp_x = ws.kp_x.as<float>();
     F.kp_y = ws.kp_y.as<float>();
     F.kp_octave = ws.kp_octave.as<int>();
@@ -521,6 +526,111 @@ static void minus_rt_t(const float *T, float *out)
         for (int k = 0; k < 3; k++)
             s += (double)T[4 * k + i] * (double)T[4 * k + 3];
         out[i] = (float)(s * -1.0);
+    }
+}
+
+// ---- device-resident Tracking::SearchLocalPoints (Tracking.cc:1447-1497) -----------------------------
+struct FrustumParams {
+    float T[12];   // rows of [Rcw | tcw]
+    float Ow[3];   // camera centre, -Rcw^T tcw (Frame.cc:266)
+    float fx, fy, cx, cy, mbf;
+    float min_x, max_x, min_y, max_y;
+    float log_sf, cos_limit, th;
+    int nlevels;
+    float scale_factors[ORBGPU_MAX_LEVELS];
+};
+
+// Thread i < m: Frame::isInFrustum (Frame.cc:269-325) + MapPoint::PredictScale (MapPoint.cc:385-394) for map
+// point i, then the query row of ORBmatcher::SearchByProjection (:45-137: radius by viewing cosine, levels
+// [l-1, l]).  Thread j < cap: the claim table entry of key point j from the incoming association.
+__global__ __launch_bounds__(256) void k_frustum_queries(int m, const float *__restrict__ world_pos,
+                                                         const float *__restrict__ normal,
+                                                         const float *__restrict__ min_dist,
+                                                         const float *__restrict__ max_dist,
+                                                         const uint8_t *__restrict__ skip,
+                                                         const uint8_t *__restrict__ obs_pos, FrustumParams P,
+                                                         Query *__restrict__ q, int cap,
+                                                         const int *__restrict__ kp_to_mp, int *__restrict__ claim_init,
+                                                         orbgpu_track_scratch out, int *__restrict__ bad_levels)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        const int v = kp_to_mp[i];
+        const bool held = v == -2 || (v >= 0 && v < m && (obs_pos ? obs_pos[v] != 0 : true));
+        claim_init[i] = held ? -1 : INT_MAX;
+    }
+    if (i >= m)
+        return;
+    Query Q{};
+    Q.blocking = obs_pos ? (obs_pos[i] != 0) : 1;
+    bool in_view = false;
+    float u = 0.f, v = 0.f, ur = 0.f, view_cos = 0.f;
+    int level = 0;
+    if (!(skip && skip[i])) {
+        const float X = world_pos[3 * i], Y = world_pos[3 * i + 1], Z = world_pos[3 * i + 2];
+        // mRcw*P + mtcw: float products summed left to right, then the translation (same convention as the host
+        // entry points, DESIGN.md "float conventions")
+        float Pc[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            Pc[r] = ((P.T[4 * r] * X + P.T[4 * r + 1] * Y) + P.T[4 * r + 2] * Z) + P.T[4 * r + 3];
+        do {
+            if (Pc[2] < 0.0f)
+                break;
+            const float invz = 1.0f / Pc[2];
+            u = P.fx * Pc[0] * invz + P.cx;
+            v = P.fy * Pc[1] * invz + P.cy;
+            if (u < P.min_x || u > P.max_x || v < P.min_y || v > P.max_y)
+                break;
+            const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+            const float PO[3] = {X - P.Ow[0], Y - P.Ow[1], Z - P.Ow[2]};
+            const float dist = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+            if (dist < minDistance || dist > maxDistance)
+                break;
+            const double dot = (double)PO[0] * normal[3 * i] + (double)PO[1] * normal[3 * i + 1] +
+                               (double)PO[2] * normal[3 * i + 2];
+            view_cos = (float)(dot / (double)dist);
+            if (view_cos < P.cos_limit)
+                break;
+            const float ratio = max_dist[i] / dist;
+            // std::log(float): evaluated in double and rounded, which is the correctly rounded float logarithm
+            level = (int)ceilf((float)log((double)ratio) / P.log_sf);
+            ur = u - P.mbf * invz;
+            in_view = true;
+        } while (0);
+    }
+    if (in_view && (level < 0 || level >= P.nlevels)) {
+        // the reference indexes mvScaleFactors out of range here (undefined); such points are left unmatched
+        atomicAdd(bad_levels, 1);
+        in_view = false;
+    }
+    if (in_view) {
+        float r = (double)view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos, ORBmatcher.cc:131-137
+        if (P.th != 1.0f)
+            r *= P.th;
+        Q.r = r * P.scale_factors[level];
+        Q.x = u;
+        Q.y = v;
+        Q.ur = ur;
+        Q.min_level = level - 1;
+        Q.max_level = level;
+        Q.check_ur = 1;
+        Q.active = 1;
+    }
+    q[i] = Q;
+    if (out.in_view)
+        out.in_view[i] = in_view ? 1 : 0;
+    if (in_view) {
+        if (out.proj_x)
+            out.proj_x[i] = u;
+        if (out.proj_y)
+            out.proj_y[i] = v;
+        if (out.proj_xr)
+            out.proj_xr[i] = ur;
+        if (out.level)
+            out.level[i] = level;
+        if (out.view_cos)
+            out.view_cos[i] = view_cos;
     }
 }
 
@@ -613,6 +723,84 @@ int orbgpu_search_by_projection(const orbgpu_frame_view *f, const orbgpu_mappoin
     if ((rc = upload_frame(*ws, f, F)) != ORBGPU_OK)
         return rc;
     return run_projection<0>(*ws, F, q, mp->desc, nullptr, nullptr, init, nnratio, ORBGPU_TH_HIGH, 0, kp_to_mp, nmatches);
+}
+
+int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const orbgpu_device_mappoint_table *mp,
+                                      const float *Tcw, float fx, float fy, float cx, float cy, float mbf,
+                                      float log_scale_factor, float cos_limit, float th, float nnratio,
+                                      int32_t *d_kp_to_mp, int32_t *d_counts, const orbgpu_track_scratch *d_track,
+                                      int32_t device_id, void *hip_stream)
+{
+    ORBGPU_REQUIRE(f && mp && Tcw && d_kp_to_mp && d_counts, "null argument");
+    ORBGPU_REQUIRE(f->cap >= 1 && f->cap <= 16384, "frame capacity out of range (max 16384)");
+    ORBGPU_REQUIRE(f->n && f->kps && f->desc && f->u_right && f->cell_start && f->cell_items, "null frame arrays");
+    ORBGPU_REQUIRE(f->nlevels >= 1 && f->nlevels <= ORBGPU_MAX_LEVELS && f->scale_factors, "bad scale factors");
+    ORBGPU_REQUIRE(f->max_x > f->min_x && f->max_y > f->min_y, "empty image bounds");
+    ORBGPU_REQUIRE(mp->m >= 0 && mp->m < (1 << 20), "bad map point count");
+    if (mp->m > 0)
+        ORBGPU_REQUIRE(mp->world_pos && mp->normal && mp->min_dist && mp->max_dist && mp->desc, "null map point arrays");
+    int rc = select_device(device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ORBGPU_HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(int32_t), st));
+    if (mp->m == 0)
+        return ORBGPU_OK;
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    const int m = mp->m, cap = f->cap;
+    PJ_TRY(ws->queries.reserve(sizeof(Query) * (size_t)m));
+    PJ_TRY(ws->claim_init.reserve(sizeof(int) * (size_t)cap));
+    PJ_TRY(ws->topk.reserve(sizeof(uint64_t) * PJ_TOPK * (size_t)m));
+    PJ_TRY(ws->match.reserve(sizeof(int) * (size_t)m));
+    PJ_TRY(ws->slow.reserve(sizeof(int) * (size_t)m));
+    PJ_TRY(ws->out.reserve(2 * sizeof(int)));
+    FrustumParams P;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++)
+            P.T[4 * r + c] = Tcw[4 * r + c];
+    minus_rt_t(Tcw, P.Ow);
+    P.fx = fx, P.fy = fy, P.cx = cx, P.cy = cy, P.mbf = mbf;
+    P.min_x = f->min_x, P.max_x = f->max_x, P.min_y = f->min_y, P.max_y = f->max_y;
+    P.log_sf = log_scale_factor, P.cos_limit = cos_limit, P.th = th;
+    P.nlevels = f->nlevels;
+    for (int l = 0; l < ORBGPU_MAX_LEVELS; l++)
+        P.scale_factors[l] = l < f->nlevels ? f->scale_factors[l] : 0.f;
+    FrameDev F;
+    F.n = cap;
+    F.n_dev = f->n;
+    F.kp_stride = (int)(sizeof(orbgpu_keypoint) / sizeof(float));
+    F.kp_x = reinterpret_cast<const float *>(f->kps);
+    F.kp_y = F.kp_x + 1;
+    F.kp_octave = reinterpret_cast<const int *>(f->kps) + 5;
+    F.u_right = f->u_right;
+    F.desc = f->desc;
+    F.min_x = f->min_x;
+    F.min_y = f->min_y;
+    F.inv_w = (float)GC / (f->max_x - f->min_x);  // Frame.cc:155-156
+    F.inv_h = (float)GR / (f->max_y - f->min_y);
+    F.cell_start = f->cell_start;
+    F.cell_items = f->cell_items;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+        attr_set = true;
+    }
+    orbgpu_track_scratch none{};
+    const int cover = std::max(m, cap);
+    hipLaunchKernelGGL(k_frustum_queries, dim3((cover + 255) / 256), dim3(256), 0, st, m, mp->world_pos, mp->normal,
+                       mp->min_dist, mp->max_dist, mp->skip, mp->obs_pos, P, ws->queries.as<Query>(), cap, d_kp_to_mp,
+                       ws->claim_init.as<int>(), d_track ? *d_track : none, d_counts + 1);
+    hipLaunchKernelGGL(k_proj_topk, dim3((m + 3) / 4), dim3(256), 0, st, m, ws->queries.as<Query>(), mp->desc, F,
+                       ws->topk.as<uint64_t>());
+    hipLaunchKernelGGL(k_proj_resolve<0>, dim3(1), dim3(1024), (size_t)8 * cap, st, m, ws->queries.as<Query>(), mp->desc,
+                       F, nnratio, (int)ORBGPU_TH_HIGH, ws->claim_init.as<int>(), ws->topk.as<uint64_t>(),
+                       ws->match.as<int>(), ws->slow.as<int>(), (const float *)nullptr, (const float *)nullptr, 0,
+                       d_kp_to_mp, d_counts, ws->out.as<int>());
+    ORBGPU_HIP_TRY(hipGetLastError());
+    return ORBGPU_OK;
 }
 
 int orbgpu_search_by_projection_last(const orbgpu_frame_view *cur, const float *cur_Tcw, float fx, float fy,

@@ -57,6 +57,23 @@ class KeyFrameView(C.Structure):
                 ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("kp_angle", C.c_void_p)]
 
 
+class DeviceFrameView(C.Structure):
+    _fields_ = [("cap", C.c_int32), ("n", C.c_void_p), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("u_right", C.c_void_p), ("cell_start", C.c_void_p), ("cell_items", C.c_void_p),
+                ("nlevels", C.c_int32), ("scale_factors", C.c_void_p), ("min_x", C.c_float), ("max_x", C.c_float),
+                ("min_y", C.c_float), ("max_y", C.c_float)]
+
+
+class DeviceMapPointTable(C.Structure):
+    _fields_ = [("m", C.c_int32), ("world_pos", C.c_void_p), ("normal", C.c_void_p), ("min_dist", C.c_void_p),
+                ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("skip", C.c_void_p), ("obs_pos", C.c_void_p)]
+
+
+class TrackScratch(C.Structure):
+    _fields_ = [("in_view", C.c_void_p), ("proj_x", C.c_void_p), ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p),
+                ("view_cos", C.c_void_p), ("level", C.c_void_p)]
+
+
 class LastFrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("has_mp", C.c_void_p), ("outlier", C.c_void_p), ("obs_pos", C.c_void_p),
                 ("world_pos", C.c_void_p), ("desc", C.c_void_p), ("kp_octave", C.c_void_p),
@@ -77,7 +94,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
-    "orbgpu_frame_glue_batch_device",
+    "orbgpu_frame_glue_batch_device", "orbgpu_search_local_points_device",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
@@ -132,6 +149,7 @@ def lib():
         "orbgpu_matcher_last_sweeps": [vp, vp],
         "orbgpu_assign_features_to_grid": [i32, vp, vp, f32, f32, f32, f32, vp, vp],
         "orbgpu_frame_glue_batch_device": [i32, i32, i32, vp, vp, vp, sz, sz, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
+        "orbgpu_search_local_points_device": [vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp],
         "orbgpu_search_by_projection": [vp, vp, f32, f32, vp, vp, i32],
         "orbgpu_search_by_projection_last": [vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
         "orbgpu_search_by_projection_keyframe": [vp, vp, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
@@ -294,6 +312,16 @@ def frame_glue_batch_device(batch, cap, d_kps, d_n, d_depth, depth_stride, depth
     check(lib().orbgpu_frame_glue_batch_device(device_id, batch, cap, d_kps, d_n, d_depth, depth_stride,
                                                depth_frame_stride, mbf, 0.0, float(width), 0.0, float(height),
                                                d_u_right, d_kp_depth, d_cell_start, d_cell_items, stream))
+
+
+def search_local_points_device(frame_view, table, Tcw, fx, fy, cx, cy, mbf, log_sf, th, nnratio, d_kp_to_mp, d_counts,
+                               track=None, cos_limit=0.5, stream=0, device_id=0):
+    """Tracking::SearchLocalPoints on device-resident data (orbgpu_search_local_points_device).
+    frame_view: DeviceFrameView, table: DeviceMapPointTable, track: TrackScratch or None."""
+    T = np.ascontiguousarray(Tcw, np.float32)
+    check(lib().orbgpu_search_local_points_device(C.byref(frame_view), C.byref(table), _p(T), fx, fy, cx, cy, mbf, log_sf,
+                                                  cos_limit, th, nnratio, d_kp_to_mp, d_counts,
+                                                  C.byref(track) if track is not None else None, device_id, stream))
 
 
 class Frame:

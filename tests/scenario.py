@@ -40,8 +40,9 @@ def world_points_from_prev(kps_prev, depth_prev, shift, stream, Tcw, rng, jitter
     return Pw.astype(np.float32), has_depth
 
 
-def local_map(O, stream, Tcw, world_pos, desc, octave, scale_factors, rng, obs_zero_frac=0.0):
-    """Pre-fills the MapPoint tracking scratch exactly as Frame::isInFrustum does (oracle)."""
+def local_map(O, stream, Tcw, world_pos, desc, octave, scale_factors, rng, obs_zero_frac=0.0, vary=False):
+    """Pre-fills the MapPoint tracking scratch exactly as Frame::isInFrustum does (oracle).
+    vary: also produce points that fail the viewing-angle and distance-range gates."""
     m = len(world_pos)
     sf = np.asarray(scale_factors, np.float32)
     log_sf = float(np.log(np.float32(sf[1])))
@@ -51,6 +52,9 @@ def local_map(O, stream, Tcw, world_pos, desc, octave, scale_factors, rng, obs_z
                                             ("level", np.int32), ("view_cos", np.float32), ("proj_x", np.float32),
                                             ("proj_y", np.float32), ("proj_xr", np.float32))}
     out["desc"] = np.ascontiguousarray(desc, np.uint8)
+    out["normal"] = np.zeros((m, 3), np.float32)      # inputs of isInFrustum, kept for the device-resident path
+    out["min_dist"] = np.zeros(m, np.float32)
+    out["max_dist"] = np.zeros(m, np.float32)
     out["obs_pos"][:] = (rng.random(m) >= obs_zero_frac).astype(np.uint8)
     out["bad"][:] = (rng.random(m) < 0.02).astype(np.uint8)
     for i in range(m):
@@ -62,9 +66,18 @@ def local_map(O, stream, Tcw, world_pos, desc, octave, scale_factors, rng, obs_z
         lvl = int(octave[i])
         max_d = np.float32(dist * sf[lvl])
         min_d = np.float32(max_d / sf[-1])
+        if vary:
+            kind = rng.integers(0, 10)
+            if kind == 0:    # oblique normal: viewCos around / below the 0.5 limit
+                normal = normal + rng.normal(0, 1.2, 3)
+                normal /= np.linalg.norm(normal)
+            elif kind == 1:  # observed from much closer / farther before: outside the invariance range
+                max_d = np.float32(max_d * rng.choice([0.4, 0.8, 0.84, 3.0]))
+                min_d = np.float32(max_d / sf[-1] * rng.choice([1.0, 1.24, 1.26]))
+        out["normal"][i], out["min_dist"][i], out["max_dist"][i] = normal.astype(np.float32), min_d, max_d
         ok, px, py, pxr, level, vc = O.is_in_frustum(Tcw, float(stream.fx), float(stream.fy), float(stream.cx),
                                                      float(stream.cy), float(stream.bf), stream.w, stream.h,
-                                                     world_pos[i], normal.astype(np.float32), float(min_d),
+                                                     world_pos[i], out["normal"][i], float(min_d),
                                                      float(max_d), log_sf)
         if ok and 0 <= level < len(sf):
             out["in_view"][i] = 1

@@ -191,3 +191,91 @@ def test_frame_glue_on_device(gpu, oracle, stream640):
         ocs, oit = oracle.assign_grid(x, y, 0.0, 0.0, np.float32(64) / np.float32(640), np.float32(48) / np.float32(480))
         assert np.array_equal(cs[f].cpu().numpy(), ocs)
         assert np.array_equal(items[f, :ocs[-1]].cpu().numpy(), oit)
+
+
+@pytest.mark.parametrize("th,obs_zero", [(3.0, 0.0), (1.0, 0.3), (5.0, 0.0)])
+def test_search_local_points_device_resident(gpu, oracle, th, obs_zero):
+    """extract -> frame glue -> isInFrustum -> SearchByProjection without leaving the device, against the oracle's
+    isInFrustum + SearchByProjection on the same map points (Tracking::SearchLocalPoints, Tracking.cc:1447-1497)."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    from orb_slam2_map_amd.synth import Stream
+    rng = np.random.default_rng(77)
+    w, h, nfeat, nprev, t_cur = 640, 480, 1000, 3, 12
+    st = Stream(w, h, 1234)
+    ts = [t_cur - 1 - i for i in range(nprev)] + [t_cur]
+    frames = [st.frame(t) for t in ts]
+    ge = gpu.ORBextractor(nfeat, max_batch=nprev + 1)
+    ks, ds = ge.extract_batch(np.stack([f[0] for f in frames]))
+    sf = np.asarray(ge.GetScaleFactors(), np.float32)
+    Tcw = scenario.rigid()
+    ox, oy = st.offset(t_cur)
+    wp, dsc, octv = [], [], []
+    for i, t in enumerate(ts[:-1]):
+        px, py = st.offset(t)
+        P, _ = scenario.world_points_from_prev(ks[i], frames[i][2], (ox - px, oy - py), st, Tcw, rng)
+        wp.append(P), dsc.append(ds[i]), octv.append(ks[i]["octave"])
+    wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
+    wp[::37] = -wp[::37]  # some points behind the camera / outside the image
+    mp = scenario.local_map(oracle, st, Tcw, wp, dsc, octv, sf, rng, obs_zero, vary=True)
+    m = len(wp)
+    assert 0.4 * m < mp["in_view"].sum() < 0.95 * m
+    # oracle side: the frame on the host, scratch from ora_is_in_frustum (scenario.local_map), skip == bad
+    of = scenario.make_frame(oracle, ks[-1], ds[-1], frames[-1][2], st, sf)
+    k0 = np.full(of.n, -1, np.int32)
+    pre = rng.choice(of.n, 200, replace=False)
+    k0[pre[:100]] = rng.integers(0, m, 100)
+    k0[pre[100:]] = -2
+    no, ko = oracle.search_by_projection(of, mp, th, 0.8, k0)
+    assert no > 50
+
+    # device side: the current frame goes through the device-resident chain
+    img = torch.from_numpy(frames[-1][0][None]).cuda()
+    depth = torch.from_numpy(frames[-1][2][None]).cuda()
+    g1 = gpu.ORBextractor(nfeat, max_batch=1)
+    cap = g1.max_keypoints(w, h)
+    kps = torch.zeros((1, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    g1.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), s)
+    ur = torch.zeros((1, cap), dtype=torch.float32, device="cuda")
+    dz = torch.zeros((1, cap), dtype=torch.float32, device="cuda")
+    cs = torch.zeros((1, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    items = torch.zeros((1, cap), dtype=torch.int32, device="cuda")
+    gpu.frame_glue_batch_device(1, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), w, w * h, float(st.bf), w, h,
+                                ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in
+           (("world_pos", wp), ("normal", mp["normal"]), ("min_dist", mp["min_dist"]), ("max_dist", mp["max_dist"]),
+            ("desc", mp["desc"]), ("skip", mp["bad"]), ("obs_pos", mp["obs_pos"]))}
+    fv = gpu.DeviceFrameView()
+    fv.cap, fv.n, fv.kps, fv.desc, fv.u_right = cap, nout.data_ptr(), kps.data_ptr(), desc.data_ptr(), ur.data_ptr()
+    fv.cell_start, fv.cell_items, fv.nlevels, fv.scale_factors = cs.data_ptr(), items.data_ptr(), len(sf), sf.ctypes.data
+    fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(w), 0.0, float(h)
+    tb = gpu.DeviceMapPointTable()
+    tb.m = m
+    for k in dev:
+        setattr(tb, k, dev[k].data_ptr())
+    trk = {k: torch.zeros(m, dtype=dt, device="cuda") for k, dt in
+           (("in_view", torch.uint8), ("proj_x", torch.float32), ("proj_y", torch.float32), ("proj_xr", torch.float32),
+            ("view_cos", torch.float32), ("level", torch.int32))}
+    ts_ = gpu.TrackScratch()
+    for k in trk:
+        setattr(ts_, k, trk[k].data_ptr())
+    k2m = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+    k2m[:of.n] = torch.from_numpy(k0).cuda()
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    log_sf = float(np.log(np.float32(sf[1])))
+    gpu.search_local_points_device(fv, tb, Tcw, float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf),
+                                   log_sf, th, 0.8, k2m.data_ptr(), counts.data_ptr(), ts_, stream=s)
+    torch.cuda.synchronize()
+    assert int(nout[0]) == of.n
+    # isInFrustum parity (bad points are skipped on the device and keep in_view 0; the oracle scenario computed them)
+    live = mp["bad"] == 0
+    iv = trk["in_view"].cpu().numpy()
+    assert np.array_equal(iv[live], mp["in_view"][live])
+    sel = live & (mp["in_view"] != 0)
+    for k in ("proj_x", "proj_y", "proj_xr", "view_cos", "level"):
+        assert np.array_equal(trk[k].cpu().numpy()[sel], mp[k][sel]), k
+    c = counts.cpu().numpy()
+    assert c[0] == no and np.array_equal(k2m.cpu().numpy()[:of.n], ko)
