@@ -67,14 +67,17 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 // One LANE per A row (its 256-bit descriptor lives in 8 VGPRs) looping over the B rows; the B row is
 // the same for the whole wave, so it arrives through the scalar cache (s_load_dwordx8) and the XORs
 // take SGPR operands: 8 v_xor + 8 v_bcnt (with accumulate) per distance, no LDS, no cross-lane merge.
-// grid = (ceil(cap / 256), pairs, BF_SPLIT): the B rows are split into BF_SPLIT contiguous ranges to double
-// the number of waves in flight; k_bf_resolve merges the partial lists (4 smallest of their union).
-constexpr int BF_SPLIT = 2;
+// grid = (ceil(cap / 256), pairs, nsplit): the B rows are split into nsplit contiguous ranges to put enough
+// waves in flight (2 for a full batch, up to BF_MAX_SPLIT for a single pair, where the scan is latency bound);
+// k_bf_resolve merges the partial lists (4 smallest of their union).
+constexpr int BF_MIN_SPLIT = 2, BF_MAX_SPLIT = 16;
+constexpr size_t BF_RESOLVE_MAX_LDS = 150 * 1024;  // of the CU's 160 KB; static LDS of k_bf_resolve is < 1 KB
 
 __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
                                                  const int *__restrict__ nb_p, uint32_t *__restrict__ topk)
 {
+    const int nsplit = gridDim.z;
     const int pair = blockIdx.y;
     const int na = min(na_p[pair], cap);
     int nb = min(nb_p[pair], cap);
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
         a[w] = ga[w];
     const uint32_t *gb = reinterpret_cast<const uint32_t *>(desc_b + (size_t)pair * cap * 32);
     uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
-    const int per = (nb + BF_SPLIT - 1) / BF_SPLIT;
+    const int per = (nb + nsplit - 1) / nsplit;
     int j = (int)blockIdx.z * per;
     nb = min(nb, j + per);
     for (; j + 4 <= nb; j += 4) {  // 4 B rows per step: their scalar loads are issued together
@@ -117,14 +120,14 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
         top4_insert(t, bf_key((int)d, j));
     }
     if ((int)(blockIdx.x * 256 + threadIdx.x) < na)
-        *reinterpret_cast<uint4 *>(topk + (((size_t)pair * cap + i) * BF_SPLIT + blockIdx.z) * BF_TOPK) =
+        *reinterpret_cast<uint4 *>(topk + (((size_t)pair * cap + i) * nsplit + blockIdx.z) * BF_TOPK) =
             make_uint4(t[0], t[1], t[2], t[3]);
 }
 
 // Exact best/second over the B rows visible to A row i: full scan by one wave (lanes stride over the
 // B rows; ties resolve to the lower index exactly as the sequential scan does).  Used only when the
 // cached top-K list cannot decide.
-__device__ void bf_full_scan_wave(const uint64_t *__restrict__ ga, const uint64_t *__restrict__ gb, int i, int nb,
+__device__ __forceinline__ void bf_full_scan_wave(const uint64_t *__restrict__ ga, const uint64_t *gb, int i, int nb,
                                   const int *claim, int &b1, int &i1, int &b2)
 {
     const int lane = threadIdx.x & 63;
@@ -157,14 +160,13 @@ __device__ void bf_full_scan_wave(const uint64_t *__restrict__ ga, const uint64_
     b2 = v2;
 }
 
-// merged candidate list of row i: the 4 smallest keys over the BF_SPLIT partial lists
-__device__ __forceinline__ void bf_load_keys(const uint32_t *__restrict__ tk, int i, uint32_t key[4])
+// merged candidate list of row i: the 4 smallest keys over the nsplit partial lists
+__device__ __forceinline__ void bf_load_keys(const uint32_t *__restrict__ tk, int i, int nsplit, uint32_t key[4])
 {
-    const uint4 k4 = *reinterpret_cast<const uint4 *>(tk + (size_t)i * BF_SPLIT * BF_TOPK);
+    const uint4 k4 = *reinterpret_cast<const uint4 *>(tk + (size_t)i * nsplit * BF_TOPK);
     key[0] = k4.x, key[1] = k4.y, key[2] = k4.z, key[3] = k4.w;
-#pragma unroll
-    for (int sp = 1; sp < BF_SPLIT; sp++) {
-        const uint4 o4 = *reinterpret_cast<const uint4 *>(tk + ((size_t)i * BF_SPLIT + sp) * BF_TOPK);
+    for (int sp = 1; sp < nsplit; sp++) {
+        const uint4 o4 = *reinterpret_cast<const uint4 *>(tk + ((size_t)i * nsplit + sp) * BF_TOPK);
         const uint32_t o[4] = {o4.x, o4.y, o4.z, o4.w};
         top4_merge(key, o);
     }
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
                                                      const uint8_t *__restrict__ angle_a,
                                                      const uint8_t *__restrict__ angle_b, size_t angle_stride,
                                                      int check_orientation, int *__restrict__ match_b,
-                                                     int *__restrict__ nmatches, int *__restrict__ sweeps_used)
+                                                     int *__restrict__ nmatches, int *__restrict__ sweeps_used,
+                                                     int stage_b, int nsplit)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int histo[ORBGPU_HISTO_LENGTH];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
     int *slow = match + cap;                      // [cap] rows whose cached list cannot decide
     const uint64_t *ga = reinterpret_cast<const uint64_t *>(desc_a + (size_t)pair * cap * 32);
     const uint64_t *gb = reinterpret_cast<const uint64_t *>(desc_b + (size_t)pair * cap * 32);
-    const uint32_t *tk = topk + (size_t)pair * cap * BF_SPLIT * BF_TOPK;
+    const uint32_t *tk = topk + (size_t)pair * cap * nsplit * BF_TOPK;
     const uint8_t *va = valid_a ? valid_a + (size_t)pair * cap : nullptr;
     int *mb = match_b + (size_t)pair * cap;
 
@@ -207,11 +210,20 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
         claimA[j] = INT_MAX;
         match[j] = -2;  // "undecided": differs from every possible result
     }
+    // the full scans of undecidable rows read every B descriptor: keep them in LDS when they fit
+    const uint64_t *scan_b = gb;
+    if (stage_b) {
+        uint4 *sb = reinterpret_cast<uint4 *>(slow + cap);
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(gb);
+        for (int x = tid; x < nb * 2; x += nt)
+            sb[x] = g4[x];
+        scan_b = reinterpret_cast<const uint64_t *>(sb);
+    }
     // the candidate list of row `tid` (the only row of this thread unless na > blockDim) stays in registers
     uint32_t key0[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
     uint8_t valid0 = 0;
     if (tid < na) {
-        bf_load_keys(tk, tid, key0);
+        bf_load_keys(tk, tid, nsplit, key0);
         valid0 = (!va || va[tid]) ? 1 : 0;
     }
     __syncthreads();
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
             if (i == tid ? valid0 != 0 : (!va || va[i])) {
                 uint32_t key[4] = {key0[0], key0[1], key0[2], key0[3]};
                 if (i != tid)
-                    bf_load_keys(tk, i, key);
+                    bf_load_keys(tk, i, nsplit, key);
                 int b1 = 256, i1 = -1, b2 = 256, found = 0;
                 bool complete = false;  // list exhausted: every B row has been considered
 #pragma unroll
@@ -249,8 +261,14 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
                         found++;
                     }
                 }
-                // a visible best that already fails the threshold needs no second distance
+                // a visible best that already fails the threshold needs no second distance; neither does one that
+                // passes the ratio test against the LAST cached distance: every B row outside the list is at least
+                // that far, so the true second distance b2 >= d4 and b1 < r*d4 implies b1 < r*b2 (:228-231)
                 decided = found == 2 || complete || (found == 1 && b1 > th_low);
+                if (!decided && found == 1 && (float)b1 < nnratio * (float)bf_key_dist(key[BF_TOPK - 1])) {
+                    decided = true;
+                    b2 = bf_key_dist(key[BF_TOPK - 1]);
+                }
                 if (decided && b1 <= th_low && (float)b1 < nnratio * (float)b2)  // ORBmatcher.cc:228-231
                     result = i1;
             }
@@ -273,7 +291,7 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
             for (int r = wave; r < nslow; r += nw) {
                 const int i = slow[r];
                 int b1, i1, b2;
-                bf_full_scan_wave(ga, gb, i, nb, claimA, b1, i1, b2);
+                bf_full_scan_wave(ga, scan_b, i, nb, claimA, b1, i1, b2);
                 if ((tid & 63) == 0) {
                     int result = -1;
                     if (b1 <= th_low && (float)b1 < nnratio * (float)b2)
@@ -400,13 +418,13 @@ int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orb
     m->max_pairs = max_pairs;
     m->cap = cap;
     const size_t P = (size_t)max_pairs;
-    if ((rc = m->d_topk.reserve(sizeof(uint32_t) * P * cap * BF_TOPK * BF_SPLIT)) != ORBGPU_OK ||
+    if ((rc = m->d_topk.reserve(sizeof(uint32_t) * std::max<size_t>(P * BF_MIN_SPLIT, BF_MAX_SPLIT) * cap * BF_TOPK)) != ORBGPU_OK ||
         (rc = m->d_sweeps.reserve(sizeof(int) * P)) != ORBGPU_OK) {
         orbgpu_matcher_destroy(m);
         return rc;
     }
     hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bf_resolve),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 4096 + 256);
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, BF_RESOLVE_MAX_LDS);
     if (he != hipSuccess) {
         set_error("hipFuncSetAttribute: %s", hipGetErrorString(he));
         orbgpu_matcher_destroy(m);
@@ -444,12 +462,20 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
         return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     uint32_t *topk = m->d_topk.as<uint32_t>();
-    const dim3 grid((cap + 255) / 256, pairs, BF_SPLIT);
+    // enough waves to cover the device (~2048) while the partial lists fit the buffer sized at creation
+    int nsplit = BF_MIN_SPLIT;
+    while (nsplit < BF_MAX_SPLIT && (size_t)pairs * ((cap + 255) / 256) * 4 * nsplit < 2048 &&
+           (size_t)pairs * nsplit * 2 <= std::max<size_t>((size_t)m->max_pairs * BF_MIN_SPLIT, BF_MAX_SPLIT))
+        nsplit *= 2;
+    const dim3 grid((cap + 255) / 256, pairs, nsplit);
     hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk);
-    hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), (size_t)16 * cap, st, cap, d_desc_a, d_valid_a, d_na,
+    // claim / match / queue tables (16 B per row) + the B descriptors (32 B per row) when both fit in LDS
+    const int stage_b = (size_t)48 * cap <= BF_RESOLVE_MAX_LDS ? 1 : 0;
+    const size_t lds = (size_t)(stage_b ? 48 : 16) * cap;
+    hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), lds, st, cap, d_desc_a, d_valid_a, d_na,
                        d_desc_b, d_nb, topk, th_low, nnratio, reinterpret_cast<const uint8_t *>(d_angle_a),
                        reinterpret_cast<const uint8_t *>(d_angle_b), angle_stride, check_orientation, d_match_b,
-                       d_nmatches, m->d_sweeps.as<int>());
+                       d_nmatches, m->d_sweeps.as<int>(), stage_b, nsplit);
     ORBGPU_HIP_TRY(hipGetLastError());
     m->last_pairs = pairs;
     return ORBGPU_OK;

@@ -260,6 +260,16 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
                 decided = found >= need || complete || (found == 1 && (int)(k1 >> 44) > th_dist);
                 if (decided && found > 0)
                     result = proj_accept<MODE>(k1, k2, F, nnratio, th_dist);
+                if (MODE == 0 && !decided && found == 1) {
+                    // every candidate outside the cached list is at least as far as its last entry d4, so the
+                    // unknown second distance is >= d4: a best that is not rejected against d4 is not rejected
+                    // against it either, whatever its level (:114-118)
+                    const int d4 = (int)(tk[PJ_TOPK - 1] >> 44);
+                    if (!((float)(int)(k1 >> 44) > nnratio * (float)d4)) {
+                        decided = true;
+                        result = (int)(k1 & 0xFFFFF);
+                    }
+                }
             }
             if (!decided) {
                 slow[atomicAdd(&s_nslow, 1)] = i;

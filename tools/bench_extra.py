@@ -58,9 +58,59 @@ def c3():
     for _ in range(reps):
         O.search_by_projection(of, mp, 3.0, 0.8, k0)
     t_cpu = (time.perf_counter() - t0) / reps
+    # device-resident chain: extract -> frame glue -> isInFrustum + SearchByProjection, only the pose goes up
+    import torch
+    W, H = 1280, 960
+    img = torch.from_numpy(frames[-1][0][None]).cuda()
+    depth = torch.from_numpy(frames[-1][2][None]).cuda()
+    g1 = G.ORBextractor(2000, max_batch=1)
+    cap = g1.max_keypoints(W, H)
+    kps = torch.zeros((1, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ur, dz = (torch.zeros((1, cap), dtype=torch.float32, device="cuda") for _ in range(2))
+    cs = torch.zeros((1, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    items = torch.zeros((1, cap), dtype=torch.int32, device="cuda")
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in
+           (("world_pos", wp), ("normal", mp["normal"]), ("min_dist", mp["min_dist"]), ("max_dist", mp["max_dist"]),
+            ("desc", mp["desc"]), ("skip", mp["bad"]), ("obs_pos", mp["obs_pos"]))}
+    sfa = np.asarray(sf, np.float32)
+    fv = G.DeviceFrameView()
+    fv.cap, fv.n, fv.kps, fv.desc, fv.u_right = cap, nout.data_ptr(), kps.data_ptr(), desc.data_ptr(), ur.data_ptr()
+    fv.cell_start, fv.cell_items, fv.nlevels, fv.scale_factors = cs.data_ptr(), items.data_ptr(), len(sfa), sfa.ctypes.data
+    fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(W), 0.0, float(H)
+    tb = G.DeviceMapPointTable()
+    tb.m = len(wp)
+    for k in dev:
+        setattr(tb, k, dev[k].data_ptr())
+    k2m = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    log_sf = float(np.log(np.float32(sfa[1])))
+
+    def chain(with_extract):
+        if with_extract:
+            g1.extract_batch_device(img.data_ptr(), 1, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), cap,
+                                    nout.data_ptr(), s)
+            G.frame_glue_batch_device(1, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), W, W * H, float(st.bf),
+                                      W, H, ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s)
+        k2m.fill_(-1)
+        G.search_local_points_device(fv, tb, Tcw, float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf),
+                                     log_sf, 3.0, 0.8, k2m.data_ptr(), counts.data_ptr(), None, stream=s)
+    res = {}
+    for name, we in (("search_local_points_device_ms", False), ("extract_glue_search_device_ms", True)):
+        chain(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            chain(we)
+            torch.cuda.synchronize()   # one frame at a time, as a Tracking thread would consume it
+        res[name] = (time.perf_counter() - t0) / reps * 1e3
+    n_dev = int(counts[0])
     print(json.dumps({"config": "C3: 1280x960, 2000 features, SearchByProjection vs %d map points (%d in view)" % (
-        len(wp), int(mp["in_view"].sum())), "matches": n, "gpu_host_api_ms_per_call": t_proj * 1e3,
-        "extract_single_frame_host_api_ms": t_ext * 1e3, "oracle_cpu_ms_per_call": t_cpu * 1e3}))
+        len(wp), int(mp["in_view"].sum())), "matches": n, "matches_device_resident": n_dev,
+        "gpu_host_api_ms_per_call": t_proj * 1e3, "extract_single_frame_host_api_ms": t_ext * 1e3,
+        "oracle_cpu_ms_per_call": t_cpu * 1e3, **res}))
 
 
 def c4():
