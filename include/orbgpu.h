@@ -259,6 +259,11 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
                                       int32_t *d_kp_to_mp, int32_t *d_counts, const orbgpu_track_scratch *d_track,
                                       int32_t device_id, void *hip_stream);
 
+/* Convergence diagnostics of the calling thread's most recent projection match (orbgpu_search_by_projection*,
+ * orbgpu_search_local_points_device): claim sweeps run and rows that had to be re-walked with the claim filter.
+ * Synchronises the device. */
+int orbgpu_projection_last_sweeps(int32_t *sweeps, int32_t *rewalked_rows);
+
 /* MapPoint tracking scratch filled by Frame::isInFrustum (MapPoint.h:91-96, Frame.cc:317-322)
  * plus the flags and descriptor the matcher reads per point (ORBmatcher.cc:53-63, 77, 88). */
 typedef struct {

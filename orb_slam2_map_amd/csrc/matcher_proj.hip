@@ -8,10 +8,11 @@
 // (map point) whose MapPoint::Observations()>0 is skipped by every later row (:87-89, :1403-1405).
 // As in the brute-force matcher the GPU evaluates all rows in parallel and iterates to the unique
 // triangular fixpoint ("row i sees the claims of rows < i"), which equals the sequential result.
-// Pass 1 (k_proj_topk): one wave per row walks the grid window ONCE -- lanes take the window's cells
-// (ix outer, iy inner: the reference's candidate order, which decides ties) -- and caches the 4 best
-// candidates as 64-bit keys (distance, order, index).  Pass 2 (k_proj_resolve): one workgroup runs the
-// sweeps from the cached lists with the claim tables in LDS.
+// Pass 1 (k_proj_lists): one wave per row walks the grid window ONCE -- lanes take the window's cells
+// (ix outer, iy inner: the reference's candidate order, which decides ties) -- and caches the 16 best
+// candidates in preference order (distance, visiting order).  Pass 2 (k_proj_resolve): one workgroup runs
+// the sweeps from the cached lists (first four words of a row in registers) with the claim tables in LDS;
+// only a row whose 16 cached candidates cannot decide is walked again with the claim filter.
 #include "common.h"
 #include "matcher_common.h"
 
@@ -47,7 +48,6 @@ struct FrameDev {
 };
 
 constexpr uint64_t KEY_NONE = ((uint64_t)256 << 44) | 0xFFFFFFFFFFFull;
-constexpr int PJ_TOPK = 4;
 
 __device__ __forceinline__ void keep2(uint64_t &k1, uint64_t &k2, uint64_t k)
 {
@@ -81,12 +81,12 @@ __device__ __forceinline__ void top4_insert64(uint64_t t[4], uint64_t k)
 //   distance << 44 | cell sequence << 32 | position in cell << 20 | key point index,
 // whose ascending order is exactly the order in which the sequential loop would prefer candidates.
 // `claim` == nullptr: no claim filtering (pass 1); otherwise key points with claim[idx] < i are hidden.
-// Returns (per lane) the 4 smallest keys of the lane's cells in t[]; the caller merges across lanes.
-__device__ __forceinline__ void proj_walk(const Query &Q, const uint64_t a[4], const FrameDev &F, const int *claim,
-                                          int i, uint64_t t[4])
+// sink(key, octave) is called by the lane that found the candidate.
+template <class Sink>
+__device__ __forceinline__ void proj_walk_each(const Query &Q, const uint64_t a[4], const FrameDev &F,
+                                               const int *claim, int i, Sink &&sink)
 {
     const int lane = threadIdx.x & 63;
-    t[0] = t[1] = t[2] = t[3] = KEY_NONE;
     const int c0 = (int)floorf((Q.x - F.min_x - Q.r) * F.inv_w);
     const int c1 = (int)ceilf((Q.x - F.min_x + Q.r) * F.inv_w);
     const int r0 = (int)floorf((Q.y - F.min_y - Q.r) * F.inv_h);
@@ -104,8 +104,8 @@ __device__ __forceinline__ void proj_walk(const Query &Q, const uint64_t a[4], c
         const int beg = F.cell_start[cell], end = F.cell_start[cell + 1];
         for (int p = beg; p < end; p++) {
             const int idx = F.cell_items[p];
+            const int oct = F.kp_octave[idx * F.kp_stride];
             if (check_levels) {
-                const int oct = F.kp_octave[idx * F.kp_stride];
                 if (oct < Q.min_level)
                     continue;
                 if (Q.max_level >= 0 && oct > Q.max_level)
@@ -125,9 +125,17 @@ __device__ __forceinline__ void proj_walk(const Query &Q, const uint64_t a[4], c
             const uint64_t *db = reinterpret_cast<const uint64_t *>(F.desc) + (size_t)idx * 4;
             uint64_t b[4] = {db[0], db[1], db[2], db[3]};
             const uint64_t d = (uint64_t)hamming256(a, b);
-            top4_insert64(t, (d << 44) | ((uint64_t)seq << 32) | ((uint64_t)(p - beg) << 20) | (uint64_t)idx);
+            sink((d << 44) | ((uint64_t)seq << 32) | ((uint64_t)(p - beg) << 20) | (uint64_t)idx, oct);
         }
     }
+}
+
+// the 4 best keys per lane (the claim-filtered re-walk of pass 2); the caller merges across lanes
+__device__ __forceinline__ void proj_walk(const Query &Q, const uint64_t a[4], const FrameDev &F, const int *claim,
+                                          int i, uint64_t t[4])
+{
+    t[0] = t[1] = t[2] = t[3] = KEY_NONE;
+    proj_walk_each(Q, a, F, claim, i, [&](uint64_t key, int) { top4_insert64(t, key); });
 }
 
 // wave merge of per-lane sorted 4-lists -> every lane holds the 4 smallest keys of the wave
@@ -153,25 +161,67 @@ __device__ __forceinline__ void top4_wave_merge64(uint64_t t[4])
     }
 }
 
-// Pass 1: one wave per row, the PJ_TOPK best candidates of every row ignoring claims.
-__global__ __launch_bounds__(256) void k_proj_topk(int m, const Query *__restrict__ q,
-                                                   const uint8_t *__restrict__ row_desc, FrameDev F,
-                                                   uint64_t *__restrict__ topk)
+// Candidate lists as the sweeps see them: one 32-bit word per candidate,
+//   key point index (14 bits) | distance (9 bits) << 14 | octave (4 bits) << 23,
+// in the preference order of the 64-bit keys, PJ_LIST words per row, PJ_NONE after the last candidate (a list
+// that contains PJ_NONE is complete: it holds every candidate of the window).
+constexpr uint32_t PJ_NONE = 0xFFFFFFFFu;
+constexpr uint32_t PJ_REWALK = 0xFFFFFFFEu;  // word 0: the window held more candidates than a wave can rank
+constexpr int PJ_LIST = 16;                  // cached candidates per row (4 stay in registers in pass 2)
+constexpr int PJ_WBUF = 64;                  // candidates a wave ranks in LDS
+__device__ __forceinline__ int pj_idx(uint32_t w) { return (int)(w & 0x3FFFu); }
+__device__ __forceinline__ int pj_dist(uint32_t w) { return w == PJ_NONE ? 256 : (int)((w >> 14) & 0x1FFu); }
+__device__ __forceinline__ int pj_oct(uint32_t w) { return (int)((w >> 23) & 0xFu); }
+
+// Pass 1: one wave per row walks the window once (no claim filter), drops every candidate into LDS, ranks them
+// by key and writes the PJ_LIST best as 32-bit words.
+__global__ __launch_bounds__(256) void k_proj_lists(int m, const Query *__restrict__ q,
+                                                    const uint8_t *__restrict__ row_desc, FrameDev F,
+                                                    uint32_t *__restrict__ lists)
 {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= m)
-        return;
-    const Query Q = q[i];
-    uint64_t t[4] = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
-    if (Q.active) {
-        const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
-        const uint64_t a[4] = {da[0], da[1], da[2], da[3]};
-        proj_walk(Q, a, F, nullptr, i, t);
-        top4_wave_merge64(t);
+    __shared__ uint64_t s_key[4][PJ_WBUF];
+    __shared__ uint32_t s_word[4][PJ_WBUF];
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + w;
+    if (lane == 0)
+        s_cnt[w] = 0;
+    __syncthreads();
+    const bool live = i < m;
+    if (live) {
+        const Query Q = q[i];
+        if (Q.active) {
+            const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
+            const uint64_t a[4] = {da[0], da[1], da[2], da[3]};
+            proj_walk_each(Q, a, F, nullptr, i, [&](uint64_t key, int oct) {
+                const int slot = atomicAdd(&s_cnt[w], 1);
+                if (slot < PJ_WBUF) {
+                    s_key[w][slot] = key;
+                    s_word[w][slot] = (uint32_t)(key & 0x3FFFu) | ((uint32_t)(key >> 44) << 14) | ((uint32_t)(oct & 0xF) << 23);
+                }
+            });
+        }
     }
-    if (lane < 4)
-        topk[(size_t)i * PJ_TOPK + lane] = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : t[3];
+    __syncthreads();
+    if (!live)
+        return;
+    uint32_t *out = lists + (size_t)i * PJ_LIST;
+    const int total = s_cnt[w];
+    if (total > PJ_WBUF) {
+        if (lane < PJ_LIST)
+            out[lane] = PJ_REWALK;
+        return;
+    }
+    if (lane < total) {
+        const uint64_t key = s_key[w][lane];
+        int rank = 0;
+        for (int j = 0; j < total; j++)
+            rank += s_key[w][j] < key ? 1 : 0;  // keys are unique (they carry the key point index)
+        if (rank < PJ_LIST)
+            out[rank] = s_word[w][lane];
+    } else if (lane < PJ_LIST) {
+        out[lane] = PJ_NONE;
+    }
 }
 
 // accept rule.  mode 0: ORBmatcher.cc:114-125 (TH_HIGH, ratio test only on equal levels);
@@ -193,6 +243,101 @@ __device__ __forceinline__ int proj_accept(uint64_t k1, uint64_t k2, const Frame
     return bestIdx;
 }
 
+// ---- pass 2 decision from the cached list ----------------------------------------------------------------
+constexpr int PJ_RC = 8;  // rows per thread whose first four words stay in registers (8 * 1024 = 8192 rows)
+
+struct PjScan {
+    uint32_t k1 = PJ_NONE, k2 = PJ_NONE;  // best / second visible candidate so far
+    int found = 0;
+    bool complete = false;  // the end of the list was reached: nothing else is in the window
+};
+
+// continue the scan over four more words under the claim table of the previous sweep
+__device__ __forceinline__ void pj_scan4(const uint32_t w[4], int i, const int *claimA, PjScan &s)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (s.complete || s.found >= 2)
+            continue;
+        if (w[k] == PJ_NONE) {
+            s.complete = true;
+        } else if (!(claimA[pj_idx(w[k])] < i)) {
+            if (s.found == 0)
+                s.k1 = w[k];
+            else
+                s.k2 = w[k];
+            s.found++;
+        }
+    }
+}
+
+// decision after scanning the list up to (and including) a word of distance d_last (only meaningful when the
+// scan is not complete).  mode 0: ORBmatcher.cc:114-125 (TH_HIGH, ratio test only on equal levels);
+// mode 1: :1424-1430 / :1554 (threshold only).
+template <int MODE>
+__device__ __forceinline__ int pj_finish(const PjScan &s, int d_last, float nnratio, int th_dist, bool &decided)
+{
+    const int need = MODE == 0 ? 2 : 1;
+    const int b1 = pj_dist(s.k1);
+    decided = s.found >= need || s.complete || (s.found == 1 && b1 > th_dist);
+    int result = -1;
+    if (decided && s.found > 0 && b1 <= th_dist) {
+        result = pj_idx(s.k1);
+        if (MODE == 0) {
+            const int b2 = pj_dist(s.k2);
+            const int l2 = b2 < 256 ? pj_oct(s.k2) : -1;
+            if (pj_oct(s.k1) == l2 && (float)b1 > nnratio * (float)b2)
+                result = -1;
+        }
+    }
+    if (MODE == 0 && !decided && s.found == 1) {
+        // every candidate beyond the scanned part of the list is at least d_last away, so the unknown second
+        // distance is >= d_last: a best that is not rejected against d_last is not rejected against it either,
+        // whatever its level (:114-118)
+        if (!((float)b1 > nnratio * (float)d_last)) {
+            decided = true;
+            result = pj_idx(s.k1);
+        }
+    }
+    return result;
+}
+
+// The words beyond the first four, fetched only when those cannot decide (kept out of line: it is the rare path
+// and would otherwise be replicated for every register-resident row).
+template <int MODE>
+__device__ __noinline__ int pj_decide_more(PjScan s, const uint32_t *__restrict__ lists, int i, const int *claimA,
+                                           float nnratio, int th_dist, bool *decided_out)
+{
+    const uint4 *more = reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST);
+    bool decided = false;
+    int result = -1;
+    for (int g = 1; g < PJ_LIST / 4 && !decided; g++) {
+        const uint4 v = more[g];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        pj_scan4(w, i, claimA, s);
+        result = pj_finish<MODE>(s, pj_dist(w[3]), nnratio, th_dist, decided);
+    }
+    *decided_out = decided;
+    return decided ? result : -1;
+}
+
+// Row i: first four words given (registers).
+template <int MODE>
+__device__ __forceinline__ int pj_decide(const uint32_t w0[4], const uint32_t *__restrict__ lists, int i,
+                                         const int *claimA, float nnratio, int th_dist, bool &decided)
+{
+    if (w0[0] == PJ_REWALK) {
+        decided = false;
+        return -1;
+    }
+    PjScan s;
+    pj_scan4(w0, i, claimA, s);
+    const int result = pj_finish<MODE>(s, pj_dist(w0[3]), nnratio, th_dist, decided);
+    if (decided)
+        return result;
+    return pj_decide_more<MODE>(s, lists, i, claimA, nnratio, th_dist, &decided);
+}
+
 // Pass 2: the greedy claim order as a fixpoint, ONE workgroup.  Claim tables (two, ping-pong) live in
 // LDS.  A sweep re-decides every row from its cached candidate list, hiding key points that rows < i
 // with Observations()>0 claimed in the previous sweep; rows whose list cannot decide are re-walked by a
@@ -200,12 +345,14 @@ __device__ __forceinline__ int proj_accept(uint64_t k1, uint64_t k2, const Frame
 // bounded by m+1.  Then F.mvpMapPoints is written: the LAST claimant of a key point wins (a
 // non-blocking claimant can be overwritten, :123 / :1428) and, for mode 1, every accepted row whose
 // rotation bin is not among the three maxima clears its key point (:1448-1467).
+// match[] (global) always holds the latest decision of every row; the owner thread mirrors it in a register
+// for its cached rows and stores only when the decision changes.
 template <int MODE>
 __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__restrict__ q,
                                                        const uint8_t *__restrict__ row_desc, FrameDev F,
                                                        float nnratio, int th_dist,
                                                        const int *__restrict__ claim_init,
-                                                       const uint64_t *__restrict__ topk, int *__restrict__ match,
+                                                       const uint32_t *__restrict__ lists, int *__restrict__ match,
                                                        int *__restrict__ slow, const float *__restrict__ row_angle,
                                                        const float *__restrict__ kp_angle, int check_orientation,
                                                        int *__restrict__ kp_to_mp, int *__restrict__ nmatches,
@@ -224,8 +371,28 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
         claimA[j] = claim_init[j];
     for (int i = tid; i < m; i += nt)
         match[i] = -2;
+    // register-resident rows: r-th row of this thread is i = r * nt + tid
+    uint32_t cw[PJ_RC][4];
+    int cres[PJ_RC];
+    uint32_t cact = 0, cblk = 0;  // bit r: row active / row blocking
+    uint32_t cslow = 0;           // bit r: row was queued in the current sweep
+#pragma unroll
+    for (int r = 0; r < PJ_RC; r++) {
+        const int i = r * nt + tid;
+        cres[r] = -2;
+        cw[r][0] = cw[r][1] = cw[r][2] = cw[r][3] = PJ_NONE;
+        if (i < m) {
+            if (q[i].active) {
+                cact |= 1u << r;
+                const uint4 v = *reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST);
+                cw[r][0] = v.x, cw[r][1] = v.y, cw[r][2] = v.z, cw[r][3] = v.w;
+            }
+            if (q[i].blocking)
+                cblk |= 1u << r;
+        }
+    }
     __syncthreads();
-    int sweeps = 0;
+    int sweeps = 0, rewalked = 0;
     for (int iter = 0; iter <= m + 1; iter++) {
         for (int j = tid; j < n; j += nt)
             claimB[j] = claim_init[j];
@@ -235,56 +402,54 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
         }
         __syncthreads();
         bool changed = false;
-        for (int i = tid; i < m; i += nt) {
-            int result = -1;
-            bool decided = true;
-            if (q[i].active) {
-                const uint64_t *tk = topk + (size_t)i * PJ_TOPK;
-                uint64_t k1 = KEY_NONE, k2 = KEY_NONE;
-                int found = 0;
-                bool complete = false;
+        cslow = 0;
 #pragma unroll
-                for (int k = 0; k < PJ_TOPK; k++) {
-                    const uint64_t key = tk[k];
-                    if (key == KEY_NONE) {
-                        complete = true;
-                    } else if (found < 2 && !(claimA[(int)(key & 0xFFFFF)] < i)) {
-                        if (found == 0)
-                            k1 = key;
-                        else
-                            k2 = key;
-                        found++;
-                    }
-                }
-                const int need = MODE == 0 ? 2 : 1;
-                decided = found >= need || complete || (found == 1 && (int)(k1 >> 44) > th_dist);
-                if (decided && found > 0)
-                    result = proj_accept<MODE>(k1, k2, F, nnratio, th_dist);
-                if (MODE == 0 && !decided && found == 1) {
-                    // every candidate outside the cached list is at least as far as its last entry d4, so the
-                    // unknown second distance is >= d4: a best that is not rejected against d4 is not rejected
-                    // against it either, whatever its level (:114-118)
-                    const int d4 = (int)(tk[PJ_TOPK - 1] >> 44);
-                    if (!((float)(int)(k1 >> 44) > nnratio * (float)d4)) {
-                        decided = true;
-                        result = (int)(k1 & 0xFFFFF);
-                    }
+        for (int r = 0; r < PJ_RC; r++) {
+            const int i = r * nt + tid;
+            if (i >= m)
+                continue;
+            int result = -1;
+            if (cact & (1u << r)) {
+                bool decided;
+                result = pj_decide<MODE>(cw[r], lists, i, claimA, nnratio, th_dist, decided);
+                if (!decided) {
+                    slow[atomicAdd(&s_nslow, 1)] = i;
+                    cslow |= 1u << r;
+                    continue;
                 }
             }
-            if (!decided) {
-                slow[atomicAdd(&s_nslow, 1)] = i;
-                continue;
+            if (cres[r] != result) {
+                changed = true;
+                cres[r] = result;
+                match[i] = result;
+            }
+            if (result >= 0 && (cblk & (1u << r)))
+                atomicMin(&claimB[result], i);
+        }
+        for (int i = PJ_RC * nt + tid; i < m; i += nt) {  // rows beyond the register budget
+            int result = -1;
+            const Query Q = q[i];
+            if (Q.active) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                bool decided;
+                result = pj_decide<MODE>(w, lists, i, claimA, nnratio, th_dist, decided);
+                if (!decided) {
+                    slow[atomicAdd(&s_nslow, 1)] = i;
+                    continue;
+                }
             }
             if (match[i] != result) {
                 changed = true;
                 match[i] = result;
             }
-            if (result >= 0 && q[i].blocking)
+            if (result >= 0 && Q.blocking)
                 atomicMin(&claimB[result], i);
         }
         __syncthreads();
         {
             const int nslow = s_nslow;
+            rewalked += nslow;
             const int wave = tid >> 6, nw = nt >> 6;
             for (int r = wave; r < nslow; r += nw) {
                 const int i = slow[r];
@@ -310,6 +475,12 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
         if (changed)
             s_changed = 1;
         __syncthreads();
+        if (cslow) {  // pick up what the wave-cooperative walk decided for this thread's queued rows
+#pragma unroll
+            for (int r = 0; r < PJ_RC; r++)
+                if (cslow & (1u << r))
+                    cres[r] = match[r * nt + tid];
+        }
         sweeps++;
         const bool again = s_changed != 0;
         __syncthreads();
@@ -370,7 +541,8 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
     __syncthreads();
     if (tid == 0) {
         *nmatches = s_count;
-        *sweeps_out = sweeps;
+        sweeps_out[0] = sweeps;
+        sweeps_out[1] = rewalked;
     }
 }
 
@@ -487,10 +659,10 @@ static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vecto
     PJ_TRY(put(ws.row_desc, row_desc_host, (size_t)m * 32, st));
     PJ_TRY(put(ws.claim_init, claim_init.data(), sizeof(int) * n, st));
     PJ_TRY(put(ws.k2m, kp_to_mp, sizeof(int) * n, st));
-    PJ_TRY(ws.topk.reserve(sizeof(uint64_t) * PJ_TOPK * (size_t)m));
+    PJ_TRY(ws.topk.reserve(sizeof(uint32_t) * PJ_LIST * (size_t)m));
     PJ_TRY(ws.match.reserve(sizeof(int) * m));
     PJ_TRY(ws.slow.reserve(sizeof(int) * m));
-    PJ_TRY(ws.out.reserve(2 * sizeof(int)));
+    PJ_TRY(ws.out.reserve(4 * sizeof(int)));
     if (check_orientation) {
         PJ_TRY(put(ws.row_angle, row_angle_host, sizeof(float) * m, st));
         PJ_TRY(put(ws.kp_angle, kp_angle_host, sizeof(float) * n, st));
@@ -503,10 +675,10 @@ static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vecto
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_proj_topk, dim3((m + 3) / 4), dim3(256), 0, st, m, ws.queries.as<Query>(),
-                       ws.row_desc.as<uint8_t>(), F, ws.topk.as<uint64_t>());
+    hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws.queries.as<Query>(),
+                       ws.row_desc.as<uint8_t>(), F, ws.topk.as<uint32_t>());
     hipLaunchKernelGGL(k_proj_resolve<MODE>, dim3(1), dim3(1024), (size_t)8 * n, st, m, ws.queries.as<Query>(),
-                       ws.row_desc.as<uint8_t>(), F, nnratio, th_dist, ws.claim_init.as<int>(), ws.topk.as<uint64_t>(),
+                       ws.row_desc.as<uint8_t>(), F, nnratio, th_dist, ws.claim_init.as<int>(), ws.topk.as<uint32_t>(),
                        ws.match.as<int>(), ws.slow.as<int>(), ws.row_angle.as<float>(), ws.kp_angle.as<float>(),
                        check_orientation, ws.k2m.as<int>(), ws.out.as<int>(), ws.out.as<int>() + 1);
     ORBGPU_HIP_TRY(hipGetLastError());
@@ -762,10 +934,10 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     const int m = mp->m, cap = f->cap;
     PJ_TRY(ws->queries.reserve(sizeof(Query) * (size_t)m));
     PJ_TRY(ws->claim_init.reserve(sizeof(int) * (size_t)cap));
-    PJ_TRY(ws->topk.reserve(sizeof(uint64_t) * PJ_TOPK * (size_t)m));
+    PJ_TRY(ws->topk.reserve(sizeof(uint32_t) * PJ_LIST * (size_t)m));
     PJ_TRY(ws->match.reserve(sizeof(int) * (size_t)m));
     PJ_TRY(ws->slow.reserve(sizeof(int) * (size_t)m));
-    PJ_TRY(ws->out.reserve(2 * sizeof(int)));
+    PJ_TRY(ws->out.reserve(4 * sizeof(int)));
     FrustumParams P;
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 4; c++)
@@ -803,13 +975,34 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     hipLaunchKernelGGL(k_frustum_queries, dim3((cover + 255) / 256), dim3(256), 0, st, m, mp->world_pos, mp->normal,
                        mp->min_dist, mp->max_dist, mp->skip, mp->obs_pos, P, ws->queries.as<Query>(), cap, d_kp_to_mp,
                        ws->claim_init.as<int>(), d_track ? *d_track : none, d_counts + 1);
-    hipLaunchKernelGGL(k_proj_topk, dim3((m + 3) / 4), dim3(256), 0, st, m, ws->queries.as<Query>(), mp->desc, F,
-                       ws->topk.as<uint64_t>());
+    hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws->queries.as<Query>(), mp->desc, F,
+                       ws->topk.as<uint32_t>());
     hipLaunchKernelGGL(k_proj_resolve<0>, dim3(1), dim3(1024), (size_t)8 * cap, st, m, ws->queries.as<Query>(), mp->desc,
-                       F, nnratio, (int)ORBGPU_TH_HIGH, ws->claim_init.as<int>(), ws->topk.as<uint64_t>(),
+                       F, nnratio, (int)ORBGPU_TH_HIGH, ws->claim_init.as<int>(), ws->topk.as<uint32_t>(),
                        ws->match.as<int>(), ws->slow.as<int>(), (const float *)nullptr, (const float *)nullptr, 0,
-                       d_kp_to_mp, d_counts, ws->out.as<int>());
+                       d_kp_to_mp, d_counts, ws->out.as<int>() + 1);
     ORBGPU_HIP_TRY(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int orbgpu_projection_last_sweeps(int32_t *sweeps, int32_t *rewalked_rows)
+{
+    // convergence diagnostics of the calling thread's most recent projection match (any of the four entry points)
+    ORBGPU_REQUIRE(sweeps && rewalked_rows, "null argument");
+    static thread_local int dummy;
+    (void)dummy;
+    ProjWorkspace *ws = nullptr;
+    int dev = 0;
+    ORBGPU_HIP_TRY(hipGetDevice(&dev));
+    int rc = workspace(dev, &ws);
+    if (rc != ORBGPU_OK)
+        return rc;
+    ORBGPU_REQUIRE(ws->out.p, "no projection match recorded on this thread");
+    ORBGPU_HIP_TRY(hipDeviceSynchronize());
+    int h[2] = {0, 0};
+    ORBGPU_HIP_TRY(hipMemcpy(h, ws->out.as<int>() + 1, sizeof(h), hipMemcpyDeviceToHost));
+    *sweeps = h[0];
+    *rewalked_rows = h[1];
     return ORBGPU_OK;
 }
 

@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
-    "orbgpu_frame_glue_batch_device", "orbgpu_search_local_points_device",
+    "orbgpu_frame_glue_batch_device", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
@@ -150,6 +150,7 @@ def lib():
         "orbgpu_assign_features_to_grid": [i32, vp, vp, f32, f32, f32, f32, vp, vp],
         "orbgpu_frame_glue_batch_device": [i32, i32, i32, vp, vp, vp, sz, sz, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
         "orbgpu_search_local_points_device": [vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp],
+        "orbgpu_projection_last_sweeps": [vp, vp],
         "orbgpu_search_by_projection": [vp, vp, f32, f32, vp, vp, i32],
         "orbgpu_search_by_projection_last": [vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
         "orbgpu_search_by_projection_keyframe": [vp, vp, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
@@ -322,6 +323,13 @@ def search_local_points_device(frame_view, table, Tcw, fx, fy, cx, cy, mbf, log_
     check(lib().orbgpu_search_local_points_device(C.byref(frame_view), C.byref(table), _p(T), fx, fy, cx, cy, mbf, log_sf,
                                                   cos_limit, th, nnratio, d_kp_to_mp, d_counts,
                                                   C.byref(track) if track is not None else None, device_id, stream))
+
+
+def projection_last_sweeps():
+    """(claim sweeps, re-walked rows) of this thread's most recent projection match."""
+    a, b = C.c_int32(), C.c_int32()
+    check(lib().orbgpu_projection_last_sweeps(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 class Frame:

@@ -279,3 +279,40 @@ def test_search_local_points_device_resident(gpu, oracle, th, obs_zero):
         assert np.array_equal(trk[k].cpu().numpy()[sel], mp[k][sel]), k
     c = counts.cpu().numpy()
     assert c[0] == no and np.array_equal(k2m.cpu().numpy()[:of.n], ko)
+
+
+@pytest.mark.parametrize("th,expect_rewalk", [(1.5, False), (3.0, True), (6.0, True)])
+def test_search_by_projection_crowded_windows(gpu, oracle, th, expect_rewalk):
+    """Windows far more crowded than real frames produce: 14 / 58 / 230 candidates per row, i.e. rows decided from
+    the cached 16-entry list, rows whose list is exhausted, and rows whose window exceeds what pass 1 can rank
+    (all of the latter are walked again under the claim filter).  Many rows share their best key point."""
+    rng = np.random.default_rng(int(th * 10))
+    w, h, n, m = 640, 480, 4000, 3000
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    x = rng.uniform(200, 400, n).astype(np.float32)
+    y = rng.uniform(150, 350, n).astype(np.float32)
+    octv = rng.integers(0, 2, n).astype(np.int32)
+    ang = rng.uniform(0, 360, n).astype(np.float32)
+    ur = np.where(rng.random(n) < 0.5, x - 8.0, -1.0).astype(np.float32)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    gf = gpu.Frame(x, y, octv, ang, ur, desc, w, h, sf)
+    of = oracle.Frame(x, y, octv, ang, ur, desc, w, h, sf)
+    src = rng.integers(0, 600, m)              # many map points descend from the same 600 key points
+    mdesc = desc[src].copy()
+    flips = rng.integers(0, 256, (m, 12))
+    for k in range(12):                         # up to 12 flipped bits: distances well below TH_HIGH
+        mdesc[np.arange(m), flips[:, k] // 8] ^= (1 << (flips[:, k] % 8)).astype(np.uint8)
+    mp = {"in_view": (rng.random(m) < 0.95).astype(np.uint8), "bad": (rng.random(m) < 0.02).astype(np.uint8),
+          "obs_pos": (rng.random(m) < 0.8).astype(np.uint8), "level": rng.integers(0, 2, m).astype(np.int32),
+          "view_cos": rng.choice(np.array([0.9, 0.999], np.float32), m),
+          "proj_x": (x[src] + rng.normal(0, 1.5, m)).astype(np.float32),
+          "proj_y": (y[src] + rng.normal(0, 1.5, m)).astype(np.float32), "desc": mdesc}
+    mp["proj_xr"] = (mp["proj_x"] - 8.0 + rng.normal(0, 1.0, m)).astype(np.float32)
+    k0 = np.full(n, -1, np.int32)
+    for ratio in (0.8, 0.95):
+        ng, kg = gpu.ORBmatcher(ratio).SearchByProjection(gf, mp, th, k0)
+        sweeps, rewalked = gpu.projection_last_sweeps()
+        no, ko = oracle.search_by_projection(of, mp, th, ratio, k0)
+        assert no > 200
+        assert ng == no and np.array_equal(kg, ko), "%d vs %d, %d differ" % (ng, no, int((kg != ko).sum()))
+        assert sweeps >= 2 and (rewalked > 0) == expect_rewalk, (sweeps, rewalked)

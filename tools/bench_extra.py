@@ -107,6 +107,7 @@ def c3():
             torch.cuda.synchronize()   # one frame at a time, as a Tracking thread would consume it
         res[name] = (time.perf_counter() - t0) / reps * 1e3
     n_dev = int(counts[0])
+    res["sweeps"], res["rewalked_rows"] = G.projection_last_sweeps()
     print(json.dumps({"config": "C3: 1280x960, 2000 features, SearchByProjection vs %d map points (%d in view)" % (
         len(wp), int(mp["in_view"].sum())), "matches": n, "matches_device_resident": n_dev,
         "gpu_host_api_ms_per_call": t_proj * 1e3, "extract_single_frame_host_api_ms": t_ext * 1e3,
