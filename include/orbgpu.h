@@ -202,15 +202,32 @@ typedef struct {
 int orbgpu_assign_features_to_grid(int32_t n, const float *kp_x, const float *kp_y, float min_x, float min_y,
                                    float grid_inv_w, float grid_inv_h, int32_t *cell_start, int32_t *cell_items);
 
+/* Camera of a Frame: mK (Frame.h:107-111), mDistCoef (k1 k2 p1 p2 k3; k3 = 0 for the 4-entry form, Tracking.cc:96-106),
+ * mbf, and the undistorted image bounds mnMinX..mnMaxY (Frame::ComputeImageBounds, Frame.cc:436-468). */
+typedef struct orbgpu_camera {
+    float fx, fy, cx, cy;
+    float dist[5];
+    float mbf;
+    float min_x, max_x, min_y, max_y;
+} orbgpu_camera;
+
+/* cv::undistortPoints(src, dst, mK, mDistCoef, Mat(), mK) as Frame::UndistortKeyPoints (Frame.cc:404-434) and
+ * Frame::ComputeImageBounds (:436-468) call it: n interleaved (x, y) pairs, host pointers, evaluated on the device
+ * in double exactly as OpenCV 2.4 cvUndistortPoints does (5 iterations).  For the four image corners this gives
+ * the bounds to put into orbgpu_camera. */
+int orbgpu_undistort_points(int32_t n, const float *xy_in, const orbgpu_camera *cam, float *xy_out, int32_t device_id);
+
 /* Device-resident Frame glue for a batch of frames straight out of orbgpu_extract_batch_device:
- * Frame::ComputeStereoFromRGBD (Frame.cc:641-662: mvuRight = kpUn.x - mbf/d, mvDepth = d where d > 0, else -1)
- * and Frame::AssignFeaturesToGrid (Frame.cc:230-245) as CSR per frame (cell_start[batch][COLS*ROWS+1],
- * cell_items[batch][cap], items in insertion order).  mvKeysUn == mvKeys (zero distortion).  d_depth may be
- * NULL (grid only); depth strides are in floats.  All pointers are device pointers; nothing is synchronised. */
+ * Frame::UndistortKeyPoints (Frame.cc:404-434; d_kps_un [batch][cap] receives mvKeysUn, required when
+ * cam->dist[0] != 0, optional otherwise), Frame::ComputeStereoFromRGBD (Frame.cc:641-662: depth looked up at the
+ * distorted key point, mvuRight = kpUn.x - mbf/d, mvDepth = d where d > 0, else -1) and
+ * Frame::AssignFeaturesToGrid (Frame.cc:230-245, on mvKeysUn) as CSR per frame (cell_start[batch][COLS*ROWS+1],
+ * cell_items[batch][cap], items in insertion order).  d_depth may be NULL (no stereo outputs); depth strides are
+ * in floats.  All pointers except cam are device pointers; nothing is synchronised. */
 int orbgpu_frame_glue_batch_device(int32_t device_id, int32_t batch, int32_t cap, const orbgpu_keypoint *d_kps,
                                    const int32_t *d_n, const float *d_depth, size_t depth_stride,
-                                   size_t depth_frame_stride, float mbf, float min_x, float max_x, float min_y,
-                                   float max_y, float *d_u_right, float *d_kp_depth, int32_t *d_cell_start,
+                                   size_t depth_frame_stride, const orbgpu_camera *cam, orbgpu_keypoint *d_kps_un,
+                                   float *d_u_right, float *d_kp_depth, int32_t *d_cell_start,
                                    int32_t *d_cell_items, void *hip_stream);
 
 /* ---- Device-resident Tracking::SearchLocalPoints (Tracking.cc:1447-1497) ----------------------------------

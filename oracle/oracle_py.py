@@ -371,6 +371,19 @@ def is_in_frustum(Tcw, fx, fy, cx, cy, mbf, width, height, P, normal, min_dist, 
     return bool(ok), px.value, py.value, pxr.value, lvl.value, vc.value
 
 
+def undistort_points(xy, fx, fy, cx, cy, dist):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    d = np.zeros(5, np.float32)
+    d[:len(dist)] = dist
+    out = np.zeros_like(xy)
+    L = lib()
+    L.ora_undistort_points.argtypes = [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                       C.c_void_p]
+    L.ora_undistort_points.restype = None
+    L.ora_undistort_points(len(xy), _p(xy), fx, fy, cx, cy, _p(d), _p(out))
+    return out
+
+
 def compute_stereo_from_rgbd(kp_x, kp_y, kpun_x, depth, mbf):
     kp_x = np.ascontiguousarray(kp_x, np.float32)
     kp_y = np.ascontiguousarray(kp_y, np.float32)

@@ -200,6 +200,10 @@ int ora_is_in_frustum(const float *Tcw, float fx, float fy, float cx, float cy, 
                       float max_dist, float log_scale_factor, int nlevels_unused, float cos_limit, float *proj_x,
                       float *proj_y, float *proj_xr, int32_t *level, float *view_cos);
 
+/* ---- cv::undistortPoints as used by Frame::UndistortKeyPoints / ComputeImageBounds (Frame.cc:404-468) ---- */
+void ora_undistort_points(int n, const float *xy_in, float fx, float fy, float cx, float cy, const float *dist,
+                          float *xy_out);
+
 /* ---- ComputeStereoFromRGBD, Frame.cc:641-662 ---- */
 void ora_compute_stereo_from_rgbd(int n, const float *kp_x, const float *kp_y, const float *kpun_x,
                                   const float *depth, size_t depth_stride_elems, float mbf, float *u_right,

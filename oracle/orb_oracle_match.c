@@ -526,6 +526,37 @@ int ora_is_in_frustum(const float *Tcw, float fx, float fy, float cx, float cy, 
     return 1;
 }
 
+/* cv::undistortPoints(src, dst, K, distCoef, Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call it
+ * (Frame.cc:404-468), OpenCV 2.4 cvUndistortPoints: everything in double, five fixed-point iterations, the
+ * rational terms k4..k6 zero, R = identity, P = K.  dist = k1 k2 p1 p2 k3 (k3 = 0 for a 4-entry mDistCoef).
+ * Restated from knowledge of the 2.4 source: unpinned like the other OpenCV pieces. */
+void ora_undistort_points(int n, const float *xy_in, float fx_, float fy_, float cx_, float cy_, const float *dist,
+                          float *xy_out)
+{
+    const double fx = fx_, fy = fy_, cx = cx_, cy = cy_;
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k[8] = {dist[0], dist[1], dist[2], dist[3], dist[4], 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        double x = xy_in[2 * i], y = xy_in[2 * i + 1];
+        const double x0 = x = (x - cx) * ifx;
+        const double y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        /* RR = P * I = K: xx = fx*x + 0*y + cx, ww = 1/(0*x + 0*y + 1) */
+        const double xx = fx * x + 0. * y + cx;
+        const double yy = 0. * x + fy * y + cy;
+        const double ww = 1. / (0. * x + 0. * y + 1.);
+        xy_out[2 * i] = (float)(xx * ww);
+        xy_out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
 /* Frame::ComputeStereoFromRGBD, Frame.cc:641-662 */
 void ora_compute_stereo_from_rgbd(int n, const float *kp_x, const float *kp_y, const float *kpun_x,
                                   const float *depth, size_t depth_stride_elems, float mbf, float *u_right,

@@ -57,6 +57,12 @@ class KeyFrameView(C.Structure):
                 ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("kp_angle", C.c_void_p)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("dist", C.c_float * 5),
+                ("mbf", C.c_float), ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float),
+                ("max_y", C.c_float)]
+
+
 class DeviceFrameView(C.Structure):
     _fields_ = [("cap", C.c_int32), ("n", C.c_void_p), ("kps", C.c_void_p), ("desc", C.c_void_p),
                 ("u_right", C.c_void_p), ("cell_start", C.c_void_p), ("cell_items", C.c_void_p),
@@ -94,7 +100,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
-    "orbgpu_frame_glue_batch_device", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps",
+    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
@@ -148,7 +154,8 @@ def lib():
         "orbgpu_match_bf_batch_device": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, sz, i32, f32, i32, vp, vp, vp],
         "orbgpu_matcher_last_sweeps": [vp, vp],
         "orbgpu_assign_features_to_grid": [i32, vp, vp, f32, f32, f32, f32, vp, vp],
-        "orbgpu_frame_glue_batch_device": [i32, i32, i32, vp, vp, vp, sz, sz, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
+        "orbgpu_frame_glue_batch_device": [i32, i32, i32, vp, vp, vp, sz, sz, vp, vp, vp, vp, vp, vp, vp],
+        "orbgpu_undistort_points": [i32, vp, vp, vp, i32],
         "orbgpu_search_local_points_device": [vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp],
         "orbgpu_projection_last_sweeps": [vp, vp],
         "orbgpu_search_by_projection": [vp, vp, f32, f32, vp, vp, i32],
@@ -307,12 +314,35 @@ def assign_features_to_grid(kp_x, kp_y, min_x, min_y, inv_w, inv_h):
     return cs, items[:cs[-1]].copy()
 
 
-def frame_glue_batch_device(batch, cap, d_kps, d_n, d_depth, depth_stride, depth_frame_stride, mbf, width, height,
+def make_camera(fx, fy, cx, cy, mbf, width, height, dist=(), device_id=0):
+    """orbgpu_camera with the image bounds of Frame::ComputeImageBounds (Frame.cc:436-468)."""
+    cam = Camera()
+    cam.fx, cam.fy, cam.cx, cam.cy, cam.mbf = fx, fy, cx, cy, mbf
+    for i in range(5):
+        cam.dist[i] = float(dist[i]) if i < len(dist) else 0.0
+    cam.min_x, cam.max_x, cam.min_y, cam.max_y = 0.0, float(width), 0.0, float(height)
+    if cam.dist[0] != 0.0:
+        c = undistort_points(np.array([[0, 0], [width, 0], [0, height], [width, height]], np.float32), cam, device_id)
+        cam.min_x, cam.max_x = min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0])
+        cam.min_y, cam.max_y = min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1])
+    return cam
+
+
+def undistort_points(xy, cam, device_id=0):
+    """cv::undistortPoints(xy, xy, mK, mDistCoef, Mat(), mK) (orbgpu_undistort_points)."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    check(lib().orbgpu_undistort_points(len(xy), _p(xy), C.byref(cam), _p(out), device_id))
+    return out
+
+
+def frame_glue_batch_device(batch, cap, d_kps, d_n, d_depth, depth_stride, depth_frame_stride, cam, d_kps_un,
                             d_u_right, d_kp_depth, d_cell_start, d_cell_items, stream=0, device_id=0):
-    """ComputeStereoFromRGBD + AssignFeaturesToGrid on the device (orbgpu_frame_glue_batch_device)."""
+    """UndistortKeyPoints + ComputeStereoFromRGBD + AssignFeaturesToGrid on the device
+    (orbgpu_frame_glue_batch_device). cam: Camera (make_camera)."""
     check(lib().orbgpu_frame_glue_batch_device(device_id, batch, cap, d_kps, d_n, d_depth, depth_stride,
-                                               depth_frame_stride, mbf, 0.0, float(width), 0.0, float(height),
-                                               d_u_right, d_kp_depth, d_cell_start, d_cell_items, stream))
+                                               depth_frame_stride, C.byref(cam), d_kps_un, d_u_right, d_kp_depth,
+                                               d_cell_start, d_cell_items, stream))
 
 
 def search_local_points_device(frame_view, table, Tcw, fx, fy, cx, cy, mbf, log_sf, th, nnratio, d_kp_to_mp, d_counts,

@@ -179,7 +179,8 @@ def test_frame_glue_on_device(gpu, oracle, stream640):
     cs = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device="cuda")
     items = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
     bf = float(stream640.bf)
-    gpu.frame_glue_batch_device(B, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), 640, 640 * 480, bf, 640, 480,
+    cam = gpu.make_camera(float(stream640.fx), float(stream640.fy), float(stream640.cx), float(stream640.cy), bf, 640, 480)
+    gpu.frame_glue_batch_device(B, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), 640, 640 * 480, cam, None,
                                 ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), st)
     torch.cuda.synchronize()
     n = nout.cpu().numpy()
@@ -243,7 +244,8 @@ def test_search_local_points_device_resident(gpu, oracle, th, obs_zero):
     dz = torch.zeros((1, cap), dtype=torch.float32, device="cuda")
     cs = torch.zeros((1, 64 * 48 + 1), dtype=torch.int32, device="cuda")
     items = torch.zeros((1, cap), dtype=torch.int32, device="cuda")
-    gpu.frame_glue_batch_device(1, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), w, w * h, float(st.bf), w, h,
+    cam = gpu.make_camera(float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), w, h)
+    gpu.frame_glue_batch_device(1, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), w, w * h, cam, None,
                                 ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s)
     dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in
            (("world_pos", wp), ("normal", mp["normal"]), ("min_dist", mp["min_dist"]), ("max_dist", mp["max_dist"]),
@@ -316,3 +318,58 @@ def test_search_by_projection_crowded_windows(gpu, oracle, th, expect_rewalk):
         assert no > 200
         assert ng == no and np.array_equal(kg, ko), "%d vs %d, %d differ" % (ng, no, int((kg != ko).sum()))
         assert sweeps >= 2 and (rewalked > 0) == expect_rewalk, (sweeps, rewalked)
+
+
+def test_frame_glue_with_distortion(gpu, oracle, stream640):
+    """Frame::UndistortKeyPoints + ComputeImageBounds + ComputeStereoFromRGBD + AssignFeaturesToGrid with the
+    TUM1 camera (Examples/RGB-D/TUM1.yaml: k1 k2 p1 p2 k3 all non-zero) against the oracle's cvUndistortPoints
+    restatement (unpinned like the other OpenCV pieces)."""
+    torch = pytest.importorskip("torch")
+    fx, fy, cx, cy = 517.306408, 516.469215, 318.643040, 255.313989
+    dist = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+    bf = 40.0
+    B = 3
+    fr = [stream640.frame(70 + i) for i in range(B)]
+    imgs = torch.from_numpy(np.stack([f[0] for f in fr])).cuda()
+    depth = torch.from_numpy(np.stack([f[2] for f in fr])).cuda()
+    ge = gpu.ORBextractor(1000, max_batch=B)
+    cap = ge.max_keypoints(640, 480)
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    kun = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ge.extract_batch_device(imgs.data_ptr(), B, 640, 480, 640, 640 * 480, kps.data_ptr(), desc.data_ptr(), cap,
+                            nout.data_ptr(), st)
+    cam = gpu.make_camera(fx, fy, cx, cy, bf, 640, 480, dist)
+    # ComputeImageBounds through the oracle
+    c = oracle.undistort_points(np.array([[0, 0], [640, 0], [0, 480], [640, 480]], np.float32), fx, fy, cx, cy, dist)
+    bounds = (min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0]), min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1]))
+    assert (cam.min_x, cam.max_x, cam.min_y, cam.max_y) == tuple(np.float32(b) for b in bounds)
+    assert abs(cam.min_x) > 5 and abs(cam.max_x - 640) > 5  # the bounds really moved
+    ur = torch.zeros((B, cap), dtype=torch.float32, device="cuda")
+    dz = torch.zeros((B, cap), dtype=torch.float32, device="cuda")
+    cs = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    items = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+    gpu.frame_glue_batch_device(B, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), 640, 640 * 480, cam,
+                                kun.data_ptr(), ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), st)
+    torch.cuda.synchronize()
+    n = nout.cpu().numpy()
+    k, ku = kps.cpu().numpy(), kun.cpu().numpy()
+    inv_w = np.float32(64) / (np.float32(bounds[1]) - np.float32(bounds[0]))
+    inv_h = np.float32(48) / (np.float32(bounds[3]) - np.float32(bounds[2]))
+    for f in range(B):
+        xy = k[f, :n[f], :2]
+        oun = oracle.undistort_points(xy, fx, fy, cx, cy, dist)
+        assert np.array_equal(ku[f, :n[f], :2], oun)
+        assert np.array_equal(ku[f, :n[f], 2:].view(np.uint32), k[f, :n[f], 2:].view(np.uint32))  # rest of the KeyPoint copied
+        assert np.abs(oun - xy).max() > 1.0  # the distortion is not a no-op
+        our, od = oracle.compute_stereo_from_rgbd(xy[:, 0], xy[:, 1], oun[:, 0], fr[f][2], bf)
+        assert np.array_equal(ur[f, :n[f]].cpu().numpy(), our) and np.array_equal(dz[f, :n[f]].cpu().numpy(), od)
+        ocs, oit = oracle.assign_grid(oun[:, 0], oun[:, 1], bounds[0], bounds[2], inv_w, inv_h)
+        assert np.array_equal(cs[f].cpu().numpy(), ocs)
+        assert np.array_equal(items[f, :ocs[-1]].cpu().numpy(), oit)
+    # the host entry point on arbitrary points (including far outside the image)
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-200, 900, (5000, 2)).astype(np.float32)
+    assert np.array_equal(gpu.undistort_points(pts, cam), oracle.undistort_points(pts, fx, fy, cx, cy, dist))

@@ -87,13 +87,14 @@ def c3():
     counts = torch.zeros(2, dtype=torch.int32, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
     log_sf = float(np.log(np.float32(sfa[1])))
+    cam = G.make_camera(float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), W, H)
 
     def chain(with_extract):
         if with_extract:
             g1.extract_batch_device(img.data_ptr(), 1, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), cap,
                                     nout.data_ptr(), s)
-            G.frame_glue_batch_device(1, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), W, W * H, float(st.bf),
-                                      W, H, ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s)
+            G.frame_glue_batch_device(1, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), W, W * H, cam, None,
+                                      ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s)
         k2m.fill_(-1)
         G.search_local_points_device(fv, tb, Tcw, float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf),
                                      log_sf, 3.0, 0.8, k2m.data_ptr(), counts.data_ptr(), None, stream=s)
