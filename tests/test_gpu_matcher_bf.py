@@ -131,3 +131,18 @@ def test_bf_batched_device_path(gpu, oracle, stream640):
         assert int(nm[p]) == no
         assert np.array_equal(mb[p, :n[p + 1]], mo)
         assert np.all(mb[p, n[p + 1]:] == -1)
+
+
+def test_bf_self_match_is_identity_at_full_size(gpu):
+    """Property at the largest supported row count (4096 x 4096, no oracle run needed): matching a descriptor set
+    against itself pairs every row with itself (distance 0 passes any ratio test against a non-zero second
+    distance); rows with an exact duplicate are the only ones allowed to differ."""
+    rng = np.random.default_rng(21)
+    n = 4096
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d[100] = d[7]  # one exact duplicate pair: the second distance is 0 for both, so neither may match
+    ang = rng.uniform(0, 360, n).astype(np.float32)
+    nm, mb = gpu.ORBmatcher(0.7, True).MatchBruteForce(d, ang, d, ang)
+    expect = np.arange(n)
+    expect[[7, 100]] = -1
+    assert np.array_equal(mb, expect) and nm == n - 2
