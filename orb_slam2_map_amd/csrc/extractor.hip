@@ -668,8 +668,12 @@ __device__ __forceinline__ int quadrant_of(uint32_t key, short4 b)
     return (x < b.x + halfx) ? ((y < b.y + halfy) ? 0 : 2) : ((y < b.y + halfy) ? 1 : 3);
 }
 
+// workgroup size of k_quadtree: a single frame is bound by the latency of its level-0 workgroup (more threads per
+// key loop help), a full batch by barrier cost and workgroups per CU (fewer threads help): 155 -> 122 us at B = 256
+constexpr int QT_THREADS = 512, QT_THREADS_BATCH = 256, QT_BATCH_MIN = 32;
+
 // In-place exclusive scan of an LDS int array by the whole workgroup; returns the total.
-__device__ int block_excl_scan(int *a, int n, int *s_tmp /*>= 8 ints*/)
+__device__ int block_excl_scan(int *a, int n, int *s_tmp /*>= 16 ints*/)
 {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
@@ -705,7 +709,7 @@ __device__ int block_excl_scan(int *a, int n, int *s_tmp /*>= 8 ints*/)
     return total;
 }
 
-__global__ __launch_bounds__(512) void k_quadtree(const LevelGeom *__restrict__ geom,
+__global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__restrict__ geom,
                                                   const CellDesc *__restrict__ cells, int ncells_total,
                                                   const uint32_t *__restrict__ slots, size_t frame_slots,
                                                   const int *__restrict__ cell_cnt,
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(512) void k_quadtree(const LevelGeom *__restrict__ 
                                                   int ncap)
 {
     extern __shared__ __align__(16) uint8_t smem[];
-    __shared__ int s_tmp[8];
+    __shared__ int s_tmp[16];
     __shared__ int s_n, s_phase, s_done, s_nexp, s_cut;
 
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -1780,7 +1784,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>());
     END(ST_FAST_NMS, st);
     BEGIN(ST_QUADTREE, st);
-    hipLaunchKernelGGL(k_quadtree, dim3(batch, nl), dim3(512), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
+    hipLaunchKernelGGL(k_quadtree, dim3(batch, nl), dim3(batch >= QT_BATCH_MIN ? QT_THREADS_BATCH : QT_THREADS), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
                        e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(), e->d_sel.as<uint32_t>(),
                        e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
