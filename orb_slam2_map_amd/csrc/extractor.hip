@@ -48,7 +48,10 @@ struct CellDesc {
     short addx, addy;      // j*wCell, i*hCell  (ORBextractor.cc:822-823)
     short cap;             // slot capacity
     int slot_off;          // offset of this cell's slots inside one frame's slot block
+    int pitch, plane_off;  // copies of the level's LevelGeom fields (k_fast_cells reads one record per cell)
+    int pad[1];
 };
+static_assert(sizeof(CellDesc) == 32, "CellDesc is read as two 16-byte words");
 
 struct XTab {  // cv::resize horizontal table entry (A2)
     uint16_t sx, sx1, a0, a1;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
 //  k_fast_nmsbits -- streaming strict 3x3 non-maximum suppression restricted to each 30-px cell's
 //     interior (cv::FAST sees only the sub-image: neighbours outside count as 0); emits survivor bits
 //     for minThFAST and iniThFAST.
-//  k_fast_cells   -- one wave per cell: chooses iniThFAST or (empty cell) minThFAST and writes the
+//  k_fast_cells   -- one half wave per cell: chooses iniThFAST or (empty cell) minThFAST and writes the
 //     survivors in row-major order (cv::FAST's output order, which the quadtree's "first maximum"
 //     rule depends on).
 // ---------------------------------------------------------------------------------------------
@@ -511,54 +514,58 @@ __global__ __launch_bounds__(256) void k_fast_nmsbits(const uint8_t *__restrict_
 #undef NB_LOAD
 }
 
-// k_fast_cells: one wave per (cell, frame), one lane per interior row.  A lane gathers its row's
-// survivor bits (<= 66 pixels) into two 64-bit masks, the wave decides iniThFAST vs minThFAST
-// (ORBextractor.cc:809-816: the fallback applies when the iniThFAST pass leaves the cell empty),
-// a wave prefix sum of the per-row counts gives every row its output offset, and each lane emits its
-// survivors left to right -- row-major order, cv::FAST's output order.
+// k_fast_cells: one HALF wave per (cell, frame), one lane per interior row (the usual 30-row cell fills 30 of the
+// 32 lanes; taller border cells take up to three row groups).  A lane gathers its row's survivor bits (<= 96
+// pixels) into two 64-bit masks, the half wave decides iniThFAST vs minThFAST (ORBextractor.cc:809-816: the
+// fallback applies when the iniThFAST pass leaves the cell empty), a prefix sum of the per-row counts gives every
+// row its output offset, every row lane drops (iy, ix) of its survivors into the half wave's LDS list (no memory
+// latency), and the list is emitted with one survivor per lane -- row-major order, cv::FAST's output order, with
+// all score reads of a cell in flight together.
+// survivors a cell can hold: strict 3x3 NMS keeps at most one pixel per 2x2 block of the <= 66 x 96 interior
+constexpr int FC_LIST = 33 * 48;
+constexpr int FC_GROUPS = 3;  // row groups of 32: cells are at most 66 rows tall
+
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ smap,
                                                     const uint8_t *__restrict__ bits, size_t frame_pyr,
-                                                    const LevelGeom *__restrict__ geom,
                                                     const CellDesc *__restrict__ cells, int ncells_total,
                                                     uint32_t *__restrict__ slots, size_t frame_slots,
                                                     int *__restrict__ cell_cnt)
 {
+    __shared__ uint16_t s_list[8][FC_LIST];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ci = blockIdx.x * 4 + wave;
+    const int hl = lane & 31, half = lane >> 5;
+    const int ci = (blockIdx.x * 4 + wave) * 2 + half;
     const int f = blockIdx.y;
-    if (ci >= ncells_total)
-        return;
-    const CellDesc cd = cells[ci];
-    const LevelGeom g = geom[cd.level];
-    const int iw = cd.x1 - cd.x0 - 6, ih = cd.y1 - cd.y0 - 6;
-    int *out_cnt = cell_cnt + (size_t)f * ncells_total + ci;
-    if (iw <= 0 || ih <= 0) {
-        if (lane == 0)
-            *out_cnt = 0;
-        return;
-    }
+    const bool have = ci < ncells_total;
+    const CellDesc cd = cells[have ? ci : 0];
+    const int iw = cd.x1 - cd.x0 - 6;
+    const int ih = (have && iw > 0) ? max(cd.y1 - cd.y0 - 6, 0) : 0;  // 0: nothing to do for this half
     const int xs = cd.x0 + 3 + EDGE, ys = cd.y0 + 3 + EDGE;  // padded coordinates of the interior origin
     const int s0 = xs >> 2, o0 = xs & 3;                     // first strip, pixel offset inside it
-    const size_t plane = (size_t)f * frame_pyr + g.plane_off;
+    const size_t plane = (size_t)f * frame_pyr + (size_t)cd.plane_off;
     const uint8_t *bplane = bits + (plane >> 2);
-    const int bpitch = g.pitch >> 2;
+    const int bpitch = cd.pitch >> 2;
     uint32_t *out = slots + (size_t)f * frame_slots + cd.slot_off;
+    uint16_t *list = s_list[wave * 2 + half];
+    // both halves run the same number of row groups (the shuffles below are per 32-lane segment)
+    const int my_groups = (ih + 31) >> 5;
+    const int ngroups = max(my_groups, __shfl_xor(my_groups, 32, 64));
 
-    // rows iy = lane (group 0) and iy = 64 + lane (group 1; cells are at most 66 rows tall).
     // A row's <= 18 strip bytes are fetched as 6 aligned dwords (24 strips from strip sa = s0 & ~3),
     // each dword's nibbles are compressed to 16 pixel bits, and the 96-bit strings are shifted so that
     // bit 0 = the row's first interior pixel.
-    unsigned long long mmin[2][2] = {{0ull, 0ull}, {0ull, 0ull}}, mini[2][2] = {{0ull, 0ull}, {0ull, 0ull}};
-    const unsigned long long keep0 = iw >= 64 ? ~0ull : (1ull << iw) - 1ull;
+    unsigned long long mmin[FC_GROUPS][2], mini[FC_GROUPS][2];
+    const unsigned long long keep0 = iw >= 64 ? ~0ull : (1ull << max(iw, 0)) - 1ull;
     const unsigned long long keep1 = iw <= 64 ? 0ull : (1ull << (iw - 64)) - 1ull;
     const int sa = s0 & ~3;
     const int shift = 4 * (s0 - sa) + o0;  // 0..15 pixel bits to drop at the front
     const int ndw = min(6, (bpitch - sa) >> 2);  // dwords available in the row from sa on
     int n_ini = 0;
 #pragma unroll
-    for (int grp = 0; grp < 2; grp++) {
-        const int iy = grp * 64 + lane;
-        if (iy < ih) {
+    for (int grp = 0; grp < FC_GROUPS; grp++) {
+        mmin[grp][0] = mmin[grp][1] = mini[grp][0] = mini[grp][1] = 0ull;
+        const int iy = grp * 32 + hl;
+        if (grp < ngroups && iy < ih) {
             const uint32_t *bp = reinterpret_cast<const uint32_t *>(bplane + (size_t)(ys + iy) * bpitch + sa);
             uint32_t lo16[6], hi16[6];
 #pragma unroll
@@ -590,49 +597,57 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             n_ini += __popcll(mini[grp][0]) + __popcll(mini[grp][1]);
         }
     }
-    n_ini = wave_reduce_add(n_ini);
-    n_ini = __shfl(n_ini, 0, 64);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+        n_ini += __shfl_xor(n_ini, off, 64);  // stays inside the 32-lane half
     const bool use_ini = n_ini > 0;
 
     int base = 0;
 #pragma unroll
-    for (int grp = 0; grp < 2; grp++) {
-        if (grp * 64 >= ih)
+    for (int grp = 0; grp < FC_GROUPS; grp++) {
+        if (grp >= ngroups)
             break;
-        const int iy = grp * 64 + lane;
+        const int iy = grp * 32 + hl;
         const unsigned long long m0 = use_ini ? mini[grp][0] : mmin[grp][0];
         const unsigned long long m1 = use_ini ? mini[grp][1] : mmin[grp][1];
         const int c = __popcll(m0) + __popcll(m1);
         int inc = c;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(inc, off, 64);
-            if (lane >= off)
+        for (int off = 1; off < 32; off <<= 1) {
+            const int t = __shfl_up(inc, off, 32);
+            if (hl >= off)
                 inc += t;
         }
         int pos = base + inc - c;
-        base += __shfl(inc, 63, 64);
-        if (c > 0) {
-            const uint8_t *srow = smap + plane + (size_t)(ys + iy) * g.pitch + xs;
-            unsigned long long m = m0;
-            int xb = 0;
+        base += __shfl(inc, 31, 32);
+        unsigned long long m = m0;
+        int xb = 0;
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                while (m) {
-                    const int ix = xb + __ffsll((long long)m) - 1;
-                    m &= m - 1ull;
-                    const int sc = srow[ix];
-                    if (pos < cd.cap)
-                        out[pos] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, sc - 1);
-                    pos++;
-                }
-                m = m1;
-                xb = 64;
+        for (int hw = 0; hw < 2; hw++) {
+            while (m) {
+                const int ix = xb + __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                if (pos < FC_LIST)
+                    list[pos] = (uint16_t)((iy << 8) | ix);  // iy < 128, ix < 96
+                pos++;
             }
+            m = m1;
+            xb = 64;
         }
     }
-    if (lane == 0)
-        *out_cnt = base;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nemit = min(base, min((int)cd.cap, FC_LIST));
+    const uint8_t *sorg = smap + plane + (size_t)ys * cd.pitch + xs;
+    for (int k = hl; k < nemit; k += 32) {
+        const int e = list[k];
+        const int iy = e >> 8, ix = e & 255;
+        const int sc = sorg[(size_t)iy * cd.pitch + ix];
+        out[k] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, sc - 1);
+    }
+    if (have && hl == 0)
+        cell_cnt[(size_t)f * ncells_total + ci] = base;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1516,6 +1531,9 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
                 // strict 3x3 NMS: no two survivors are 8-neighbours
                 c.cap = (short)(((iw + 1) / 2) * ((ih + 1) / 2));
                 c.slot_off = slot_off;
+                c.pitch = g.pitch;
+                c.plane_off = g.plane_off;
+                c.pad[0] = 0;
                 slot_off += c.cap;
                 cells.push_back(c);
             }
@@ -1779,8 +1797,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     hipLaunchKernelGGL(k_fast_nmsbits, dim3((e->nms_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st,
                        e->d_smap.as<uint8_t>(), e->d_bits.as<uint8_t>(), e->frame_pyr, dg, e->nms_geom,
                        e->d_colmask.as<uint4>(), e->d_rowflag.as<uint8_t>(), e->prm.ini_th_fast, e->prm.min_th_fast);
-    hipLaunchKernelGGL(k_fast_cells, dim3(((unsigned)e->cells.size() + 3) / 4, batch), dim3(256), 0, st,
-                       e->d_smap.as<uint8_t>(), e->d_bits.as<uint8_t>(), e->frame_pyr, dg, e->d_cells.as<CellDesc>(),
+    hipLaunchKernelGGL(k_fast_cells, dim3(((unsigned)e->cells.size() + 7) / 8, batch), dim3(256), 0, st,
+                       e->d_smap.as<uint8_t>(), e->d_bits.as<uint8_t>(), e->frame_pyr, e->d_cells.as<CellDesc>(),
                        (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>());
     END(ST_FAST_NMS, st);
     BEGIN(ST_QUADTREE, st);
