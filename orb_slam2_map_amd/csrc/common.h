@@ -36,6 +36,24 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // Simple owning device buffer (grow-only).
+// XCD-aware block placement for (items, frames) grids.  Workgroups are dealt round-robin over the 8 XCDs (each
+// with a private 4 MiB L2), so in launch order the blocks of ONE frame land on all eight L2s and every L2 fetches
+// that frame's rows from HBM.  The remap gives the blocks that share an XCD (linear id % 8) a contiguous range of
+// the frame-major virtual order, i.e. whole frames, so the halo rows / overlapping patches that neighbouring
+// blocks of a frame read are L2 hits.  Bijective for any grid size (cdna_hip_programming.md, "XCD swizzle must be
+// bijective"); placement is a speed matter only -- results never depend on it.
+#ifdef __HIPCC__
+__device__ __forceinline__ void xcd_frame_block(int &bx, int &frame)
+{
+    const unsigned gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const unsigned orig = blockIdx.x + gx * blockIdx.y;
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+    const unsigned v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    frame = (int)(v / gx);
+    bx = (int)(v - (unsigned)frame * gx);
+}
+#endif
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;

@@ -94,10 +94,11 @@ __global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src
     // work item = (group of PYR_ROWS padded rows, aligned dword of the row), flattened so that every lane
     // of a workgroup has work whatever the row length
     const int ndw = g.pitch >> 2;
-    const int item = blockIdx.x * 256 + threadIdx.x;
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int item = bx * 256 + threadIdx.x;
     const int rg = item / ndw;
     const int x4 = (item - rg * ndw) * 4;
-    const int f = blockIdx.y;
     if (rg * PYR_ROWS >= g.h + 2 * EDGE)
         return;
     const int sx0 = x4 - EDGE;  // source column of the first of the 4 output pixels
@@ -183,10 +184,11 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     const LevelGeom g = geom[level];
     const LevelGeom gs = geom[level - 1];
     const int ndw = g.pitch >> 2;
-    const int item = blockIdx.x * 256 + threadIdx.x;  // (row group, output dword column), flattened
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int item = bx * 256 + threadIdx.x;  // (row group, output dword column), flattened
     const int rg = item / ndw;
     const int sdw = item - rg * ndw;
-    const int f = blockIdx.y;
     if (rg * PYR_ROWS >= g.h + 2 * EDGE)
         return;
     const uint32_t bq = strips[strip_off + sdw].base_q;
@@ -360,8 +362,9 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
                                                     size_t frame_pyr, const LevelGeom *__restrict__ geom,
                                                     StripGeom sg)
 {
-    const int strip = blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.y;
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int strip = bx * 256 + threadIdx.x;
     if (strip >= sg.first[sg.nlevels])
         return;
     int level = 0;
@@ -469,8 +472,9 @@ __global__ __launch_bounds__(256) void k_fast_nmsbits(const uint8_t *__restrict_
                                                       StripGeom sg, const uint4 *__restrict__ colmask,
                                                       const uint8_t *__restrict__ rowflag, int ini_th, int min_th)
 {
-    const int strip = blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.y;
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int strip = bx * 256 + threadIdx.x;
     if (strip >= sg.first[sg.nlevels])
         return;
     int level = 0;
@@ -534,8 +538,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     __shared__ uint16_t s_list[8][FC_LIST];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hl = lane & 31, half = lane >> 5;
-    const int ci = (blockIdx.x * 4 + wave) * 2 + half;
-    const int f = blockIdx.y;
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int ci = (bx * 4 + wave) * 2 + half;
     const bool have = ci < ncells_total;
     const CellDesc cd = cells[have ? ci : 0];
     const int iw = cd.x1 - cd.x0 - 6;
@@ -1075,6 +1080,8 @@ struct UMax {
 // byte-weight tables built once per workgroup in LDS: W10 holds (u+16) inside the disc (0 outside),
 // M01 holds 1 inside the disc, so  sum u*I = dot(W10) - 16*dot(M01)  and  sum I = dot(M01).
 // Integer moments: exact in any summation order.
+constexpr int OR_ITERS = 4;
+
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                 const LevelGeom *__restrict__ geom, int nlevels,
                                                 const uint32_t *__restrict__ sel, int sel_cap_total,
@@ -1101,9 +1108,12 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     __syncthreads();
 
     const int hl = threadIdx.x & 31;  // lane inside the half wave = disc row index
-    const int slot = blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int f = blockIdx.y;
+    int bx, f;
+    xcd_frame_block(bx, f);
     const int *ns = nsel + (size_t)f * nlevels;
+    // OR_ITERS slots per half wave: the weight tables above are built once per 8 * OR_ITERS key points
+    for (int it = 0; it < OR_ITERS; it++) {
+    const int slot = (bx * OR_ITERS + it) * 8 + (threadIdx.x >> 5);
     // locate (level, j) of this slot and the output offset
     int level = -1, j = 0, out_off = 0, total = 0;
     bool bad = false;
@@ -1122,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     if (slot == 0 && hl == 0)
         n_out[f] = bad ? -1 - total : (total > cap ? -1 - total : total);
     if (level < 0 || bad || total > cap || j >= ns[level])
-        return;
+        continue;
     const LevelGeom g = geom[level];
     const uint32_t key = sel[(size_t)f * sel_cap_total + g.sel_off + j];
     const int x = key_x(key) + BORDER0, y = key_y(key) + BORDER0;
@@ -1172,8 +1182,8 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         ax.angle = angle;
         aux[(size_t)f * cap + out_off + j] = ax;
     }
+    }
 }
-
 // computeOrbDescriptor's  a = (float)cos(angle), b = (float)sin(angle)  (ORBextractor.cc:112-113): the
 // float angle in radians is promoted to double for libm's cos/sin and the result rounded to float.
 // One thread per key point so the double-precision evaluation is amortised over 64 key points per wave.
@@ -1237,8 +1247,9 @@ __device__ __forceinline__ uint32_t blur_vsum(const uint32_t r0[4], const uint32
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               size_t frame_pyr, const LevelGeom *__restrict__ geom, StripGeom bg)
 {
-    const int strip = blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.y;
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int strip = bx * 256 + threadIdx.x;
     if (strip >= bg.first[bg.nlevels])
         return;
     int level = 0;
@@ -1313,10 +1324,11 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     // (10 consecutive dwords per row); the 512 rotated samples are then LDS byte reads instead of 512
     // scattered global byte loads
     __shared__ __align__(16) uint8_t patch[8][DP_BYTES];
-    const int f = blockIdx.y;
+    int bx, f;
+    xcd_frame_block(bx, f);
     const int n = n_out[f];
     const int slot = threadIdx.x >> 5;
-    const int kpi = blockIdx.x * 8 + slot;
+    const int kpi = bx * 8 + slot;
     if (kpi >= n)
         return;  // whole half-wave leaves together; the other half of the wave is independent
     const int byte = threadIdx.x & 31;
@@ -1808,7 +1820,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
     END(ST_QUADTREE, st);
     BEGIN(ST_ORIENT, st);
-    hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 7) / 8, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
+    hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 8 * OR_ITERS - 1) / (8 * OR_ITERS), batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out);
     hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
