@@ -152,6 +152,14 @@ int orbgpu_extractor_stage_times(orbgpu_extractor *h, float *ms_out);
  * out[i] = Hamming(a[i], b[i]) over 256 bits. Host pointers. */
 int orbgpu_hamming256(const uint8_t *a, const uint8_t *b, int32_t n, int32_t *out, int32_t device_id);
 
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242-307), batched over `groups` map points: group g owns the
+ * descriptors [offsets[g], offsets[g+1]) of desc (the rows of its non-bad observing key frames, in the iteration
+ * order of mObservations).  best_idx[g] = index INSIDE the group of the descriptor with the least median Hamming
+ * distance to the group (median = sorted row [(size_t)(0.5*(N-1))], first minimum), -1 for an empty group (the
+ * reference leaves mDescriptor untouched).  Host pointers; at most 2048 descriptors per group. */
+int orbgpu_distinctive_descriptors(int32_t groups, const int32_t *offsets, const uint8_t *desc, int32_t *best_idx,
+                                   int32_t device_id);
+
 /* Brute-force 256-bit Hamming matcher with the acceptance rule, greedy claim order and rotation
  * consistency of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:159-288) when all
  * features share one vocabulary node (the reference has no other brute-force matcher).

@@ -371,6 +371,14 @@ def is_in_frustum(Tcw, fx, fy, cx, cy, mbf, width, height, P, normal, min_dist, 
     return bool(ok), px.value, py.value, pxr.value, lvl.value, vc.value
 
 
+def distinctive_descriptor(desc):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    L = lib()
+    L.ora_distinctive_descriptor.argtypes = [C.c_int, C.c_void_p]
+    L.ora_distinctive_descriptor.restype = C.c_int
+    return int(L.ora_distinctive_descriptor(len(desc), _p(desc)))
+
+
 def undistort_points(xy, fx, fy, cx, cy, dist):
     xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
     d = np.zeros(5, np.float32)

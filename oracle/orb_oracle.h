@@ -194,6 +194,9 @@ int ora_search_by_projection_keyframe(const ora_frame_view *cur, const float *cu
                                       float cy, float log_scale_factor, const ora_keyframe_view *kf, float th,
                                       int orb_dist, int check_orientation, int32_t *kp_to_mp);
 
+/* ---- MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:242-307 ---- */
+int ora_distinctive_descriptor(int n, const uint8_t *desc);
+
 /* ---- M8: Frame::isInFrustum, Frame.cc:269-325 (+ MapPoint::PredictScale, MapPoint.cc:385-394) ---- */
 int ora_is_in_frustum(const float *Tcw, float fx, float fy, float cx, float cy, float mbf, float min_x,
                       float max_x, float min_y, float max_y, const float *P, const float *normal, float min_dist,

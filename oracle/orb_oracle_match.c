@@ -482,6 +482,29 @@ done:
     return nmatches;
 }
 
+/* MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:242-307: index of the descriptor with the least median
+ * distance to the set (float Distances[N][N], rows copied to int, std::sort, [0.5*(N-1)], first minimum). */
+static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }
+int ora_distinctive_descriptor(int n, const uint8_t *desc)
+{
+    if (n <= 0)
+        return -1;
+    int *row = (int *)malloc(sizeof(int) * (size_t)n);
+    int best_median = INT32_MAX, best_idx = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++)
+            row[j] = i == j ? 0 : ora_descriptor_distance(desc + (size_t)i * 32, desc + (size_t)j * 32);
+        qsort(row, (size_t)n, sizeof(int), cmp_int);
+        const int median = row[(size_t)(0.5 * (n - 1))];
+        if (median < best_median) {
+            best_median = median;
+            best_idx = i;
+        }
+    }
+    free(row);
+    return best_idx;
+}
+
 /* ------------------------------------------------------------------ M8 */
 /* Frame::isInFrustum, Frame.cc:269-325; MapPoint::PredictScale, MapPoint.cc:385-394 */
 int ora_is_in_frustum(const float *Tcw, float fx, float fy, float cx, float cy, float mbf, float min_x,

@@ -389,6 +389,58 @@ __global__ void k_hamming_pairs(const uint8_t *__restrict__ a, const uint8_t *__
     out[i] = hamming256(x, y);
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:242-307): among the n descriptors observing a
+// map point pick the one whose MEDIAN Hamming distance to all of them (itself included, distance 0) is least;
+// median = sorted row [ (size_t)(0.5 * (n - 1)) ], the first minimum wins.  One workgroup per map point, its
+// descriptors in LDS; a thread owns rows i = tid, tid + 256, ... and finds the row's k-th smallest distance by
+// bisection on the value range [0, 256] (9 counting passes over the row) instead of sorting it.
+constexpr int DD_MAX = 2048;  // descriptors per map point (64 KB of LDS)
+
+__global__ __launch_bounds__(256) void k_distinctive(const int *__restrict__ offsets,
+                                                     const uint8_t *__restrict__ desc, int *__restrict__ best_idx)
+{
+    extern __shared__ __align__(16) uint8_t smem[];
+    __shared__ unsigned long long s_best;
+    uint64_t *sd = reinterpret_cast<uint64_t *>(smem);
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int beg = offsets[g], n = offsets[g + 1] - beg;
+    if (n <= 0) {
+        if (tid == 0)
+            best_idx[g] = -1;  // the reference returns without touching mDescriptor
+        return;
+    }
+    const uint64_t *gd = reinterpret_cast<const uint64_t *>(desc) + (size_t)beg * 4;
+    for (int x = tid; x < n * 4; x += 256)
+        sd[x] = gd[x];
+    if (tid == 0)
+        s_best = ~0ull;
+    __syncthreads();
+    const int k = (n - 1) >> 1;  // (size_t)(0.5 * (n - 1))
+    unsigned long long mine = ~0ull;
+    for (int i = tid; i < n; i += 256) {
+        const uint64_t a[4] = {sd[i * 4], sd[i * 4 + 1], sd[i * 4 + 2], sd[i * 4 + 3]};
+        int lo = 0, hi = 256;  // smallest v with #{j : d_ij <= v} >= k + 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < n; j++) {
+                const uint64_t b[4] = {sd[j * 4], sd[j * 4 + 1], sd[j * 4 + 2], sd[j * 4 + 3]};
+                cnt += hamming256(a, b) <= mid ? 1 : 0;
+            }
+            if (cnt >= k + 1)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const unsigned long long key = ((unsigned long long)lo << 32) | (unsigned)i;  // least median, then least index
+        mine = key < mine ? key : mine;
+    }
+    atomicMin(&s_best, mine);
+    __syncthreads();
+    if (tid == 0)
+        best_idx[g] = (int)(s_best & 0xFFFFFFFFull);
+}
+
 } // namespace orbgpu
 
 using namespace orbgpu;
@@ -595,6 +647,41 @@ int orbgpu_hamming256(const uint8_t *a, const uint8_t *b, int32_t n, int32_t *ou
         set_error("hamming256: %s", hipGetErrorString(e));
         return ORBGPU_EHIP;
     }
+    return ORBGPU_OK;
+}
+
+int orbgpu_distinctive_descriptors(int32_t groups, const int32_t *offsets, const uint8_t *desc, int32_t *best_idx,
+                                   int32_t device_id)
+{
+    ORBGPU_REQUIRE(groups >= 0 && (groups == 0 || (offsets && best_idx)), "bad arguments");
+    int rc = select_device(device_id);
+    if (rc != ORBGPU_OK || groups == 0)
+        return rc;
+    int max_n = 0;
+    ORBGPU_REQUIRE(offsets[0] == 0, "offsets[0] must be 0");
+    for (int g = 0; g < groups; g++) {
+        const int n = offsets[g + 1] - offsets[g];
+        ORBGPU_REQUIRE(n >= 0 && n <= DD_MAX, "group %d has %d descriptors (limit %d)", g, n, DD_MAX);
+        max_n = std::max(max_n, n);
+    }
+    const size_t total = (size_t)offsets[groups];
+    ORBGPU_REQUIRE(total == 0 || desc, "null descriptors");
+    struct Scoped : DevBuf {
+        ~Scoped() { release(); }
+    } d_off, d_desc, d_out;
+    if ((rc = d_off.reserve(sizeof(int) * ((size_t)groups + 1))) != ORBGPU_OK ||
+        (rc = d_desc.reserve(std::max<size_t>(total * 32, 32))) != ORBGPU_OK ||
+        (rc = d_out.reserve(sizeof(int) * (size_t)groups)) != ORBGPU_OK)
+        return rc;
+    ORBGPU_HIP_TRY(hipMemcpy(d_off.p, offsets, sizeof(int) * ((size_t)groups + 1), hipMemcpyHostToDevice));
+    if (total)
+        ORBGPU_HIP_TRY(hipMemcpy(d_desc.p, desc, total * 32, hipMemcpyHostToDevice));
+    ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_distinctive),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DD_MAX * 32));
+    hipLaunchKernelGGL(k_distinctive, dim3(groups), dim3(256), (size_t)std::max(max_n, 1) * 32, nullptr, d_off.as<int>(),
+                       d_desc.as<uint8_t>(), d_out.as<int>());
+    ORBGPU_HIP_TRY(hipGetLastError());
+    ORBGPU_HIP_TRY(hipMemcpy(best_idx, d_out.p, sizeof(int) * (size_t)groups, hipMemcpyDeviceToHost));
     return ORBGPU_OK;
 }
 

@@ -100,7 +100,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
-    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps",
+    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
@@ -158,6 +158,7 @@ def lib():
         "orbgpu_undistort_points": [i32, vp, vp, vp, i32],
         "orbgpu_search_local_points_device": [vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp],
         "orbgpu_projection_last_sweeps": [vp, vp],
+        "orbgpu_distinctive_descriptors": [i32, vp, vp, vp, i32],
         "orbgpu_search_by_projection": [vp, vp, f32, f32, vp, vp, i32],
         "orbgpu_search_by_projection_last": [vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
         "orbgpu_search_by_projection_keyframe": [vp, vp, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
@@ -353,6 +354,18 @@ def search_local_points_device(frame_view, table, Tcw, fx, fy, cx, cy, mbf, log_
     check(lib().orbgpu_search_local_points_device(C.byref(frame_view), C.byref(table), _p(T), fx, fy, cx, cy, mbf, log_sf,
                                                   cos_limit, th, nnratio, d_kp_to_mp, d_counts,
                                                   C.byref(track) if track is not None else None, device_id, stream))
+
+
+def distinctive_descriptors(groups, device_id=0):
+    """MapPoint::ComputeDistinctiveDescriptors for a list of (n_i, 32) descriptor arrays -> best index per group."""
+    off = np.zeros(len(groups) + 1, np.int32)
+    for i, g in enumerate(groups):
+        off[i + 1] = off[i] + len(g)
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(g, np.uint8).reshape(-1, 32) for g in groups])
+                                if len(groups) else np.zeros((0, 32), np.uint8))
+    out = np.zeros(max(1, len(groups)), np.int32)
+    check(lib().orbgpu_distinctive_descriptors(len(groups), _p(off), _p(flat) if len(flat) else None, _p(out), device_id))
+    return out[:len(groups)]
 
 
 def projection_last_sweeps():

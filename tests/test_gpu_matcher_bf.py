@@ -146,3 +146,29 @@ def test_bf_self_match_is_identity_at_full_size(gpu):
     expect = np.arange(n)
     expect[[7, 100]] = -1
     assert np.array_equal(mb, expect) and nm == n - 2
+
+
+def test_distinctive_descriptors(gpu, oracle):
+    """MapPoint::ComputeDistinctiveDescriptors batched over map points: group sizes 0, 1, 2 (even: lower median),
+    odd / even sizes, many ties (duplicated descriptors), one group beyond a workgroup's 256 rows."""
+    rng = np.random.default_rng(8)
+    groups = []
+    for n in (0, 1, 2, 3, 4, 7, 16, 33, 64, 100, 257, 600):
+        base = rng.integers(0, 256, (1, 32), dtype=np.uint8)
+        d = np.repeat(base, n, 0)
+        if n:
+            flips = rng.integers(0, 256, (n, 40))
+            nflip = rng.integers(0, 40, n)
+            for i in range(n):
+                for b in flips[i, :nflip[i]]:
+                    d[i, b // 8] ^= np.uint8(1 << (b % 8))
+        groups.append(d)
+    dup = groups[6].copy()
+    dup[5] = dup[2]
+    dup[9] = dup[2]      # exact duplicates: equal medians, the first index must win
+    groups.append(dup)
+    got = gpu.distinctive_descriptors(groups)
+    want = [oracle.distinctive_descriptor(g) for g in groups]
+    assert list(got) == want, (list(got), want)
+    assert got[0] == -1 and got[1] == 0
+    assert len(gpu.distinctive_descriptors([])) == 0

@@ -369,3 +369,15 @@ def test_undistort_points_inverts_the_brown_model(oracle):
     assert np.abs(back - pts).max() < 0.05  # five iterations: a few hundredths of a pixel in the image centre region
     same = oracle.undistort_points(pts, fx, fy, cx, cy, np.zeros(5))
     assert np.abs(same - pts).max() < 1e-4
+
+
+def test_distinctive_descriptor_vs_numpy(oracle):
+    """Least median distance (MapPoint.cc:289-301): sorted row [floor((N-1)/2)], first minimum."""
+    rng = np.random.default_rng(12)
+    for n in (1, 2, 5, 8, 31):
+        d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        bits = np.unpackbits(d, axis=1).astype(np.int32)
+        dist = (bits[:, None, :] != bits[None, :, :]).sum(2)
+        med = np.sort(dist, axis=1)[:, (n - 1) // 2]
+        assert oracle.distinctive_descriptor(d) == int(np.argmin(med))
+    assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == -1
