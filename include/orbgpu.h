@@ -284,6 +284,26 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
                                       int32_t *d_kp_to_mp, int32_t *d_counts, const orbgpu_track_scratch *d_track,
                                       int32_t device_id, void *hip_stream);
 
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
+ * vector<MapPoint*>& vpMatched, int th) (ORBmatcher.cc:290-403; loop closing, LoopClosing.cc:397).
+ * kf: the key frame as a frame view (mvKeysUn, mDescriptors, mGrid; u_right is not read).  Scw: HOST 4x4 row-major
+ * float Sim3 [sR | st].  pts: the candidate points.  kp_to_mp [kf->n] in/out = vpMatched: -1 NULL, -2 a map point
+ * outside pts, >= 0 row of pts (those rows form spAlreadyFound and are skipped); every accepted point (best
+ * distance <= TH_LOW among the free key points of levels [l-1, l] in the window) is written there.
+ * ORBGPU_ELEVEL if a predicted level falls outside [0, nlevels). */
+typedef struct orbgpu_points_view {
+    int32_t m;
+    const uint8_t *bad;      /* [m] isBad(), may be NULL */
+    const float *world_pos;  /* [m][3] GetWorldPos() */
+    const float *normal;     /* [m][3] GetNormal() */
+    const float *min_dist;   /* [m] mfMinDistance */
+    const float *max_dist;   /* [m] mfMaxDistance */
+    const uint8_t *desc;     /* [m][32] GetDescriptor() */
+} orbgpu_points_view;
+int orbgpu_search_by_projection_sim3(const orbgpu_frame_view *kf, const float *Scw, float fx, float fy, float cx,
+                                     float cy, float log_scale_factor, const orbgpu_points_view *pts, int32_t th,
+                                     int32_t *kp_to_mp, int32_t *nmatches, int32_t device_id);
+
 /* Convergence diagnostics of the calling thread's most recent projection match (orbgpu_search_by_projection*,
  * orbgpu_search_local_points_device): claim sweeps run and rows that had to be re-walked with the claim filter.
  * Synchronises the device. */

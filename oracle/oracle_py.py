@@ -359,6 +359,30 @@ def search_by_projection_keyframe(cur, cur_Tcw, fx, fy, cx, cy, log_sf, kf, th, 
     return n, out
 
 
+class _PointsView(C.Structure):
+    _fields_ = [("m", C.c_int32), ("bad", C.c_void_p), ("world_pos", C.c_void_p), ("normal", C.c_void_p),
+                ("min_dist", C.c_void_p), ("max_dist", C.c_void_p), ("desc", C.c_void_p)]
+
+
+def search_by_projection_sim3(kf_frame, Scw, fx, fy, cx, cy, log_sf, pts, th, kp_to_mp):
+    keep = {k: np.ascontiguousarray(pts[k], dt) for k, dt in
+            (("bad", np.uint8), ("world_pos", np.float32), ("normal", np.float32), ("min_dist", np.float32),
+             ("max_dist", np.float32), ("desc", np.uint8))}
+    v = _PointsView()
+    v.m = len(keep["bad"])
+    for k in keep:
+        setattr(v, k, _p(keep[k]))
+    fv = kf_frame.view()
+    S = np.ascontiguousarray(Scw, np.float32)
+    out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
+    L = lib()
+    L.ora_search_by_projection_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    L.ora_search_by_projection_sim3.restype = C.c_int
+    n = L.ora_search_by_projection_sim3(C.byref(fv), _p(S), fx, fy, cx, cy, log_sf, C.byref(v), int(th), _p(out))
+    return n, out
+
+
 def is_in_frustum(Tcw, fx, fy, cx, cy, mbf, width, height, P, normal, min_dist, max_dist, log_sf, cos_limit=0.5):
     T = np.ascontiguousarray(Tcw, np.float32)
     P = np.ascontiguousarray(P, np.float32)

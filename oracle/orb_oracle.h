@@ -194,6 +194,20 @@ int ora_search_by_projection_keyframe(const ora_frame_view *cur, const float *cu
                                       float cy, float log_scale_factor, const ora_keyframe_view *kf, float th,
                                       int orb_dist, int check_orientation, int32_t *kp_to_mp);
 
+/* ---- M5b: ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th), ORBmatcher.cc:290-403 ---- */
+typedef struct {
+    int32_t m;
+    const uint8_t *bad;      /* isBad() */
+    const float *world_pos;  /* m x 3 */
+    const float *normal;     /* m x 3 */
+    const float *min_dist;   /* mfMinDistance */
+    const float *max_dist;   /* mfMaxDistance */
+    const uint8_t *desc;     /* m x 32 */
+} ora_points_view;
+void ora_sim3_decompose(const float *Scw, float *T34, float *Ow);
+int ora_search_by_projection_sim3(const ora_frame_view *kf, const float *Scw, float fx, float fy, float cx, float cy,
+                                  float log_scale_factor, const ora_points_view *pts, int th, int32_t *kp_to_mp);
+
 /* ---- MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:242-307 ---- */
 int ora_distinctive_descriptor(int n, const uint8_t *desc);
 

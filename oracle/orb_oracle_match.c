@@ -482,6 +482,98 @@ done:
     return nmatches;
 }
 
+/* ------------------------------------------------------------------ M5b */
+/* Sim3 decomposition of ORBmatcher.cc:299-303: scw = sqrt(row0 . row0) (Mat::dot: double), Rcw = sRcw / scw and
+ * tcw = t / scw (cv::Mat / scalar = convertTo with alpha = 1/scw, applied in float for CV_32F), Ow = -Rcw^t tcw.
+ * T34 receives [Rcw | tcw] rows. */
+void ora_sim3_decompose(const float *Scw, float *T34, float *Ow)
+{
+    const double d = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+    const float scw = (float)sqrt(d);
+    const float alpha = (float)(1.0 / (double)scw);
+    float T[16];
+    memset(T, 0, sizeof(T));
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) {
+            volatile float v = Scw[4 * r + c] * alpha;
+            T[4 * r + c] = v;
+            T34[4 * r + c] = v;
+        }
+    minus_rt_t(T, Ow);
+}
+
+/* ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th), :290-403 (loop closing).
+ * kp_to_mp in: vpMatched as -1 (NULL), -2 (a map point outside `pts`) or the row of `pts`; out: rows written
+ * by this search.  Returns nmatches, -1 on a predicted level outside [0, nlevels). */
+int ora_search_by_projection_sim3(const ora_frame_view *kf, const float *Scw, float fx, float fy, float cx, float cy,
+                                  float log_scale_factor, const ora_points_view *pts, int th, int32_t *kp_to_mp)
+{
+    float T[16], Ow[3];
+    memset(T, 0, sizeof(T));
+    ora_sim3_decompose(Scw, T, Ow);
+    int nmatches = 0;
+    int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(kf->n > 0 ? kf->n : 1));
+    uint8_t *found = (uint8_t *)calloc((size_t)(pts->m > 0 ? pts->m : 1), 1); /* spAlreadyFound */
+    for (int j = 0; j < kf->n; j++)
+        if (kp_to_mp[j] >= 0 && kp_to_mp[j] < pts->m)
+            found[kp_to_mp[j]] = 1;
+    for (int i = 0; i < pts->m; i++) {
+        if ((pts->bad && pts->bad[i]) || found[i])
+            continue;
+        const float *Pw = pts->world_pos + 3 * (size_t)i;
+        float pc[3];
+        rt_apply(T, Pw, pc);
+        if (pc[2] < 0.0f)
+            continue;
+        const float invz = 1 / pc[2];
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y)) /* KeyFrame::IsInImage */
+            continue;
+        const float maxDistance = 1.2f * pts->max_dist[i], minDistance = 0.8f * pts->min_dist[i];
+        const float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
+        const float dist = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        if (dist < minDistance || dist > maxDistance)
+            continue;
+        const float *Pn = pts->normal + 3 * (size_t)i;
+        const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+        if (dot < 0.5 * dist)
+            continue;
+        const float ratio = pts->max_dist[i] / dist;
+        const int lvl = (int)ceilf(logf(ratio) / log_scale_factor);
+        if (lvl < 0 || lvl >= kf->nlevels) {
+            nmatches = -1;
+            goto done;
+        }
+        const float radius = th * kf->scale_factors[lvl];
+        const int nc = ora_get_features_in_area(kf, u, v, radius, -1, -1, vIndices);
+        if (nc == 0)
+            continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = vIndices[c];
+            if (kp_to_mp[idx] != -1)
+                continue; /* vpMatched[idx] */
+            const int kpLevel = kf->kp_octave[idx];
+            if (kpLevel < lvl - 1 || kpLevel > lvl)
+                continue;
+            const int dd = ora_descriptor_distance(pts->desc + (size_t)i * 32, kf->desc + (size_t)idx * 32);
+            if (dd < bestDist) {
+                bestDist = dd;
+                bestIdx = idx;
+            }
+        }
+        if (bestDist <= ORA_TH_LOW) {
+            kp_to_mp[bestIdx] = i;
+            nmatches++;
+        }
+    }
+done:
+    free(vIndices);
+    free(found);
+    return nmatches;
+}
+
 /* MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:242-307: index of the descriptor with the least median
  * distance to the set (float Distances[N][N], rows copied to int, std::sort, [0.5*(N-1)], first minimum). */
 static int cmp_int(const void *a, const void *b) { return (*(const int *)a > *(const int *)b) - (*(const int *)a < *(const int *)b); }

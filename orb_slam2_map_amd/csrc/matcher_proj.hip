@@ -1168,4 +1168,95 @@ int orbgpu_search_by_projection_keyframe(const orbgpu_frame_view *cur, const flo
                              kp_to_mp, nmatches);
 }
 
+int orbgpu_search_by_projection_sim3(const orbgpu_frame_view *kf, const float *Scw, float fx, float fy, float cx,
+                                     float cy, float log_scale_factor, const orbgpu_points_view *pts, int32_t th,
+                                     int32_t *kp_to_mp, int32_t *nmatches, int32_t device_id)
+{
+    ORBGPU_REQUIRE(pts && Scw && kp_to_mp && nmatches, "null argument");
+    int rc = validate_frame(kf);
+    if (rc != ORBGPU_OK)
+        return rc;
+    ORBGPU_REQUIRE(pts->m >= 0, "bad point count");
+    if (pts->m > 0)
+        ORBGPU_REQUIRE(pts->world_pos && pts->normal && pts->min_dist && pts->max_dist && pts->desc, "null point arrays");
+    ORBGPU_REQUIRE(log_scale_factor > 0, "log_scale_factor must be positive");
+    rc = select_device(device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    // Scw = [s R | s t] decomposed as ORBmatcher.cc:299-303 does: scw from the first row (double dot), then
+    // cv::Mat / scalar (float multiply by (float)(1/scw)), Ow = -Rcw^T tcw
+    float T[16] = {0}, Ow[3];
+    {
+        const double d = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+        const float scw = (float)sqrt(d);
+        ORBGPU_REQUIRE(scw > 0.f, "degenerate Scw");
+        const float alpha = (float)(1.0 / (double)scw);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) {
+                volatile float v = Scw[4 * r + c] * alpha;
+                T[4 * r + c] = v;
+            }
+        minus_rt_t(T, Ow);
+    }
+    // spAlreadyFound (:306-307): points some key point of the key frame already holds
+    std::vector<uint8_t> found((size_t)std::max(pts->m, 1), 0);
+    for (int j = 0; j < kf->n; j++) {
+        const int v = kp_to_mp[j];
+        ORBGPU_REQUIRE(v >= -2 && v < pts->m, "kp_to_mp[%d] = %d out of range", j, v);
+        if (v >= 0)
+            found[v] = 1;
+    }
+    std::vector<Query> q((size_t)pts->m);
+    for (int i = 0; i < pts->m; i++) {
+        Query &Q = q[i];
+        Q = Query{};
+        Q.blocking = 1;  // :394 vpMatched[bestIdx] = pMP hides the key point from every later point
+        if ((pts->bad && pts->bad[i]) || found[i])
+            continue;
+        const float *Pw = pts->world_pos + 3 * (size_t)i;
+        float pc[3];
+        rt_apply(T, Pw, pc);
+        if (pc[2] < 0.0f)
+            continue;
+        const float invz = 1 / pc[2];
+        volatile float x = pc[0] * invz, y = pc[1] * invz;
+        volatile float ux = fx * x, vy = fy * y;
+        const float u = ux + cx, v = vy + cy;
+        if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y))  // KeyFrame::IsInImage
+            continue;
+        const float maxDistance = 1.2f * pts->max_dist[i], minDistance = 0.8f * pts->min_dist[i];
+        const float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
+        const float dist = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        if (dist < minDistance || dist > maxDistance)
+            continue;
+        const float *Pn = pts->normal + 3 * (size_t)i;
+        const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+        if (dot < 0.5 * dist)  // viewing angle below 60 degrees (:352)
+            continue;
+        const float ratio = pts->max_dist[i] / dist;
+        const int lvl = (int)ceilf(logf(ratio) / log_scale_factor);  // MapPoint::PredictScale
+        if (lvl < 0 || lvl >= kf->nlevels) {
+            set_error("point %d: predicted level %d outside [0,%d)", i, lvl, kf->nlevels);
+            return ORBGPU_ELEVEL;
+        }
+        Q.r = (float)th * kf->scale_factors[lvl];
+        Q.x = u;
+        Q.y = v;
+        Q.min_level = lvl - 1;
+        Q.max_level = lvl;
+        Q.check_ur = 0;
+        Q.active = 1;
+    }
+    std::vector<int> init((size_t)std::max(kf->n, 1));
+    for (int j = 0; j < kf->n; j++)
+        init[j] = kp_to_mp[j] == -1 ? INT_MAX : -1;  // :373 vpMatched[idx] set: skipped
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    FrameDev F;
+    if ((rc = upload_frame(*ws, kf, F)) != ORBGPU_OK)
+        return rc;
+    return run_projection<1>(*ws, F, q, pts->desc, nullptr, nullptr, init, 0.f, ORBGPU_TH_LOW, 0, kp_to_mp, nmatches);
+}
+
 } // extern "C"

@@ -80,6 +80,11 @@ class TrackScratch(C.Structure):
                 ("view_cos", C.c_void_p), ("level", C.c_void_p)]
 
 
+class PointsView(C.Structure):
+    _fields_ = [("m", C.c_int32), ("bad", C.c_void_p), ("world_pos", C.c_void_p), ("normal", C.c_void_p),
+                ("min_dist", C.c_void_p), ("max_dist", C.c_void_p), ("desc", C.c_void_p)]
+
+
 class LastFrameView(C.Structure):
     _fields_ = [("n", C.c_int32), ("has_mp", C.c_void_p), ("outlier", C.c_void_p), ("obs_pos", C.c_void_p),
                 ("world_pos", C.c_void_p), ("desc", C.c_void_p), ("kp_octave", C.c_void_p),
@@ -100,7 +105,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
-    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors",
+    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
@@ -159,6 +164,7 @@ def lib():
         "orbgpu_search_local_points_device": [vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp],
         "orbgpu_projection_last_sweeps": [vp, vp],
         "orbgpu_distinctive_descriptors": [i32, vp, vp, vp, i32],
+        "orbgpu_search_by_projection_sim3": [vp, vp, f32, f32, f32, f32, f32, vp, i32, vp, vp, i32],
         "orbgpu_search_by_projection": [vp, vp, f32, f32, vp, vp, i32],
         "orbgpu_search_by_projection_last": [vp, vp, f32, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
         "orbgpu_search_by_projection_keyframe": [vp, vp, f32, f32, f32, f32, f32, vp, f32, i32, i32, vp, vp, i32],
@@ -495,6 +501,25 @@ class ORBmatcher:
                                                           int(orb_dist), int(self.check_ori), _p(out), C.byref(n),
                                                           self.device_id))
         return n.value, out
+
+
+def search_by_projection_sim3(kf_frame, Scw, fx, fy, cx, cy, log_sf, pts, th, kp_to_mp, device_id=0):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:290-403).
+    pts: dict of arrays bad, world_pos, normal, min_dist, max_dist, desc."""
+    keep = {k: np.ascontiguousarray(pts[k], dt) for k, dt in
+            (("bad", np.uint8), ("world_pos", np.float32), ("normal", np.float32), ("min_dist", np.float32),
+             ("max_dist", np.float32), ("desc", np.uint8))}
+    v = PointsView()
+    v.m = len(keep["bad"])
+    for k in keep:
+        setattr(v, k, _p(keep[k]))
+    fv = kf_frame.view()
+    S = np.ascontiguousarray(Scw, np.float32)
+    out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
+    n = C.c_int32()
+    check(lib().orbgpu_search_by_projection_sim3(C.byref(fv), _p(S), fx, fy, cx, cy, log_sf, C.byref(v), int(th), _p(out),
+                                                 C.byref(n), device_id))
+    return n.value, out
 
 
 class BatchMatcher:

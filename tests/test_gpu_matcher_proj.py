@@ -373,3 +373,44 @@ def test_frame_glue_with_distortion(gpu, oracle, stream640):
     rng = np.random.default_rng(0)
     pts = rng.uniform(-200, 900, (5000, 2)).astype(np.float32)
     assert np.array_equal(gpu.undistort_points(pts, cam), oracle.undistort_points(pts, fx, fy, cx, cy, dist))
+
+
+@pytest.mark.parametrize("th,scale,pre", [(10, 1.0, 0), (10, 1.7, 150), (4, 0.6, 60)])
+def test_search_by_projection_sim3_loop_closing(gpu, oracle, th, scale, pre):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:290-403): candidate points of a loop
+    key frame's neighbourhood projected with a Sim3 (scale != 1), some key points already matched (vpMatched),
+    some of those to candidate points (spAlreadyFound), oblique and out-of-range points included."""
+    st, Tcw, gf, of, mp, wp, dsc, octv, ang, cur_k = build_c3(gpu, oracle, 640, 480, 1000, 3, 31)
+    rng = np.random.default_rng(5)
+    m = len(wp)
+    # Sim3: world' = world / scale  <=>  Scw = [s R | s t] maps world' points (= wp / scale... ) -- here simply scale
+    # the rigid pose: points are given in a world that is `scale` times smaller than the key frame's
+    Scw = Tcw.copy().astype(np.float32)
+    Scw[:3, :3] *= np.float32(scale)
+    Scw[:3, 3] *= np.float32(scale)
+    pts_w = wp.copy()            # Rcw * P + tcw with Rcw = sR/s, tcw = st/s reproduces the rigid projection
+    sf = np.asarray(gf.scale_factors, np.float32)
+    log_sf = float(np.log(np.float32(sf[1])))
+    T = Tcw.astype(np.float64)
+    Ow = -T[:3, :3].T @ T[:3, 3]
+    dist = np.linalg.norm(pts_w.astype(np.float64) - Ow, axis=1)
+    normal = (pts_w.astype(np.float64) - Ow) / dist[:, None]
+    kind = rng.integers(0, 12, m)
+    normal[kind == 0] += rng.normal(0, 1.0, (int((kind == 0).sum()), 3))   # oblique: some fail the 60 degree test
+    normal /= np.linalg.norm(normal, axis=1)[:, None]
+    max_d = (dist * sf[octv]).astype(np.float32)
+    max_d[kind == 1] *= np.float32(0.5)                                     # outside the invariance range
+    min_d = (max_d / sf[-1]).astype(np.float32)
+    pts = {"bad": (rng.random(m) < 0.03).astype(np.uint8), "world_pos": pts_w, "normal": normal.astype(np.float32),
+           "min_dist": min_d, "max_dist": max_d, "desc": dsc}
+    k0 = np.full(gf.n, -1, np.int32)
+    if pre:
+        idx = rng.choice(gf.n, pre, replace=False)
+        k0[idx[:pre // 2]] = rng.integers(0, m, pre // 2)   # already matched to candidate points
+        k0[idx[pre // 2:]] = -2                              # matched to other map points
+    fx, fy, cx, cy = float(st.fx), float(st.fy), float(st.cx), float(st.cy)
+    ng, kg = gpu.search_by_projection_sim3(gf, Scw, fx, fy, cx, cy, log_sf, pts, th, k0)
+    no, ko = oracle.search_by_projection_sim3(of, Scw, fx, fy, cx, cy, log_sf, pts, th, k0)
+    assert no > 100, no
+    assert ng == no and np.array_equal(kg, ko), "%d vs %d, %d key points differ" % (ng, no, int((kg != ko).sum()))
+    assert np.all(kg[k0 != -1] == k0[k0 != -1])  # vpMatched entries that were set stay
