@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "orbgpu.h"
@@ -309,6 +310,70 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
             if (k2m[j] >= 0)
                 CurrentFrame.mvpMapPoints[j] = vpMPs[k2m[j]];  // :1556
         return nmatches;
+    }
+
+    // int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*> &vpPoints,
+    //                        std::vector<MapPoint*> &vpMatched, int th)   (ORBmatcher.h:60, ORBmatcher.cc:290-403)
+    // KeyFrameT needs the Frame member names FrameSoA reads (KeyFrame.h has them all) plus fx, fy, cx, cy and
+    // mfLogScaleFactor; Scw is the 4x4 row-major float Sim3; normal / min_dist / max_dist return GetNormal() and the
+    // protected mfMinDistance / mfMaxDistance of a map point.
+    template <typename KeyFrameT, typename DescRow, typename MpDesc, typename WorldPos, typename Normal,
+              typename MinDist, typename MaxDist>
+    int SearchByProjection(KeyFrameT *pKF, const float *Scw, const std::vector<MapPointT *> &vpPoints,
+                           std::vector<MapPointT *> &vpMatched, int th, DescRow desc_row, MpDesc mp_desc,
+                           WorldPos world_pos, Normal normal, MinDist min_dist, MaxDist max_dist)
+    {
+        FrameSoA<KeyFrameT> kf(*pKF, desc_row);
+        const int m = (int)vpPoints.size();
+        std::vector<uint8_t> bad(std::max(m, 1)), desc((size_t)std::max(m, 1) * 32);
+        std::vector<float> wp((size_t)std::max(m, 1) * 3), nr((size_t)std::max(m, 1) * 3), mind(std::max(m, 1)),
+            maxd(std::max(m, 1));
+        std::map<MapPointT *, int> row;  // first row of every distinct point (vpPoints has no duplicates in the reference)
+        for (int i = 0; i < m; i++) {
+            MapPointT *p = vpPoints[i];
+            row.emplace(p, i);
+            bad[i] = p->isBad();
+            const float *w = world_pos(p), *nn = normal(p);
+            wp[3 * i] = w[0], wp[3 * i + 1] = w[1], wp[3 * i + 2] = w[2];
+            nr[3 * i] = nn[0], nr[3 * i + 1] = nn[1], nr[3 * i + 2] = nn[2];
+            mind[i] = min_dist(p), maxd[i] = max_dist(p);
+            std::memcpy(&desc[(size_t)i * 32], mp_desc(p), 32);
+        }
+        orbgpu_points_view pv{m, bad.data(), wp.data(), nr.data(), mind.data(), maxd.data(), desc.data()};
+        std::vector<int32_t> k2m(pKF->N, -1);
+        for (int j = 0; j < pKF->N; j++)
+            if (vpMatched[j]) {
+                auto it = row.find(vpMatched[j]);
+                k2m[j] = it == row.end() ? -2 : it->second;
+            }
+        const std::vector<int32_t> before = k2m;
+        int32_t nmatches = 0;
+        check(orbgpu_search_by_projection_sim3(&kf.view, Scw, pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mfLogScaleFactor,
+                                               &pv, th, k2m.data(), &nmatches, device_),
+              "SearchByProjection(Sim3)");
+        for (int j = 0; j < pKF->N; j++)
+            if (k2m[j] != before[j])
+                vpMatched[j] = vpPoints[k2m[j]];  // :394
+        return nmatches;
+    }
+
+    // void MapPoint::ComputeDistinctiveDescriptors()  (MapPoint.cc:242-307) for a batch of map points: groups[g] holds
+    // the descriptor rows of the non-bad observing key frames of point g (in mObservations order); returns the index
+    // of the chosen row per point (-1: no observation, mDescriptor stays).
+    static std::vector<int32_t> ComputeDistinctiveDescriptors(const std::vector<std::vector<const uint8_t *>> &groups,
+                                                              int device_id = 0)
+    {
+        std::vector<int32_t> off(groups.size() + 1, 0), best(std::max<size_t>(groups.size(), 1), -1);
+        for (size_t g = 0; g < groups.size(); g++)
+            off[g + 1] = off[g] + (int32_t)groups[g].size();
+        std::vector<uint8_t> flat((size_t)std::max(off.back(), 1) * 32);
+        for (size_t g = 0; g < groups.size(); g++)
+            for (size_t i = 0; i < groups[g].size(); i++)
+                std::memcpy(&flat[((size_t)off[g] + i) * 32], groups[g][i], 32);
+        check(orbgpu_distinctive_descriptors((int32_t)groups.size(), off.data(), flat.data(), best.data(), device_id),
+              "ComputeDistinctiveDescriptors");
+        best.resize(groups.size());
+        return best;
     }
 
   protected:

@@ -18,7 +18,7 @@ struct MapPoint {  // members read by the matcher: MapPoint.h:91-96 + accessors
     float mTrackViewCos = 0, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
     bool bad = false;
     int nObs = 1;
-    float world[3] = {0, 0, 0};
+    float world[3] = {0, 0, 0}, normal[3] = {0, 0, 1}, minDist = 0, maxDist = 0;
     uint8_t desc[32];
     int id = -1;
     bool isBad() const { return bad; }
@@ -35,7 +35,7 @@ struct Frame {  // Frame.h:100-190
     std::vector<size_t> mGrid[orbgpu_shim::FRAME_GRID_COLS][orbgpu_shim::FRAME_GRID_ROWS];
     float mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
     std::vector<float> mvScaleFactors;
-    float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0, mfLogScaleFactor = 0;
     float mTcw[16];
 };
 
@@ -131,6 +131,9 @@ int main(int argc, char **argv)
             rd(in, &lvl, 1);
             rd(in, f4, 4);
             rd(in, p.world, 3);
+            rd(in, p.normal, 3);
+            rd(in, &p.minDist, 1);
+            rd(in, &p.maxDist, 1);
             rd(in, p.desc, 32);
             p.mbTrackInView = flags[0], p.bad = flags[1], p.nObs = flags[2] ? 1 : 0;
             p.mnTrackScaleLevel = lvl, p.mTrackViewCos = f4[0], p.mTrackProjX = f4[1], p.mTrackProjY = f4[2],
@@ -151,6 +154,33 @@ int main(int argc, char **argv)
         const int dist = orbgpu_shim::ORBmatcherT<Frame, MapPoint>::DescriptorDistance(mps[0].desc, mps[m - 1].desc);
         int32_t d32 = dist;
         wr(out, &d32, 1);
+
+        // ---- loop-closing projection (the stand-in Frame plays the key frame) and distinctive descriptors
+        {
+            // (the test driver computes the same value: double log rounded to float, so both sides agree to the bit)
+            F.mfLogScaleFactor = (float)std::log((double)F.mvScaleFactors[1]);
+            std::vector<MapPoint *> vpMatched(F.N, nullptr);
+            float Scw[16];
+            std::memcpy(Scw, Tcw, 64);
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 4; c++)
+                    Scw[4 * r + c] *= 1.5f;
+            const int ns = matcher.SearchByProjection(
+                &F, Scw, vp, vpMatched, 10, desc_row, mp_desc, [](MapPoint *p) { return p->world; },
+                [](MapPoint *p) { return p->normal; }, [](MapPoint *p) { return p->minDist; },
+                [](MapPoint *p) { return p->maxDist; });
+            int32_t ns32 = ns;
+            wr(out, &ns32, 1);
+            for (int j = 0; j < F.N; j++) {
+                int32_t id = vpMatched[j] ? vpMatched[j]->id : -1;
+                wr(out, &id, 1);
+            }
+            std::vector<std::vector<const uint8_t *>> groups(3);
+            for (int i = 0; i < m; i++)
+                groups[i % 2].push_back(mps[i].desc);  // group 2 stays empty
+            const std::vector<int32_t> best = orbgpu_shim::ORBmatcherT<Frame, MapPoint>::ComputeDistinctiveDescriptors(groups);
+            wr(out, best.data(), best.size());
+        }
 
         // ---- point cloud thread protocol
         KeyFrame kf;

@@ -56,6 +56,10 @@ def test_shim_end_to_end(gpu, oracle, stream640):
         wp.append(P), dsc.append(d), octv.append(k["octave"])
     wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
     mp = scenario.local_map(oracle, st, Tcw, wp, dsc, octv, sf, rng, obs_zero_frac=0.1)
+    # points outside the frustum (or whose predicted level leaves the pyramid: an error for the Sim3 matcher, which the
+    # reference leaves undefined) are flagged bad; SearchByProjection(F, ...) skips them either way
+    # (points created on the top level predict level 7 or 8 depending on the last ulp of the camera distance)
+    mp["bad"] = (mp["bad"] | (mp["in_view"] == 0) | (octv == len(sf) - 1)).astype(np.uint8)
     th = 3.0
     with tempfile.TemporaryDirectory() as d:
         exe = build_exe(d)
@@ -69,7 +73,10 @@ def test_shim_end_to_end(gpu, oracle, stream640):
                 f.write(struct.pack("<i", int(mp["level"][i])))
                 f.write(struct.pack("<4f", float(mp["view_cos"][i]), float(mp["proj_x"][i]), float(mp["proj_y"][i]),
                                     float(mp["proj_xr"][i])))
-                f.write(wp[i].astype("<f4").tobytes()), f.write(mp["desc"][i].tobytes())
+                f.write(wp[i].astype("<f4").tobytes())
+                f.write(mp["normal"][i].astype("<f4").tobytes())
+                f.write(struct.pack("<2f", float(mp["min_dist"][i]), float(mp["max_dist"][i])))
+                f.write(mp["desc"][i].tobytes())
         r = subprocess.run([exe, scen, outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout
         buf = open(outp, "rb").read()
@@ -90,6 +97,22 @@ def test_shim_end_to_end(gpu, oracle, stream640):
     dist = struct.unpack_from("<i", buf, off)[0]
     off += 4
     assert dist == oracle.descriptor_distance(mp["desc"][0], mp["desc"][-1])
+    # loop-closing projection through the shim (Sim3 = 1.5 x the rigid pose) and distinctive descriptors
+    ns = struct.unpack_from("<i", buf, off)[0]
+    off += 4
+    matched = np.frombuffer(buf, np.int32, n, off)
+    off += 4 * n
+    Scw = Tcw.astype(np.float32).copy()
+    Scw[:3, :] *= np.float32(1.5)
+    pts = {"bad": mp["bad"], "world_pos": wp, "normal": mp["normal"], "min_dist": mp["min_dist"],
+           "max_dist": mp["max_dist"], "desc": mp["desc"]}
+    log_sf = float(np.float32(np.log(np.float64(np.float32(sf[1])))))
+    nso, kso = oracle.search_by_projection_sim3(of, Scw, float(st.fx), float(st.fy), float(st.cx), float(st.cy),
+                                                log_sf, pts, 10, np.full(n, -1, np.int32))
+    assert ns == nso and np.array_equal(matched, kso) and nso > 50
+    best = np.frombuffer(buf, np.int32, 3, off)
+    off += 12
+    assert list(best) == [oracle.distinctive_descriptor(mp["desc"][0::2]), oracle.distinctive_descriptor(mp["desc"][1::2]), -1]
     nc = struct.unpack_from("<q", buf, off)[0]
     off += 8
     cloud = np.frombuffer(buf, oracle.POINT_DTYPE, nc, off)
