@@ -64,62 +64,117 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 }
 
 // Pass 1: for every A row the BF_TOPK best B rows over ALL B rows (claims are applied in pass 2).
-// One LANE per A row (its 256-bit descriptor lives in 8 VGPRs) looping over the B rows; the B row is
-// the same for the whole wave, so it arrives through the scalar cache (s_load_dwordx8) and the XORs
-// take SGPR operands: 8 v_xor + 8 v_bcnt (with accumulate) per distance, no LDS, no cross-lane merge.
-// grid = (ceil(cap / 256), pairs, nsplit): the B rows are split into nsplit contiguous ranges to put enough
+//
+// All-pairs Hamming distance is a GEMM: with every bit b mapped to the signed byte 2b-1 (+1 / -1), the dot product
+// of two 256-byte rows is 256 - 2 * hamming.  The matrix cores (idle everywhere else on this path) evaluate it with
+// v_mfma_i32_32x32x32_i8: a wave owns 32 A rows, whose expanded descriptors stay in 32 VGPRs as the MFMA's B operand
+// (N = A row = the accumulator's COLUMN = lane & 31), and walks the B rows in tiles of 32 (the MFMA's A operand,
+// M = B row = accumulator ROW), 8 MFMAs per tile.  Each lane then holds 16 distances of ONE A row to 16 different B
+// rows and feeds them to its private sorted top-4 (key = distance << 12 | B index); lanes l and l + 32 share an A
+// row and merge at the end.  The 4 waves of a workgroup (128 A rows) share every B tile: the workgroup expands the
+// tile's 32 x 256 bits to bytes once (one dword per thread -> 32 B) into LDS, double buffered, and each wave reads its
+// 8 fragments back with ds_read_b128 (row stride 272 B: conflict free).  Lane maps of the i8 MFMA verified with
+// exact integer data: tools/ubench/mfma_i8_probe.hip.
+// grid = (ceil(cap / 128), pairs, nsplit): the B rows are split into nsplit contiguous ranges to put enough
 // waves in flight (2 for a full batch, up to BF_MAX_SPLIT for a single pair, where the scan is latency bound);
 // k_bf_resolve merges the partial lists (4 smallest of their union).
 constexpr int BF_MIN_SPLIT = 2, BF_MAX_SPLIT = 16;
 constexpr size_t BF_RESOLVE_MAX_LDS = 150 * 1024;  // of the CU's 160 KB; static LDS of k_bf_resolve is < 1 KB
+constexpr int BF_TILE_STRIDE = 272;                // bytes per expanded B row in LDS (256 + 16: bank spread)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// 16 descriptor bits -> 16 signed bytes (bit 1 -> +1, bit 0 -> -1); byte j <- bit j.
+// (n * 0x00204081) & 0x01010101 spreads the 4 bits of a nibble to the low bits of 4 bytes; 0xFF - 0xFE * b = +1 / -1.
+__device__ __forceinline__ v4i bf_expand16(uint32_t hw)
+{
+    v4i r;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t n = (hw >> (4 * q)) & 0xFu;
+        const uint32_t w01 = (n * 0x00204081u) & 0x01010101u;
+        r[q] = (int)~(w01 * 0xFEu);
+    }
+    return r;
+}
 
 __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
                                                  const int *__restrict__ nb_p, uint32_t *__restrict__ topk)
 {
+    __shared__ __align__(16) uint8_t s_tile[2][32 * BF_TILE_STRIDE];
     const int nsplit = gridDim.z;
     const int pair = blockIdx.y;
     const int na = min(na_p[pair], cap);
-    int nb = min(nb_p[pair], cap);
-    if ((int)(blockIdx.x * 256) >= na)
-        return;
-    const int i = min((int)(blockIdx.x * 256 + threadIdx.x), na - 1);  // tail lanes repeat the last row
-    const uint32_t *ga = reinterpret_cast<const uint32_t *>(desc_a + ((size_t)pair * cap + i) * 32);
-    uint32_t a[8];
+    const int nb = min(nb_p[pair], cap);
+    if ((int)(blockIdx.x * 128) >= na)
+        return;  // the whole workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int i = blockIdx.x * 128 + wave * 32 + r;  // this lane's A row (= accumulator column)
+    // the A rows of this wave as the MFMA's B operand: fragment s holds k = 32 s + 16 h .. + 15 = halfword 2 s + h
+    v4i fa[8];
+    {
+        const uint32_t *ga = reinterpret_cast<const uint32_t *>(desc_a + ((size_t)pair * cap + min(i, na - 1)) * 32);
 #pragma unroll
-    for (int w = 0; w < 8; w++)
-        a[w] = ga[w];
-    const uint32_t *gb = reinterpret_cast<const uint32_t *>(desc_b + (size_t)pair * cap * 32);
-    uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
+        for (int s = 0; s < 8; s++)
+            fa[s] = bf_expand16(ga[s] >> (16 * h));
+    }
     const int per = (nb + nsplit - 1) / nsplit;
-    int j = (int)blockIdx.z * per;
-    nb = min(nb, j + per);
-    for (; j + 4 <= nb; j += 4) {  // 4 B rows per step: their scalar loads are issued together
-        const uint32_t *b = gb + (size_t)j * 8;  // wave-uniform address -> s_load_dwordx8
-        uint32_t bb[4][8];
+    const int jbeg = (int)blockIdx.z * per, jend = min(nb, jbeg + per);
+    const int ntiles = (jend - jbeg + 31) / 32;
+    const uint32_t *gb = reinterpret_cast<const uint32_t *>(desc_b + (size_t)pair * cap * 32);
+    // staging: thread t expands dword (t & 7) of tile row (t >> 3): two fragments, 32 contiguous bytes
+    const int sm = tid >> 3, sw = tid & 7;
+    auto stage = [&](int tile, int buf) {
+        const int j = min(jbeg + tile * 32 + sm, nb - 1);  // rows past the end repeat the last one (never selected)
+        const uint32_t d = gb[(size_t)j * 8 + sw];
+        v4i *dst = reinterpret_cast<v4i *>(&s_tile[buf][sm * BF_TILE_STRIDE + sw * 32]);
+        dst[0] = bf_expand16(d);
+        dst[1] = bf_expand16(d >> 16);
+    };
+    uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
+    if (ntiles > 0)
+        stage(0, 0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; tile++) {
+        if (tile + 1 < ntiles)
+            stage(tile + 1, (tile + 1) & 1);
+        const uint8_t *tb = &s_tile[tile & 1][r * BF_TILE_STRIDE + h * 16];
+        v16i acc = {0};
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int w = 0; w < 8; w++)
-                bb[u][w] = b[u * 8 + w];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            uint32_t d = 0;
-#pragma unroll
-            for (int w = 0; w < 8; w++)
-                d += __popc(a[w] ^ bb[u][w]);
-            top4_insert(t, bf_key((int)d, j + u));
+        for (int s = 0; s < 8; s++) {
+            const v4i fb = *reinterpret_cast<const v4i *>(tb + s * 32);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa[s], acc, 0, 0, 0);
         }
-    }
-    for (; j < nb; j++) {
-        const uint32_t *b = gb + (size_t)j * 8;
-        uint32_t d = 0;
+        // acc[reg] = 256 - 2 * hamming(A row i, B row j0 + (reg & 3) + 8 (reg >> 2) + 4 h)
+        const int j0 = jbeg + tile * 32 + 4 * h;
+        if (j0 - 4 * h + 32 <= jend) {
 #pragma unroll
-        for (int w = 0; w < 8; w++)
-            d += __popc(a[w] ^ b[w]);
-        top4_insert(t, bf_key((int)d, j));
+            for (int reg = 0; reg < 16; reg++) {
+                const int j = j0 + (reg & 3) + 8 * (reg >> 2);
+                top4_insert(t, (uint32_t)(((256 - acc[reg]) << 11) + j));  // (2 ham) << 11 = ham << 12
+            }
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int j = j0 + (reg & 3) + 8 * (reg >> 2);
+                if (j < jend)
+                    top4_insert(t, (uint32_t)(((256 - acc[reg]) << 11) + j));
+            }
+        }
+        __syncthreads();
     }
-    if ((int)(blockIdx.x * 256 + threadIdx.x) < na)
+    // lanes l and l + 32 hold the same A row
+    {
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            o[k] = __shfl_xor(t[k], 32, 64);
+        top4_merge(t, o);
+    }
+    if (h == 0 && i < na)
         *reinterpret_cast<uint4 *>(topk + (((size_t)pair * cap + i) * nsplit + blockIdx.z) * BF_TOPK) =
             make_uint4(t[0], t[1], t[2], t[3]);
 }
@@ -516,10 +571,10 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
     uint32_t *topk = m->d_topk.as<uint32_t>();
     // enough waves to cover the device (~2048) while the partial lists fit the buffer sized at creation
     int nsplit = BF_MIN_SPLIT;
-    while (nsplit < BF_MAX_SPLIT && (size_t)pairs * ((cap + 255) / 256) * 4 * nsplit < 2048 &&
+    while (nsplit < BF_MAX_SPLIT && (size_t)pairs * ((cap + 127) / 128) * 4 * nsplit < 2048 &&
            (size_t)pairs * nsplit * 2 <= std::max<size_t>((size_t)m->max_pairs * BF_MIN_SPLIT, BF_MAX_SPLIT))
         nsplit *= 2;
-    const dim3 grid((cap + 255) / 256, pairs, nsplit);
+    const dim3 grid((cap + 127) / 128, pairs, nsplit);
     hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk);
     // claim / match / queue tables (16 B per row) + the B descriptors (32 B per row) when both fit in LDS
     const int stage_b = (size_t)48 * cap <= BF_RESOLVE_MAX_LDS ? 1 : 0;
