@@ -128,14 +128,15 @@ enum {
 int orbgpu_extractor_debug_read(orbgpu_extractor *h, int32_t what, int32_t frame, int32_t level, void *dst,
                                 size_t dst_bytes, size_t *n, int32_t *aux);
 
-/* Per-stage device time (ms), measured with HIP events recorded on the call's own stream around
- * every stage of every call made while profiling is enabled (up to 256 calls per window).
+/* Per-stage device time (ms), measured with HIP events recorded on the call's own stream at the stage
+ * boundaries of every call made while profiling is enabled (up to 256 calls per window; enabling and
+ * disabling keeps the window, so a caller may profile a sample of its calls).
  * Names are returned by orbgpu_extractor_stage_name(i); count by orbgpu_extractor_stage_count(). */
 int orbgpu_extractor_set_profiling(orbgpu_extractor *h, int32_t enable);
 int orbgpu_extractor_stage_count(void);
 const char *orbgpu_extractor_stage_name(int32_t i);
 /* Synchronises the recorded events, returns the AVERAGE ms per stage over the calls profiled since
- * the last set_profiling/stage_times, and starts a new window. */
+ * the last stage_times, and starts a new window. */
 int orbgpu_extractor_stage_times(orbgpu_extractor *h, float *ms_out);
 
 /* ======================================================================================

@@ -1424,7 +1424,7 @@ struct orbgpu_extractor {
     // profiling: one event set per profiled call (up to PROF_SLOTS), averaged by stage_times()
     static constexpr int PROF_SLOTS = 256;
     bool profiling = false;
-    std::vector<hipEvent_t> ev;  // PROF_SLOTS * 2 * ST_COUNT (start/end per stage), created lazily
+    std::vector<hipEvent_t> ev;  // PROF_SLOTS * 2 * ST_COUNT slots (ST_COUNT + 1 boundary events used per call), created lazily
     int prof_calls = 0;
 
 };
@@ -1780,8 +1780,10 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
             ORBGPU_HIP_TRY(hipEventCreate(&x));
     }
     hipEvent_t *evs = prof ? &e->ev[(size_t)e->prof_calls * 2 * ST_COUNT] : nullptr;
-#define BEGIN(stage, s) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[2 * (stage)], s))
-#define END(stage, s) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[2 * (stage) + 1], s))
+// one event per stage boundary (an event costs the stream several microseconds): evs[0] before the first stage,
+// evs[1 + stage] after each; stage time = evs[1 + stage] - evs[stage]
+#define BEGIN(stage, s) if (prof && (stage) == 0) ORBGPU_HIP_TRY(hipEventRecord(evs[0], s))
+#define END(stage, s) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[1 + (stage)], s))
     BEGIN(ST_PYRAMID, st);
     {
         const LevelGeom &g = e->geom[0];
@@ -2095,8 +2097,7 @@ int orbgpu_extractor_debug_read(orbgpu_extractor *e, int32_t what, int32_t frame
 int orbgpu_extractor_set_profiling(orbgpu_extractor *e, int32_t enable)
 {
     ORBGPU_REQUIRE(e, "null argument");
-    e->profiling = enable != 0;
-    e->prof_calls = 0;
+    e->profiling = enable != 0;  // the averaging window is kept: stage_times() reads and resets it
     return ORBGPU_OK;
 }
 int orbgpu_extractor_stage_count(void) { return ST_COUNT; }
@@ -2115,7 +2116,7 @@ int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms)
         for (int i = 0; i < ST_COUNT; i++) {
             float t = 0.f;
             ORBGPU_HIP_TRY(hipEventSynchronize(evs[2 * i + 1]));
-            ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[2 * i], evs[2 * i + 1]));
+            ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
             ms[i] += t;
         }
     }

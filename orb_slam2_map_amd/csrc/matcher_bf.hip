@@ -75,6 +75,10 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 // tile's 32 x 256 bits to bytes once (one dword per thread -> 32 B) into LDS, double buffered, and each wave reads its
 // 8 fragments back with ds_read_b128 (row stride 272 B: conflict free).  Lane maps of the i8 MFMA verified with
 // exact integer data: tools/ubench/mfma_i8_probe.hip.
+// Only B rows within dmax of the A row are listed, dmax = the largest distance that can change a decision of pass 2:
+// a best beyond th_low is rejected whatever it is, and a second best b2 with nnratio * b2 > th_low passes every
+// ratio test (ORBmatcher.cc:228-231), so a list that ends early means "nothing else matters" exactly like a list
+// that ran out of B rows.
 // grid = (ceil(cap / 128), pairs, nsplit): the B rows are split into nsplit contiguous ranges to put enough
 // waves in flight (2 for a full batch, up to BF_MAX_SPLIT for a single pair, where the scan is latency bound);
 // k_bf_resolve merges the partial lists (4 smallest of their union).
@@ -101,7 +105,8 @@ __device__ __forceinline__ v4i bf_expand16(uint32_t hw)
 
 __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
-                                                 const int *__restrict__ nb_p, uint32_t *__restrict__ topk)
+                                                 const int *__restrict__ nb_p, uint32_t *__restrict__ topk,
+                                                 int acc_min)
 {
     __shared__ __align__(16) uint8_t s_tile[2][32 * BF_TILE_STRIDE];
     const int nsplit = gridDim.z;
@@ -125,22 +130,32 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
     const int jbeg = (int)blockIdx.z * per, jend = min(nb, jbeg + per);
     const int ntiles = (jend - jbeg + 31) / 32;
     const uint32_t *gb = reinterpret_cast<const uint32_t *>(desc_b + (size_t)pair * cap * 32);
-    // staging: thread t expands dword (t & 7) of tile row (t >> 3): two fragments, 32 contiguous bytes
+    // staging: thread t expands dword (t & 7) of tile row (t >> 3): two fragments, 32 contiguous bytes.  The dword of
+    // tile + 2 is requested while tile is multiplied, so its latency never sits in front of an expansion.
     const int sm = tid >> 3, sw = tid & 7;
-    auto stage = [&](int tile, int buf) {
+    auto fetch = [&](int tile) {
         const int j = min(jbeg + tile * 32 + sm, nb - 1);  // rows past the end repeat the last one (never selected)
-        const uint32_t d = gb[(size_t)j * 8 + sw];
+        return gb[(size_t)j * 8 + sw];
+    };
+    auto stage = [&](uint32_t d, int buf) {
         v4i *dst = reinterpret_cast<v4i *>(&s_tile[buf][sm * BF_TILE_STRIDE + sw * 32]);
         dst[0] = bf_expand16(d);
         dst[1] = bf_expand16(d >> 16);
     };
     uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
+    int lim = acc_min;  // accumulator value a distance must reach to be inserted
+    uint32_t d_next = 0;
     if (ntiles > 0)
-        stage(0, 0);
+        stage(fetch(0), 0);
+    if (ntiles > 1)
+        d_next = fetch(1);
     __syncthreads();
     for (int tile = 0; tile < ntiles; tile++) {
+        const uint32_t d_cur = d_next;
+        if (tile + 2 < ntiles)
+            d_next = fetch(tile + 2);
         if (tile + 1 < ntiles)
-            stage(tile + 1, (tile + 1) & 1);
+            stage(d_cur, (tile + 1) & 1);
         const uint8_t *tb = &s_tile[tile & 1][r * BF_TILE_STRIDE + h * 16];
         v16i acc = {0};
 #pragma unroll
@@ -148,20 +163,24 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
             const v4i fb = *reinterpret_cast<const v4i *>(tb + s * 32);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa[s], acc, 0, 0, 0);
         }
-        // acc[reg] = 256 - 2 * hamming(A row i, B row j0 + (reg & 3) + 8 (reg >> 2) + 4 h)
-        const int j0 = jbeg + tile * 32 + 4 * h;
-        if (j0 - 4 * h + 32 <= jend) {
+        // acc[reg] = 256 - 2 * hamming(A row i, B row j0 + (reg & 3) + 8 (reg >> 2) + 4 h).  Only distances <= dmax
+        // can influence a decision (see the host side), i.e. acc >= acc_min: most tiles hold no such value for any
+        // lane of the wave and are dismissed with 8 v_max3 and one branch.
+        int best = max(max(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int reg = 3; reg < 15; reg += 2)
+            best = max(max(best, acc[reg]), acc[reg + 1]);
+        best = max(best, acc[15]);
+        if (__any(best >= lim)) {
+            const int j0 = jbeg + tile * 32 + 4 * h;
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const int j = j0 + (reg & 3) + 8 * (reg >> 2);
-                top4_insert(t, (uint32_t)(((256 - acc[reg]) << 11) + j));  // (2 ham) << 11 = ham << 12
-            }
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int j = j0 + (reg & 3) + 8 * (reg >> 2);
-                if (j < jend)
-                    top4_insert(t, (uint32_t)(((256 - acc[reg]) << 11) + j));
+                if (acc[reg] >= lim && j < jend) {
+                    top4_insert(t, (uint32_t)(((256 - acc[reg]) << 11) + j));  // (2 ham) << 11 = ham << 12
+                    if (t[3] != BF_KEY_NONE)
+                        lim = max(lim, 256 - 2 * (int)(t[3] >> 12));  // a full list only admits distances <= its last
+                }
             }
         }
         __syncthreads();
@@ -575,7 +594,12 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
            (size_t)pairs * nsplit * 2 <= std::max<size_t>((size_t)m->max_pairs * BF_MIN_SPLIT, BF_MAX_SPLIT))
         nsplit *= 2;
     const dim3 grid((cap + 127) / 128, pairs, nsplit);
-    hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk);
+    // largest second-best distance that can still fail the ratio test for some best <= th_low (same float
+    // arithmetic as the test itself, which is monotone in the second distance)
+    int dmax = std::min(std::max(th_low, 0), 256);
+    while (dmax < 256 && !(nnratio * (float)(dmax + 1) > (float)th_low))
+        dmax++;
+    hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk, 256 - 2 * dmax);
     // claim / match / queue tables (16 B per row) + the B descriptors (32 B per row) when both fit in LDS
     const int stage_b = (size_t)48 * cap <= BF_RESOLVE_MAX_LDS ? 1 : 0;
     const size_t lds = (size_t)(stage_b ? 48 : 16) * cap;
