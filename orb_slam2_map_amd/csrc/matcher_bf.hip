@@ -85,6 +85,7 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 constexpr int BF_MIN_SPLIT = 2, BF_MAX_SPLIT = 16;
 constexpr size_t BF_RESOLVE_MAX_LDS = 150 * 1024;  // of the CU's 160 KB; static LDS of k_bf_resolve is < 1 KB
 constexpr int BF_TILE_STRIDE = 272;                // bytes per expanded B row in LDS (256 + 16: bank spread)
+constexpr int BF_TILE_ROWS = 64;                   // B rows staged per iteration
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
                                                  const int *__restrict__ nb_p, uint32_t *__restrict__ topk,
                                                  int acc_min)
 {
-    __shared__ __align__(16) uint8_t s_tile[2][32 * BF_TILE_STRIDE];
+    __shared__ __align__(16) uint8_t s_tile[2][BF_TILE_ROWS * BF_TILE_STRIDE];
     const int nsplit = gridDim.z;
     const int pair = blockIdx.y;
     const int na = min(na_p[pair], cap);
@@ -128,59 +129,82 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
     }
     const int per = (nb + nsplit - 1) / nsplit;
     const int jbeg = (int)blockIdx.z * per, jend = min(nb, jbeg + per);
-    const int ntiles = (jend - jbeg + 31) / 32;
+    const int ntiles = (jend - jbeg + BF_TILE_ROWS - 1) / BF_TILE_ROWS;
     const uint32_t *gb = reinterpret_cast<const uint32_t *>(desc_b + (size_t)pair * cap * 32);
-    // staging: thread t expands dword (t & 7) of tile row (t >> 3): two fragments, 32 contiguous bytes.  The dword of
-    // tile + 2 is requested while tile is multiplied, so its latency never sits in front of an expansion.
+    // staging: a tile is BF_TILE_ROWS = 64 B rows (two MFMA row blocks, i.e. two independent accumulator chains per
+    // iteration and half as many barriers); thread t expands dword (t & 7) of tile rows (t >> 3) and 32 + (t >> 3):
+    // two fragments = 32 contiguous bytes each.  The dwords of tile + 2 are requested while tile is multiplied, so
+    // their latency never sits in front of an expansion.
     const int sm = tid >> 3, sw = tid & 7;
-    auto fetch = [&](int tile) {
-        const int j = min(jbeg + tile * 32 + sm, nb - 1);  // rows past the end repeat the last one (never selected)
-        return gb[(size_t)j * 8 + sw];
+    auto fetch = [&](int tile, uint32_t d[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = min(jbeg + tile * BF_TILE_ROWS + 32 * u + sm, nb - 1);  // past the end: repeats (never selected)
+            d[u] = gb[(size_t)j * 8 + sw];
+        }
     };
-    auto stage = [&](uint32_t d, int buf) {
-        v4i *dst = reinterpret_cast<v4i *>(&s_tile[buf][sm * BF_TILE_STRIDE + sw * 32]);
-        dst[0] = bf_expand16(d);
-        dst[1] = bf_expand16(d >> 16);
+    auto stage = [&](const uint32_t d[2], int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            v4i *dst = reinterpret_cast<v4i *>(&s_tile[buf][(32 * u + sm) * BF_TILE_STRIDE + sw * 32]);
+            dst[0] = bf_expand16(d[u]);
+            dst[1] = bf_expand16(d[u] >> 16);
+        }
     };
     uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
     int lim = acc_min;  // accumulator value a distance must reach to be inserted
-    uint32_t d_next = 0;
-    if (ntiles > 0)
-        stage(fetch(0), 0);
+    uint32_t d_next[2] = {0, 0};
+    if (ntiles > 0) {
+        uint32_t d0[2];
+        fetch(0, d0);
+        stage(d0, 0);
+    }
     if (ntiles > 1)
-        d_next = fetch(1);
+        fetch(1, d_next);
     __syncthreads();
     for (int tile = 0; tile < ntiles; tile++) {
-        const uint32_t d_cur = d_next;
+        const uint32_t d_cur[2] = {d_next[0], d_next[1]};
         if (tile + 2 < ntiles)
-            d_next = fetch(tile + 2);
+            fetch(tile + 2, d_next);
         if (tile + 1 < ntiles)
             stage(d_cur, (tile + 1) & 1);
         const uint8_t *tb = &s_tile[tile & 1][r * BF_TILE_STRIDE + h * 16];
-        v16i acc = {0};
+        v16i acc0 = {0}, acc1 = {0};
 #pragma unroll
         for (int s = 0; s < 8; s++) {
-            const v4i fb = *reinterpret_cast<const v4i *>(tb + s * 32);
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa[s], acc, 0, 0, 0);
+            const v4i fb0 = *reinterpret_cast<const v4i *>(tb + s * 32);
+            const v4i fb1 = *reinterpret_cast<const v4i *>(tb + 32 * BF_TILE_STRIDE + s * 32);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb0, fa[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb1, fa[s], acc1, 0, 0, 0);
         }
         // acc[reg] = 256 - 2 * hamming(A row i, B row j0 + (reg & 3) + 8 (reg >> 2) + 4 h).  Only distances <= dmax
-        // can influence a decision (see the host side), i.e. acc >= acc_min: most tiles hold no such value for any
+        // can influence a decision (see the host side), i.e. acc >= acc_min: most row blocks hold no such value for any
         // lane of the wave and are dismissed with 8 v_max3 and one branch.
-        int best = max(max(acc[0], acc[1]), acc[2]);
+        const bool full = jbeg + (tile + 1) * BF_TILE_ROWS <= jend;  // no row of this tile lies past the range
 #pragma unroll
-        for (int reg = 3; reg < 15; reg += 2)
-            best = max(max(best, acc[reg]), acc[reg + 1]);
-        best = max(best, acc[15]);
-        if (__any(best >= lim)) {
-            const int j0 = jbeg + tile * 32 + 4 * h;
+        for (int u = 0; u < 2; u++) {
+            const v16i &acc = u ? acc1 : acc0;
+            // maxima of the four register groups (= 4 consecutive B rows each), then of the block
+            int gmax[4];
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                const int j = j0 + (reg & 3) + 8 * (reg >> 2);
-                if (acc[reg] >= lim && j < jend) {
-                    top4_insert(t, (uint32_t)(((256 - acc[reg]) << 11) + j));  // (2 ham) << 11 = ham << 12
-                    if (t[3] != BF_KEY_NONE)
-                        lim = max(lim, 256 - 2 * (int)(t[3] >> 12));  // a full list only admits distances <= its last
+            for (int g = 0; g < 4; g++)
+                gmax[g] = max(max(acc[4 * g], acc[4 * g + 1]), max(acc[4 * g + 2], acc[4 * g + 3]));
+            const int best = max(max(gmax[0], gmax[1]), max(gmax[2], gmax[3]));
+            if (__any(best >= lim)) {
+                const int j0 = jbeg + tile * BF_TILE_ROWS + 32 * u + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    if (!__any(gmax[g] >= lim))
+                        continue;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int reg = 4 * g + q, j = j0 + q + 8 * g;
+                        if (acc[reg] >= lim && (full || j < jend))
+                            top4_insert(t, (uint32_t)(((256 - acc[reg]) << 11) + j));  // (2 ham) << 11 = ham << 12
+                    }
                 }
+                if (t[3] != BF_KEY_NONE)
+                    lim = max(lim, 256 - 2 * (int)(t[3] >> 12));  // a full list only admits distances <= its last
             }
         }
         __syncthreads();
