@@ -71,21 +71,23 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 // (N = A row = the accumulator's COLUMN = lane & 31), and walks the B rows in tiles of 32 (the MFMA's A operand,
 // M = B row = accumulator ROW), 8 MFMAs per tile.  Each lane then holds 16 distances of ONE A row to 16 different B
 // rows and feeds them to its private sorted top-4 (key = distance << 12 | B index); lanes l and l + 32 share an A
-// row and merge at the end.  The 4 waves of a workgroup (128 A rows) share every B tile: the workgroup expands the
-// tile's 32 x 256 bits to bytes once (one dword per thread -> 32 B) into LDS, double buffered, and each wave reads its
-// 8 fragments back with ds_read_b128 (row stride 272 B: conflict free).  Lane maps of the i8 MFMA verified with
+// row and merge at the end.  The 8 waves of a workgroup (256 A rows) share every B tile: the workgroup expands the
+// tile's 64 x 256 bits to bytes once (one dword per thread -> 32 B) into LDS, double buffered, and each wave reads its
+// 16 fragments back with ds_read_b128 (row stride 272 B: conflict free).  Lane maps of the i8 MFMA verified with
 // exact integer data: tools/ubench/mfma_i8_probe.hip.
 // Only B rows within dmax of the A row are listed, dmax = the largest distance that can change a decision of pass 2:
 // a best beyond th_low is rejected whatever it is, and a second best b2 with nnratio * b2 > th_low passes every
 // ratio test (ORBmatcher.cc:228-231), so a list that ends early means "nothing else matters" exactly like a list
 // that ran out of B rows.
-// grid = (ceil(cap / 128), pairs, nsplit): the B rows are split into nsplit contiguous ranges to put enough
+// grid = (ceil(cap / 256), pairs, nsplit): the B rows are split into nsplit contiguous ranges to put enough
 // waves in flight (2 for a full batch, up to BF_MAX_SPLIT for a single pair, where the scan is latency bound);
 // k_bf_resolve merges the partial lists (4 smallest of their union).
 constexpr int BF_MIN_SPLIT = 2, BF_MAX_SPLIT = 16;
 constexpr size_t BF_RESOLVE_MAX_LDS = 150 * 1024;  // of the CU's 160 KB; static LDS of k_bf_resolve is < 1 KB
 constexpr int BF_TILE_STRIDE = 272;                // bytes per expanded B row in LDS (256 + 16: bank spread)
 constexpr int BF_TILE_ROWS = 64;                   // B rows staged per iteration
+constexpr int BF_TOPK_THREADS = 512;               // 8 waves = 256 A rows share every staged B tile
+constexpr int BF_TOPK_ROWS = BF_TOPK_THREADS / 64 * 32;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -104,7 +106,7 @@ __device__ __forceinline__ v4i bf_expand16(uint32_t hw)
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
+__global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
                                                  const int *__restrict__ nb_p, uint32_t *__restrict__ topk,
                                                  int acc_min)
@@ -114,11 +116,11 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
     const int pair = blockIdx.y;
     const int na = min(na_p[pair], cap);
     const int nb = min(nb_p[pair], cap);
-    if ((int)(blockIdx.x * 128) >= na)
+    if ((int)(blockIdx.x * BF_TOPK_ROWS) >= na)
         return;  // the whole workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int i = blockIdx.x * 128 + wave * 32 + r;  // this lane's A row (= accumulator column)
+    const int i = blockIdx.x * BF_TOPK_ROWS + wave * 32 + r;  // this lane's A row (= accumulator column)
     // the A rows of this wave as the MFMA's B operand: fragment s holds k = 32 s + 16 h .. + 15 = halfword 2 s + h
     v4i fa[8];
     {
@@ -132,40 +134,31 @@ __global__ __launch_bounds__(256) void k_bf_topk(int cap, const uint8_t *__restr
     const int ntiles = (jend - jbeg + BF_TILE_ROWS - 1) / BF_TILE_ROWS;
     const uint32_t *gb = reinterpret_cast<const uint32_t *>(desc_b + (size_t)pair * cap * 32);
     // staging: a tile is BF_TILE_ROWS = 64 B rows (two MFMA row blocks, i.e. two independent accumulator chains per
-    // iteration and half as many barriers); thread t expands dword (t & 7) of tile rows (t >> 3) and 32 + (t >> 3):
-    // two fragments = 32 contiguous bytes each.  The dwords of tile + 2 are requested while tile is multiplied, so
-    // their latency never sits in front of an expansion.
-    const int sm = tid >> 3, sw = tid & 7;
-    auto fetch = [&](int tile, uint32_t d[2]) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int j = min(jbeg + tile * BF_TILE_ROWS + 32 * u + sm, nb - 1);  // past the end: repeats (never selected)
-            d[u] = gb[(size_t)j * 8 + sw];
-        }
+    // iteration and half as many barriers); thread t expands dword (t & 7) of tile row (t >> 3): two
+    // fragments = 32 contiguous bytes.  The dword of tile + 2 is requested while tile is multiplied, so its latency
+    // never sits in front of an expansion.
+    const int sm = tid >> 3, sw = tid & 7;  // tile row 0..63, dword 0..7: one dword per thread
+    auto fetch = [&](int tile) {
+        const int j = min(jbeg + tile * BF_TILE_ROWS + sm, nb - 1);  // past the end: repeats (never selected)
+        return gb[(size_t)j * 8 + sw];
     };
-    auto stage = [&](const uint32_t d[2], int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            v4i *dst = reinterpret_cast<v4i *>(&s_tile[buf][(32 * u + sm) * BF_TILE_STRIDE + sw * 32]);
-            dst[0] = bf_expand16(d[u]);
-            dst[1] = bf_expand16(d[u] >> 16);
-        }
+    auto stage = [&](uint32_t d, int buf) {
+        v4i *dst = reinterpret_cast<v4i *>(&s_tile[buf][sm * BF_TILE_STRIDE + sw * 32]);
+        dst[0] = bf_expand16(d);
+        dst[1] = bf_expand16(d >> 16);
     };
     uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
     int lim = acc_min;  // accumulator value a distance must reach to be inserted
-    uint32_t d_next[2] = {0, 0};
-    if (ntiles > 0) {
-        uint32_t d0[2];
-        fetch(0, d0);
-        stage(d0, 0);
-    }
+    uint32_t d_next = 0;
+    if (ntiles > 0)
+        stage(fetch(0), 0);
     if (ntiles > 1)
-        fetch(1, d_next);
+        d_next = fetch(1);
     __syncthreads();
     for (int tile = 0; tile < ntiles; tile++) {
-        const uint32_t d_cur[2] = {d_next[0], d_next[1]};
+        const uint32_t d_cur = d_next;
         if (tile + 2 < ntiles)
-            fetch(tile + 2, d_next);
+            d_next = fetch(tile + 2);
         if (tile + 1 < ntiles)
             stage(d_cur, (tile + 1) & 1);
         const uint8_t *tb = &s_tile[tile & 1][r * BF_TILE_STRIDE + h * 16];
@@ -614,16 +607,16 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
     uint32_t *topk = m->d_topk.as<uint32_t>();
     // enough waves to cover the device (~2048) while the partial lists fit the buffer sized at creation
     int nsplit = BF_MIN_SPLIT;
-    while (nsplit < BF_MAX_SPLIT && (size_t)pairs * ((cap + 127) / 128) * 4 * nsplit < 2048 &&
+    while (nsplit < BF_MAX_SPLIT && (size_t)pairs * ((cap + BF_TOPK_ROWS - 1) / BF_TOPK_ROWS) * (BF_TOPK_THREADS / 64) * nsplit < 2048 &&
            (size_t)pairs * nsplit * 2 <= std::max<size_t>((size_t)m->max_pairs * BF_MIN_SPLIT, BF_MAX_SPLIT))
         nsplit *= 2;
-    const dim3 grid((cap + 127) / 128, pairs, nsplit);
+    const dim3 grid((cap + BF_TOPK_ROWS - 1) / BF_TOPK_ROWS, pairs, nsplit);
     // largest second-best distance that can still fail the ratio test for some best <= th_low (same float
     // arithmetic as the test itself, which is monotone in the second distance)
     int dmax = std::min(std::max(th_low, 0), 256);
     while (dmax < 256 && !(nnratio * (float)(dmax + 1) > (float)th_low))
         dmax++;
-    hipLaunchKernelGGL(k_bf_topk, grid, dim3(256), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk, 256 - 2 * dmax);
+    hipLaunchKernelGGL(k_bf_topk, grid, dim3(BF_TOPK_THREADS), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk, 256 - 2 * dmax);
     // claim / match / queue tables (16 B per row) + the B descriptors (32 B per row) when both fit in LDS
     const int stage_b = (size_t)48 * cap <= BF_RESOLVE_MAX_LDS ? 1 : 0;
     const size_t lds = (size_t)(stage_b ? 48 : 16) * cap;
