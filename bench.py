@@ -220,7 +220,9 @@ def main():
     torch.cuda.synchronize()
     stage_ms = ext.stage_times()
     ext.set_profiling(False)
-    match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0)
+    # serial schedule only: what the step spends outside the extraction stages = the matcher (+ 3 small copies);
+    # with the matcher on its own stream the difference is not a duration of anything
+    match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0) if not args.overlap_match else None
 
     elapsed_max, total_frames = D.aggregate(elapsed, B * args.steps, world,
                                             device="cuda" if args.backend == "nccl" else "cpu")
@@ -278,7 +280,7 @@ def main():
                          "algorithmic_bytes": algorithmic_bytes(dom, n_kp, n_cand) * B,
                          "ms_per_launch": stage_ms[dom], "frames_per_launch": B},
             "stages": per_stage,
-            "match_ms_per_step": round(match_ms, 4),
+            "match_ms_per_step": None if match_ms is None else round(match_ms, 4),
             "keypoints_per_frame": n_kp,
             "matches_per_frame": float(nm_host.mean()),
             "bf_sweeps_max": int(sweeps.max()),

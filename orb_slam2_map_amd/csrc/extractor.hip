@@ -1080,14 +1080,15 @@ struct UMax {
 // byte-weight tables built once per workgroup in LDS: W10 holds (u+16) inside the disc (0 outside),
 // M01 holds 1 inside the disc, so  sum u*I = dot(W10) - 16*dot(M01)  and  sum I = dot(M01).
 // Integer moments: exact in any summation order.
-constexpr int OR_ITERS = 4;
+constexpr int OR_ITERS = 4;  // key points per half wave for full batches (1 below OR_BATCH_MIN frames: latency)
+constexpr int OR_BATCH_MIN = 32;
 
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                 const LevelGeom *__restrict__ geom, int nlevels,
                                                 const uint32_t *__restrict__ sel, int sel_cap_total,
                                                 const int *__restrict__ nsel, UMax um,
                                                 orbgpu_keypoint *__restrict__ kps, KpAux *__restrict__ aux,
-                                                int cap, int *__restrict__ n_out)
+                                                int cap, int *__restrict__ n_out, int iters)
 {
     __shared__ uint32_t W10[4 * 16 * 9], M01[4 * 16 * 9];
     for (int i = threadIdx.x; i < 4 * 16 * 9; i += 256) {
@@ -1111,9 +1112,9 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     int bx, f;
     xcd_frame_block(bx, f);
     const int *ns = nsel + (size_t)f * nlevels;
-    // OR_ITERS slots per half wave: the weight tables above are built once per 8 * OR_ITERS key points
-    for (int it = 0; it < OR_ITERS; it++) {
-    const int slot = (bx * OR_ITERS + it) * 8 + (threadIdx.x >> 5);
+    // `iters` slots per half wave: the weight tables above are built once per 8 * iters key points
+    for (int it = 0; it < iters; it++) {
+    const int slot = (bx * iters + it) * 8 + (threadIdx.x >> 5);
     // locate (level, j) of this slot and the output offset
     int level = -1, j = 0, out_off = 0, total = 0;
     bool bad = false;
@@ -1822,9 +1823,10 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap);
     END(ST_QUADTREE, st);
     BEGIN(ST_ORIENT, st);
-    hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 8 * OR_ITERS - 1) / (8 * OR_ITERS), batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
+    const int or_iters = batch >= OR_BATCH_MIN ? OR_ITERS : 1;
+    hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 8 * or_iters - 1) / (8 * or_iters), batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
-                       e->d_aux.as<KpAux>(), cap, d_n_out);
+                       e->d_aux.as<KpAux>(), cap, d_n_out, or_iters);
     hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
                        e->d_aux.as<KpAux>(), d_n_out, cap);
     END(ST_ORIENT, st);
