@@ -173,31 +173,41 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
         // acc[reg] = 256 - 2 * hamming(A row i, B row j0 + (reg & 3) + 8 (reg >> 2) + 4 h).  Only distances <= dmax
         // can influence a decision (see the host side), i.e. acc >= acc_min: most row blocks hold no such value for any
         // lane of the wave and are dismissed with 8 v_max3 and one branch.
-        const bool full = jbeg + (tile + 1) * BF_TILE_ROWS <= jend;  // no row of this tile lies past the range
+        // Selection.  A lane's 16 values per row block rarely hold anything that beats its list, but SOME lane of the
+        // wave nearly always does, so a test-and-branch per value would run every insert body for the whole wave.
+        // Instead each value is tagged with its register index (e = acc << 4 | 15 - reg: larger = closer, then lower
+        // B row), a lane's best candidate is one v_max3 tree away, and the wave loops only while some lane still has
+        // a candidate above its bar: one insert per lane per trip, typically one or two trips per block.
+        const int jlast = jend - 1;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             const v16i &acc = u ? acc1 : acc0;
-            // maxima of the four register groups (= 4 consecutive B rows each), then of the block
-            int gmax[4];
+            int e[16];
 #pragma unroll
-            for (int g = 0; g < 4; g++)
-                gmax[g] = max(max(acc[4 * g], acc[4 * g + 1]), max(acc[4 * g + 2], acc[4 * g + 3]));
-            const int best = max(max(gmax[0], gmax[1]), max(gmax[2], gmax[3]));
-            if (__any(best >= lim)) {
-                const int j0 = jbeg + tile * BF_TILE_ROWS + 32 * u + 4 * h;
+            for (int reg = 0; reg < 16; reg++)
+                e[reg] = (acc[reg] << 4) | (15 - reg);
+            const int j0 = jbeg + tile * BF_TILE_ROWS + 32 * u + 4 * h;
+            for (;;) {
+                int m = max(max(e[0], e[1]), e[2]);
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    if (!__any(gmax[g] >= lim))
-                        continue;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int reg = 4 * g + q, j = j0 + q + 8 * g;
-                        if (acc[reg] >= lim && (full || j < jend))
-                            top4_insert(t, (uint32_t)(((256 - acc[reg]) << 11) + j));  // (2 ham) << 11 = ham << 12
+                for (int reg = 3; reg < 15; reg += 2)
+                    m = max(max(m, e[reg]), e[reg + 1]);
+                m = max(m, e[15]);
+                const bool hit = (m >> 4) >= lim;
+                if (!__any(hit))
+                    break;
+                if (hit) {
+                    const int reg = 15 - (m & 15);
+                    const int j = j0 + (reg & 3) + 8 * (reg >> 2);
+                    if (j <= jlast) {
+                        top4_insert(t, (uint32_t)(((256 - (m >> 4)) << 11) + j));  // (2 ham) << 11 = ham << 12
+                        if (t[3] != BF_KEY_NONE)
+                            lim = max(lim, 256 - 2 * (int)(t[3] >> 12));  // a full list admits distances <= its last
                     }
+#pragma unroll
+                    for (int r2 = 0; r2 < 16; r2++)
+                        e[r2] = e[r2] == m ? INT_MIN : e[r2];  // taken
                 }
-                if (t[3] != BF_KEY_NONE)
-                    lim = max(lim, 256 - 2 * (int)(t[3] >> 12));  // a full list only admits distances <= its last
             }
         }
         __syncthreads();
