@@ -112,8 +112,8 @@ def cpu_baseline(frames, seconds_budget=18.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per step and per GPU")
     ap.add_argument("--pool", type=int, default=1024, help="distinct resident frames cycled through (> Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

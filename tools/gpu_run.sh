@@ -20,7 +20,7 @@ case $step in
 tests) run tests 900 bash -c "python -m pytest tests -m gpu -q -x --timeout 600 > $OUT/pytest_gpu.log 2>&1; tail -15 $OUT/pytest_gpu.log" ;;
 testsall) run tests 900 bash -c "python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_gpu.log 2>&1; tail -25 $OUT/pytest_gpu.log" ;;
 smoke) run smoke 300 bash -c "python -c 'import __graft_entry__ as g; g.smoke()' > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log" ;;
-bench) run bench 420 bash -c "python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err" ;;
+bench) run bench 420 bash -c "python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 3000 $OUT/bench.json; tail -5 $OUT/bench.err" ;;
 prof) run prof 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; tail -3 $OUT/prof.err; find $OUT/prof -name '*stats*' | head" ;;
 pmc) run pmc 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --batch 64 --pool 256 --no-cpu-baseline > $OUT/pmc1.json 2> $OUT/pmc1.err; tail -2 $OUT/pmc1.err"
      run pmc2 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --batch 64 --pool 256 --no-cpu-baseline > $OUT/pmc2.json 2> $OUT/pmc2.err; tail -2 $OUT/pmc2.err" ;;
