@@ -255,46 +255,58 @@ __device__ __forceinline__ pk16 pkmax(pk16 a, pk16 b) { return __builtin_element
 // bytes).  With d = c - p:  max over arcs of min(d) = c - min over arcs of max(p)  (dark arcs) and
 // max over arcs of min(-d) = max over arcs of min(p) - c  (bright arcs), so the networks run on the raw
 // ring values and the 16 subtractions disappear.
-// The 16 circular windows of 9 are evaluated with block prefix/suffix extrema (van Herk): the ring is
-// split into two blocks of 8; window [k, k+8] = suffix of k's block from k  +  prefix of the next block
-// up to k+8, so ext9[k] = ext(S[k], P[(k+8) & 15]).  59 packed ops per polarity instead of 79.
+// gfx950 has packed THREE-input extrema only for f16 (v_pk_maximum3_f16 / v_pk_minimum3_f16).  A 16-bit lane
+// holding an integer 0..255 is, read as f16, the subnormal n * 2^-24: positive f16 bit patterns order like the
+// integers they are, f16 denormals are never flushed on this target, and no value is a NaN, so the f16 extrema of
+// the bit patterns ARE the integer extrema.  With 3-input ops the 16 circular windows of 9 cost
+//   M3[k] = ext3(v[k], v[k+1], v[k+2])            (16 ops)
+//   W9[k] = ext3(M3[k], M3[k+3], M3[k+6])          (16 ops)
+// and the reduction over the 16 windows 8 more: 40 packed ops per polarity (59 with the two-input van Herk
+// prefix/suffix scheme this replaces, 79 before that).
+typedef _Float16 pkh __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pkh as_h(pk16 v) { return __builtin_bit_cast(pkh, v); }
+__device__ __forceinline__ pk16 h_as_pk(pkh v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ pkh hmax3(pkh a, pkh b, pkh c)
+{
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
+}
+__device__ __forceinline__ pkh hmin3(pkh a, pkh b, pkh c)
+{
+    return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c);
+}
+
 __device__ __forceinline__ pk16 fast_score_pk(pk16 c, const pk16 p[16])
 {
-    pk16 P[16], S[16];
+    pkh v[16], m3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        v[k] = as_h(p[k]);
     // ---- dark arcs: A = min over windows of the window maximum
 #pragma unroll
-    for (int b = 0; b < 16; b += 8) {
-        P[b] = p[b];
+    for (int k = 0; k < 16; k++)
+        m3[k] = hmax3(v[k], v[(k + 1) & 15], v[(k + 2) & 15]);
+    pkh w[16];
 #pragma unroll
-        for (int i = 1; i < 8; i++)
-            P[b + i] = pkmax(P[b + i - 1], p[b + i]);
-        S[b + 7] = p[b + 7];
+    for (int k = 0; k < 16; k++)
+        w[k] = hmax3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+    pkh a5[5];
 #pragma unroll
-        for (int i = 6; i >= 0; i--)
-            S[b + i] = pkmax(S[b + i + 1], p[b + i]);
-    }
-    pk16 A = pkmax(S[0], P[8]);
-#pragma unroll
-    for (int k = 1; k < 16; k++)
-        A = pkmin(A, pkmax(S[k], P[(k + 8) & 15]));
+    for (int k = 0; k < 5; k++)
+        a5[k] = hmin3(w[3 * k], w[3 * k + 1], w[3 * k + 2]);
+    const pkh A = __builtin_elementwise_minimum(hmin3(a5[0], a5[1], a5[2]), hmin3(a5[3], a5[4], w[15]));
     // ---- bright arcs: B = max over windows of the window minimum
 #pragma unroll
-    for (int b = 0; b < 16; b += 8) {
-        P[b] = p[b];
+    for (int k = 0; k < 16; k++)
+        m3[k] = hmin3(v[k], v[(k + 1) & 15], v[(k + 2) & 15]);
 #pragma unroll
-        for (int i = 1; i < 8; i++)
-            P[b + i] = pkmin(P[b + i - 1], p[b + i]);
-        S[b + 7] = p[b + 7];
+    for (int k = 0; k < 16; k++)
+        w[k] = hmin3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
 #pragma unroll
-        for (int i = 6; i >= 0; i--)
-            S[b + i] = pkmin(S[b + i + 1], p[b + i]);
-    }
-    pk16 B = pkmin(S[0], P[8]);
-#pragma unroll
-    for (int k = 1; k < 16; k++)
-        B = pkmax(B, pkmin(S[k], P[(k + 8) & 15]));
+    for (int k = 0; k < 5; k++)
+        a5[k] = hmax3(w[3 * k], w[3 * k + 1], w[3 * k + 2]);
+    const pkh B = __builtin_elementwise_maximum(hmax3(a5[0], a5[1], a5[2]), hmax3(a5[3], a5[4], w[15]));
     const pk16 zero = {0, 0};
-    return pkmax(pkmax(c - A, B - c), zero);  // values are in [0,255]
+    return pkmax(pkmax(c - h_as_pk(A), h_as_pk(B) - c), zero);  // values are in [0,255]
 }
 
 // v_perm selectors that zero-extend bytes (o, o+2) resp. (o+1, o+3) of the 8-byte pair {lo,hi}
