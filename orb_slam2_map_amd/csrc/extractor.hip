@@ -233,8 +233,9 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
 //     [0,255].  A pixel is a FAST corner for threshold t  <=>  s > t, and cv::FAST's cornerScore is
 //     s-1, so one map serves both thresholds.  Register-only streaming like k_blur: a thread owns 4
 //     pixels x FS_ROWS rows, keeps a 7-row x 12-byte window in registers, unpacks ring bytes with
-//     v_perm_b32 into packed 16-bit lanes and runs the min/max network with v_pk_min/max_i16 (two
-//     pixels per instruction, no divergence, no LDS).
+//     v_perm_b32 into packed 16-bit lanes and runs the min/max network with three-input packed extrema
+//     (v_pk_maximum3_f16 / v_pk_minimum3_f16 on the integer bit patterns: two pixels per instruction, no
+//     divergence, no LDS).
 //  k_fast_nmsbits -- streaming strict 3x3 non-maximum suppression restricted to each 30-px cell's
 //     interior (cv::FAST sees only the sub-image: neighbours outside count as 0); emits survivor bits
 //     for minThFAST and iniThFAST.
