@@ -469,8 +469,9 @@ __device__ __forceinline__ uint32_t nms_bits(const NmsRow &u, const NmsRow &c, c
                                              pk16 tmin, pk16 tini)
 {
     const uint32_t um = (rf & 1u) ? 0xFFFFFFFFu : 0u, dm = (rf & 2u) ? 0xFFFFFFFFu : 0u;
-    const pk16 nbE = pkmax(c.HE, pkmax(as_pk(as_u32(u.VE) & um), as_pk(as_u32(d.VE) & dm)));
-    const pk16 nbO = pkmax(c.HO, pkmax(as_pk(as_u32(u.VO) & um), as_pk(as_u32(d.VO) & dm)));
+    // three-input packed maximum on the bit patterns (see fast_score_pk)
+    const pk16 nbE = h_as_pk(hmax3(as_h(c.HE), as_h(as_pk(as_u32(u.VE) & um)), as_h(as_pk(as_u32(d.VE) & dm))));
+    const pk16 nbO = h_as_pk(hmax3(as_h(c.HO), as_h(as_pk(as_u32(u.VO) & um)), as_h(as_pk(as_u32(d.VO) & dm))));
     // x > y  <=>  sign(y - x); all values are in [0,255]
     const uint32_t sE = as_u32(nbE - c.E), sO = as_u32(nbO - c.O);
     const uint32_t minE = sE & as_u32(tmin - c.E), minO = sO & as_u32(tmin - c.O);
