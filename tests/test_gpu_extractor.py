@@ -174,6 +174,26 @@ def test_dense_corners_high_candidate_count(gpu, oracle):
     assert_same_keypoints(gk, gd, ok, od, "checkerboard")
 
 
+def test_full_value_range_extremes(gpu, oracle):
+    """Salt-and-pepper blobs and uniform noise over the whole 0..255 range: ring values 0 and 255, centre minus ring
+    differences up to +-255 and corner scores up to the 255 clamp.  The score network compares the 16-bit integer
+    lanes as f16 bit patterns (subnormals), so the extremes of the range are the cases to pin."""
+    rng = np.random.default_rng(29)
+    img = rng.integers(0, 256, (480, 640)).astype(np.uint8)
+    img[100:200, 100:300] = 0
+    img[250:330, 330:600] = 255
+    for _ in range(400):
+        cx, cy = rng.integers(20, 620), rng.integers(20, 460)
+        img[cy:cy + rng.integers(1, 4), cx:cx + rng.integers(1, 4)] = rng.choice([0, 255])
+    ge = gpu.ORBextractor(1000)
+    oe = oracle.Extractor(1000)
+    gk, gd = ge(img)
+    ok, od = oe.extract(img)
+    assert len(ok) > 900 and ok["response"].max() >= 200
+    check_stages(gpu, ge, oe, 0, 8, "extremes")
+    assert_same_keypoints(gk, gd, ok, od, "extremes")
+
+
 def test_too_small_image_is_rejected(gpu):
     ge = gpu.ORBextractor(1000)
     with pytest.raises(gpu.OrbGpuError) as ei:
