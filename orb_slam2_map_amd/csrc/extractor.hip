@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
                                                      const LevelGeom *__restrict__ geom, int level,
                                                      const ResizeStrip *__restrict__ strips,
                                                      const uint4 *__restrict__ sels, const uint4 *__restrict__ wts,
-                                                     const YTab *__restrict__ ytab, int strip_off)
+                                                     const YTab *__restrict__ ytab, int strip_off, int rows)
 {
     const LevelGeom g = geom[level];
     const LevelGeom gs = geom[level - 1];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     const int item = bx * 256 + threadIdx.x;  // (row group, output dword column), flattened
     const int rg = item / ndw;
     const int sdw = item - rg * ndw;
-    if (rg * PYR_ROWS >= g.h + 2 * EDGE)
+    if (rg * rows >= g.h + 2 * EDGE)
         return;
     const uint32_t bq = strips[strip_off + sdw].base_q;
     const uint4 sel = sels[strip_off + sdw], wt = wts[strip_off + sdw];
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + (bq & 0xFFFFu);
     uint8_t *dst = pyr + (size_t)f * frame_pyr + g.plane_off + sdw * 4;
 #pragma unroll 2
-    for (int rr = 0; rr < PYR_ROWS; rr++) {
-        const int py = rg * PYR_ROWS + rr;
+    for (int rr = 0; rr < rows; rr++) {
+        const int py = rg * rows + rr;
         if (py >= g.h + 2 * EDGE)
             break;
         const int dy = reflect101(py - EDGE, g.h);
@@ -1807,11 +1807,14 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
         for (int l = 1; l < nl; l++) {
             const LevelGeom &gl = e->geom[l];
             dim3 gr((gl.pitch / 4 + 255) / 256, gl.h + 2 * EDGE, batch);
-            dim3 grf(((gl.pitch / 4) * ((gl.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS) + 255) / 256, batch);
+            // rows per thread: 8 on the large levels; the small ones get more (shorter) threads to hide latency with
+            const int ndw_l = (gl.pitch / 4) * (gl.h + 2 * EDGE);
+            const int rows = ndw_l >= 32768 ? PYR_ROWS : ndw_l >= 16384 ? PYR_ROWS / 2 : PYR_ROWS / 4;
+            dim3 grf(((gl.pitch / 4) * ((gl.h + 2 * EDGE + rows - 1) / rows) + 255) / 256, batch);
             if (gl.rs_fast)
                 hipLaunchKernelGGL(k_resize_fast, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
                                    e->d_rstrip.as<ResizeStrip>(), e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(),
-                                   e->d_ytab.as<YTab>(), gl.rs_off);
+                                   e->d_ytab.as<YTab>(), gl.rs_off, rows);
             else
                 hipLaunchKernelGGL(k_resize_level, gr, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
                                    e->d_xtab.as<XTab>(), e->d_ytab.as<YTab>());
