@@ -46,7 +46,7 @@ def algorithmic_bytes(stage, n_kp, n_cand):
     if stage == "fast_score":
         return tot  # every level read once (the score map it writes is an intermediate, not counted)
     if stage == "fast_nms":
-        return tot + 4 * n_cand  # score map read once + surviving keys written
+        return tot + 4 * n_cand  # score map read once (NMS + cell logic in one kernel) + surviving keys written
     if stage == "blur":
         return 2 * tot
     if stage == "orient":
@@ -59,7 +59,7 @@ def algorithmic_bytes(stage, n_kp, n_cand):
 
 
 STAGE_KERNELS = {"pyramid": ["k_border0"] + ["k_resize_fast"] * 7, "fast_score": ["k_fast_score"],
-                 "fast_nms": ["k_fast_nmsbits", "k_fast_cells"], "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
+                 "fast_nms": ["k_fast_cells"], "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
                  "blur": ["k_blur"], "describe": ["k_describe"]}
 
 

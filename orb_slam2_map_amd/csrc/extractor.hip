@@ -38,7 +38,6 @@ struct LevelGeom {
     float scale;
     int patch;
     int xtab_off, ytab_off;  // resize tables (levels >= 1)
-    int cm_off, rf_off;      // NMS tables: column masks per padded dword, row flags per image row
     int rs_off, rs_fast;     // fast-path strip tables (k_resize_fast); rs_fast = 0 -> k_resize_level
 };
 
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
 // K2: FAST-9/16 with NMS and per-cell threshold fallback
 //     (ORBextractor.cc:789-829 calling cv::FAST(sub, kps, th, true), A4)
 //
-// Three kernels.
+// Two kernels.
 //  k_fast_score  -- the corner score map s(x,y) of every level: s = max over the 16 arcs of 9
 //     contiguous ring pixels of the minimum |centre - ring| (dark and bright polarity), clamped to
 //     [0,255].  A pixel is a FAST corner for threshold t  <=>  s > t, and cv::FAST's cornerScore is
@@ -236,12 +235,10 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
 //     v_perm_b32 into packed 16-bit lanes and runs the min/max network with three-input packed extrema
 //     (v_pk_maximum3_f16 / v_pk_minimum3_f16 on the integer bit patterns: two pixels per instruction, no
 //     divergence, no LDS).
-//  k_fast_nmsbits -- streaming strict 3x3 non-maximum suppression restricted to each 30-px cell's
-//     interior (cv::FAST sees only the sub-image: neighbours outside count as 0); emits survivor bits
-//     for minThFAST and iniThFAST.
-//  k_fast_cells   -- one half wave per cell: chooses iniThFAST or (empty cell) minThFAST and writes the
-//     survivors in row-major order (cv::FAST's output order, which the quadtree's "first maximum"
-//     rule depends on).
+//  k_fast_cells   -- one half wave per cell: strict 3x3 non-maximum suppression restricted to the cell's
+//     interior (cv::FAST sees only the sub-image: neighbours outside count as 0), iniThFAST or (empty
+//     cell) minThFAST, survivors written in row-major order (cv::FAST's output order, which the
+//     quadtree's "first maximum" rule depends on).
 // ---------------------------------------------------------------------------------------------
 constexpr int FS_ROWS = 28;   // output rows per strip (4 x 7)
 constexpr int MAX_CELL = 66;  // max cell interior edge
@@ -435,207 +432,199 @@ __global__ __launch_bounds__(256) void k_fast_score(const uint8_t *__restrict__ 
 #undef FS_LOAD
 }
 
-// k_fast_nmsbits: streaming 3x3 non-maximum suppression over the score map with the cell structure
-// of the reference folded in: a pixel survives iff its score is strictly greater than the scores of its
-// 8 neighbours THAT LIE INSIDE THE SAME CELL INTERIOR (cv::FAST sees only the cell's sub-image, so
-// outside neighbours count as 0).  Because a survivor at the lower threshold with s > t_hi is also a
-// survivor at t_hi (a neighbour with s_n <= t_hi cannot beat it), one NMS serves both thresholds:
-//   survivor(t)  <=>  s > max(t, 1)  and  s > every in-cell neighbour.
-// Output: one byte per aligned group of 4 pixels; bits 0..3 = survivor at minThFAST, bits 4..7 =
-// survivor at iniThFAST.  Same register-streaming shape as k_blur (3-row window, packed 16-bit).
-constexpr int NB_ROWS = 30;  // output rows per strip (multiple of 3: the 3-row ring unrolls evenly)
-
-struct NmsRow {
-    pk16 E, O;    // scores of (px0,px2) and (px1,px3)
-    pk16 HE, HO;  // max of their masked left/right neighbours
-    pk16 VE, VO;  // max(H, own): what this row contributes to the rows above / below
-};
-
-__device__ __forceinline__ void nms_row(const uint32_t d0, const uint32_t d1, const uint32_t d2, const uint4 cm,
-                                        NmsRow &r)
-{
-    // window bytes 0..11 = padded columns 4c-4 .. 4c+7; px p at byte 4+p; left of px0 = byte 3, right of px3 = byte 8
-    const pk16 LE = as_pk(__builtin_amdgcn_perm(d1, d0, ORBGPU_SEL_EVEN(3)));  // (b3, b5)
-    r.E = as_pk(__builtin_amdgcn_perm(d2, d1, ORBGPU_SEL_EVEN(0)));            // (b4, b6)
-    r.O = as_pk(__builtin_amdgcn_perm(d2, d1, ORBGPU_SEL_ODD(0)));             // (b5, b7)
-    const pk16 RO = as_pk(__builtin_amdgcn_perm(d2, d1, ORBGPU_SEL_EVEN(2)));  // (b6, b8)
-    r.HE = pkmax(as_pk(as_u32(LE) & cm.x), as_pk(as_u32(r.O) & cm.y));
-    r.HO = pkmax(as_pk(as_u32(r.E) & cm.z), as_pk(as_u32(RO) & cm.w));
-    r.VE = pkmax(r.HE, r.E);
-    r.VO = pkmax(r.HO, r.O);
-}
-
-__device__ __forceinline__ uint32_t nms_bits(const NmsRow &u, const NmsRow &c, const NmsRow &d, uint32_t rf,
-                                             pk16 tmin, pk16 tini)
-{
-    const uint32_t um = (rf & 1u) ? 0xFFFFFFFFu : 0u, dm = (rf & 2u) ? 0xFFFFFFFFu : 0u;
-    // three-input packed maximum on the bit patterns (see fast_score_pk)
-    const pk16 nbE = h_as_pk(hmax3(as_h(c.HE), as_h(as_pk(as_u32(u.VE) & um)), as_h(as_pk(as_u32(d.VE) & dm))));
-    const pk16 nbO = h_as_pk(hmax3(as_h(c.HO), as_h(as_pk(as_u32(u.VO) & um)), as_h(as_pk(as_u32(d.VO) & dm))));
-    // x > y  <=>  sign(y - x); all values are in [0,255]
-    const uint32_t sE = as_u32(nbE - c.E), sO = as_u32(nbO - c.O);
-    const uint32_t minE = sE & as_u32(tmin - c.E), minO = sO & as_u32(tmin - c.O);
-    const uint32_t iniE = sE & as_u32(tini - c.E), iniO = sO & as_u32(tini - c.O);
-    // px0 = E.lo (bit 15), px1 = O.lo, px2 = E.hi (bit 31), px3 = O.hi
-    return ((minE >> 15) & 1u) | ((minO >> 14) & 2u) | ((minE >> 29) & 4u) | ((minO >> 28) & 8u) |
-           ((iniE >> 11) & 16u) | ((iniO >> 10) & 32u) | ((iniE >> 25) & 64u) | ((iniO >> 24) & 128u);
-}
-
-__global__ __launch_bounds__(256) void k_fast_nmsbits(const uint8_t *__restrict__ smap, uint8_t *__restrict__ bits,
-                                                      size_t frame_pyr, const LevelGeom *__restrict__ geom,
-                                                      StripGeom sg, const uint4 *__restrict__ colmask,
-                                                      const uint8_t *__restrict__ rowflag, int ini_th, int min_th)
-{
-    int bx, f;
-    xcd_frame_block(bx, f);
-    const int strip = bx * 256 + threadIdx.x;
-    if (strip >= sg.first[sg.nlevels])
-        return;
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < ORBGPU_MAX_LEVELS; l++)
-        level += (l < sg.nlevels && strip >= sg.first[l]) ? 1 : 0;
-    const LevelGeom g = geom[level];
-    const int local = strip - sg.first[level];
-    const int sy = local / sg.nsx[level], sx = local - sy * sg.nsx[level];
-    const int dwc = 9 + sx;  // padded dword column (detection region starts in dword 9)
-    const int col = dwc * 4;
-    const int y0 = EDGE + sy * NB_ROWS;
-    const int rows = min(NB_ROWS, g.h - EDGE - y0);
-    const size_t plane = (size_t)f * frame_pyr + g.plane_off;
-    const uint8_t *src = smap + plane + (size_t)(y0 + EDGE - 1) * g.pitch + (col - 4);
-    uint8_t *dst = bits + (plane >> 2) + (size_t)(y0 + EDGE) * (g.pitch >> 2) + dwc;
-    const uint4 cm = colmask[g.cm_off + dwc];
-    const uint8_t *rf = rowflag + g.rf_off + y0;
-    const short t1 = (short)max(min_th, 1), t2 = (short)max(ini_th, 1);
-    const pk16 tmin = {t1, t1}, tini = {t2, t2};
-
-    NmsRow a, b, c;
-#define NB_LOAD(R, row)                                                                                      \
-    {                                                                                                        \
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);               \
-        nms_row(q[0], q[1], q[2], cm, R);                                                                    \
-    }
-#define NB_STEP(U, C, D, k)                                                                                  \
-    if ((k) < rows) {                                                                                        \
-        NB_LOAD(D, (k) + 2)                                                                                  \
-        dst[(size_t)(k) * (g.pitch >> 2)] = (uint8_t)nms_bits(U, C, D, rf[k], tmin, tini);                   \
-    }
-    NB_LOAD(a, 0) NB_LOAD(b, 1)
-#pragma unroll 1
-    for (int k = 0; k < NB_ROWS; k += 3) {
-        NB_STEP(a, b, c, k)
-        NB_STEP(b, c, a, k + 1)
-        NB_STEP(c, a, b, k + 2)
-    }
-#undef NB_STEP
-#undef NB_LOAD
-}
-
-// k_fast_cells: one HALF wave per (cell, frame), one lane per interior row (the usual 30-row cell fills 30 of the
-// 32 lanes; taller border cells take up to three row groups).  A lane gathers its row's survivor bits (<= 96
-// pixels) into two 64-bit masks, the half wave decides iniThFAST vs minThFAST (ORBextractor.cc:809-816: the
-// fallback applies when the iniThFAST pass leaves the cell empty), a prefix sum of the per-row counts gives every
-// row its output offset, every row lane drops (iy, ix) of its survivors into the half wave's LDS list (no memory
-// latency), and the list is emitted with one survivor per lane -- row-major order, cv::FAST's output order, with
-// all score reads of a cell in flight together.
-// survivors a cell can hold: strict 3x3 NMS keeps at most one pixel per 2x2 block of the <= 66 x 96 interior
-constexpr int FC_LIST = 33 * 48;
+// survivors a cell can hold: strict 3x3 NMS keeps at most one pixel per 2x2 block of the interior
 constexpr int FC_GROUPS = 3;  // row groups of 32: cells are at most 66 rows tall
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ smap,
-                                                    const uint8_t *__restrict__ bits, size_t frame_pyr,
-                                                    const CellDesc *__restrict__ cells, int ncells_total,
-                                                    uint32_t *__restrict__ slots, size_t frame_slots,
-                                                    int *__restrict__ cell_cnt)
+// k_fast_cells: strict 3x3 non-maximum suppression, threshold choice and ordered emission of a cell's corners in one
+// pass over the score map.  cv::FAST runs on a cell's sub-image, so the suppression never looks outside the cell
+// interior (outside neighbours count as 0): a cell is self-contained.  Because a survivor at the lower threshold
+// with s > t_hi is also a survivor at t_hi (a neighbour with s_n <= t_hi cannot beat it), one NMS serves both
+// thresholds:  survivor(t)  <=>  s > max(t, 1)  and  s > every in-cell neighbour.
+// One half wave per (cell, frame), one lane per interior row (the usual 30-row cell fills 30 of the 32 lanes; taller
+// border cells take up to three row groups):
+//   phase 1  the lane loads its row of scores (aligned dwords, bytes outside the interior cleared), keeps it in LDS
+//            (the emission reads responses from there) and stores T[x] = max(s[x-1], s[x], s[x+1]) of the row, one
+//            byte per pixel, between a zero row above and below the cell;
+//   phase 2  with H[x] = max(s[x-1], s[x+1]) of its own row and T of the rows above / below from LDS, a pixel
+//            survives threshold t  <=>  s > max(t, 1)  and  s > max(H, T_up, T_down), which yields the row's survivor
+//            mask: for iniThFAST first, for minThFAST only if that leaves the whole cell empty (ORBextractor.cc:809-816);
+// then a prefix sum of the per-row counts gives every row its output offset, every row lane drops (iy, ix) of its
+// survivors into the half wave's LDS list, and the list is emitted with one survivor per lane -- row-major order,
+// cv::FAST's output order (which the quadtree's "first maximum" rule depends on).  All extrema are three-input packed f16 ops on integer bit
+// patterns (see fast_score_pk).
+constexpr int FCN_ND = (3 + MAX_CELL + 3) / 4;  // aligned dwords a row of the widest cell can touch (18)
+
+struct FcnGeom {
+    int rawp;       // dwords per staged row: nd_max + 2 (a zero dword on each side)
+    int max_rows;   // tallest cell interior
+    int list_cap;   // survivors the largest cell can hold
+    int hw_bytes;   // LDS bytes per half wave
+};
+
+template <int ND>  // unroll bound of the per-dword loops: smallest of 10 / 14 / 18 that covers the widest cell
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ smap, size_t frame_pyr,
+                                                        const CellDesc *__restrict__ cells, int ncells_total,
+                                                        uint32_t *__restrict__ slots, size_t frame_slots,
+                                                        int *__restrict__ cell_cnt, int ini_th, int min_th, FcnGeom fg)
 {
-    __shared__ uint16_t s_list[8][FC_LIST];
+    extern __shared__ __align__(16) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hl = lane & 31, half = lane >> 5;
     int bx, f;
     xcd_frame_block(bx, f);
-    const int ci = (bx * 4 + wave) * 2 + half;
+    const int ci0 = (bx * 4 + wave) * 2, ci = ci0 + half;
     const bool have = ci < ncells_total;
-    const CellDesc cd = cells[have ? ci : 0];
-    const int iw = cd.x1 - cd.x0 - 6;
+    // the wave's two descriptors sit next to each other: fetched through the scalar cache (wave-uniform addresses),
+    // each half then picks its own -- the score loads below depend on them
+    const CellDesc cdA = cells[min(ci0, ncells_total - 1)], cdB = cells[min(ci0 + 1, ncells_total - 1)];
+    const CellDesc cd = half ? cdB : cdA;
+    const int iw = (have ? cd.x1 - cd.x0 - 6 : 0);
     const int ih = (have && iw > 0) ? max(cd.y1 - cd.y0 - 6, 0) : 0;  // 0: nothing to do for this half
     const int xs = cd.x0 + 3 + EDGE, ys = cd.y0 + 3 + EDGE;  // padded coordinates of the interior origin
-    const int s0 = xs >> 2, o0 = xs & 3;                     // first strip, pixel offset inside it
+    const int o0 = xs & 3, sa = xs - o0;                     // first aligned byte column, offset of the interior in it
+    const int nd = ih > 0 ? (o0 + iw + 3) >> 2 : 0;          // aligned dwords per row
     const size_t plane = (size_t)f * frame_pyr + (size_t)cd.plane_off;
-    const uint8_t *bplane = bits + (plane >> 2);
-    const int bpitch = cd.pitch >> 2;
+    const int rawp = fg.rawp;
+    uint32_t *rawL = reinterpret_cast<uint32_t *>(smem + (size_t)(wave * 2 + half) * fg.hw_bytes);  // [max_rows][rawp]
+    uint32_t *TL = rawL + (size_t)rawp * fg.max_rows;                                              // [max_rows+2][rawp]
+    uint16_t *list = reinterpret_cast<uint16_t *>(TL);  // reuses the T block once the masks are known
     uint32_t *out = slots + (size_t)f * frame_slots + cd.slot_off;
-    uint16_t *list = s_list[wave * 2 + half];
-    // both halves run the same number of row groups (the shuffles below are per 32-lane segment)
     const int my_groups = (ih + 31) >> 5;
     const int ngroups = max(my_groups, __shfl_xor(my_groups, 32, 64));
 
-    // A row's <= 18 strip bytes are fetched as 6 aligned dwords (24 strips from strip sa = s0 & ~3),
-    // each dword's nibbles are compressed to 16 pixel bits, and the 96-bit strings are shifted so that
-    // bit 0 = the row's first interior pixel.
-    unsigned long long mmin[FC_GROUPS][2], mini[FC_GROUPS][2];
-    const unsigned long long keep0 = iw >= 64 ? ~0ull : (1ull << max(iw, 0)) - 1ull;
-    const unsigned long long keep1 = iw <= 64 ? 0ull : (1ull << (iw - 64)) - 1ull;
-    const int sa = s0 & ~3;
-    const int shift = 4 * (s0 - sa) + o0;  // 0..15 pixel bits to drop at the front
-    const int ndw = min(6, (bpitch - sa) >> 2);  // dwords available in the row from sa on
-    int n_ini = 0;
-#pragma unroll
-    for (int grp = 0; grp < FC_GROUPS; grp++) {
-        mmin[grp][0] = mmin[grp][1] = mini[grp][0] = mini[grp][1] = 0ull;
+    // zero rows above / below the cell and the halo dwords (the whole T block: (ih + 2) * rawp dwords)
+    for (int x = hl; x < (ih + 2) * rawp; x += 32)
+        TL[x] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // bytes of the first / last dword that lie outside the interior
+    const uint32_t first_keep = 0xFFFFFFFFu << (8 * o0);
+    const int tail = o0 + iw - 4 * (nd - 1);  // bytes of the last dword inside the interior: 1..4
+    const uint32_t last_keep = tail >= 4 ? 0xFFFFFFFFu : ((1u << (8 * max(tail, 0))) - 1u);
+    const uint32_t LO = 0x00FF00FFu;
+
+    // ---- phase 1: stage the rows and their horizontal 3-maxima
+#pragma unroll 1
+    for (int grp = 0; grp < ngroups; grp++) {
         const int iy = grp * 32 + hl;
-        if (grp < ngroups && iy < ih) {
-            const uint32_t *bp = reinterpret_cast<const uint32_t *>(bplane + (size_t)(ys + iy) * bpitch + sa);
-            uint32_t lo16[6], hi16[6];
+        if (iy < ih) {
+            const uint32_t *gp = reinterpret_cast<const uint32_t *>(smap + plane + (size_t)(ys + iy) * cd.pitch + sa);
+            uint32_t d[ND];
 #pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const uint32_t d = k < ndw ? bp[k] : 0u;
-                uint32_t x = d & 0x0F0F0F0Fu, y = (d >> 4) & 0x0F0F0F0Fu;
-                x = (x | (x >> 4)) & 0x00FF00FFu;
-                y = (y | (y >> 4)) & 0x00FF00FFu;
-                lo16[k] = (x | (x >> 8)) & 0xFFFFu;
-                hi16[k] = (y | (y >> 8)) & 0xFFFFu;
+            for (int j = 0; j < ND; j++)
+                d[j] = j < nd ? gp[j] : 0u;
+            d[0] &= first_keep;
+#pragma unroll
+            for (int j = 0; j < ND; j++)
+                if (j == nd - 1)
+                    d[j] &= last_keep;
+            uint32_t *rr = rawL + (size_t)iy * rawp, *tr = TL + (size_t)(iy + 1) * rawp;
+            rr[0] = 0u;
+            uint32_t prevO = 0u;
+#pragma unroll
+            for (int j = 0; j < ND; j++) {
+                if (j < nd) {
+                    const uint32_t dj = d[j];
+                    const uint32_t E = dj & LO, O = (dj >> 8) & LO;                       // (b0,b2), (b1,b3)
+                    const uint32_t En = (j + 1 < ND ? d[j + 1] : 0u) & LO;            // next dword's (b0,b2)
+                    const uint32_t leftE = __builtin_amdgcn_alignbit(O, prevO, 16);       // (b-1, b1)
+                    const uint32_t rightO = __builtin_amdgcn_alignbit(En, E, 16);         // (b2, b4)
+                    const uint32_t TE = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(pkh, leftE), __builtin_bit_cast(pkh, E), __builtin_bit_cast(pkh, O)));
+                    const uint32_t TO = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(pkh, E), __builtin_bit_cast(pkh, O), __builtin_bit_cast(pkh, rightO)));
+                    rr[1 + j] = dj;
+                    tr[1 + j] = TE | (TO << 8);
+                    prevO = O;
+                }
             }
-            // 96 pixel bits -> (w0: bits 0..63, w1: bits 64..95), then drop `shift` leading bits
-            unsigned long long a0 = (unsigned long long)lo16[0] | ((unsigned long long)lo16[1] << 16) |
-                                    ((unsigned long long)lo16[2] << 32) | ((unsigned long long)lo16[3] << 48);
-            unsigned long long a1 = (unsigned long long)lo16[4] | ((unsigned long long)lo16[5] << 16);
-            unsigned long long b0 = (unsigned long long)hi16[0] | ((unsigned long long)hi16[1] << 16) |
-                                    ((unsigned long long)hi16[2] << 32) | ((unsigned long long)hi16[3] << 48);
-            unsigned long long b1 = (unsigned long long)hi16[4] | ((unsigned long long)hi16[5] << 16);
-            if (shift) {
-                a0 = (a0 >> shift) | (a1 << (64 - shift));
-                a1 >>= shift;
-                b0 = (b0 >> shift) | (b1 << (64 - shift));
-                b1 >>= shift;
-            }
-            mmin[grp][0] = a0 & keep0;
-            mmin[grp][1] = a1 & keep1;
-            mini[grp][0] = b0 & keep0;
-            mini[grp][1] = b1 & keep1;
-            n_ini += __popcll(mini[grp][0]) + __popcll(mini[grp][1]);
+            rr[1 + nd] = 0u;  // right halo
         }
     }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1)
-        n_ini += __shfl_xor(n_ini, off, 64);  // stays inside the 32-lane half
-    const bool use_ini = n_ini > 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+    // ---- phase 2: survivor masks of every row for one threshold, relative to the aligned column sa (bit 4 j + p =
+    //      byte p of dword j), then shifted so that bit 0 = the row's first interior pixel.  iniThFAST first; the
+    //      minThFAST masks are only computed when that leaves the whole cell empty (ORBextractor.cc:809-816).
+    const unsigned long long keep0 = iw >= 64 ? ~0ull : (1ull << max(iw, 0)) - 1ull;
+    const unsigned long long keep1 = iw <= 64 ? 0ull : (1ull << (iw - 64)) - 1ull;
+    unsigned long long msk[FC_GROUPS][2];
+    auto row_masks = [&](int thr) {
+        const short th = (short)max(thr, 1);
+        const pk16 tpk = {th, th};
+        int count = 0;
+#pragma unroll
+        for (int grp = 0; grp < FC_GROUPS; grp++) {
+            msk[grp][0] = msk[grp][1] = 0ull;
+            const int iy = grp * 32 + hl;
+            if (grp < ngroups && iy < ih) {
+                const uint32_t *rr = rawL + (size_t)iy * rawp, *tu = TL + (size_t)iy * rawp, *td = TL + (size_t)(iy + 2) * rawp;
+                uint32_t w[3] = {0u, 0u, 0u};  // 96 pixel bits
+                uint32_t prevO = 0u;
+                uint32_t dj = rr[1];
+#pragma unroll
+                for (int j = 0; j < ND; j++) {
+                    if (j < nd) {
+                        const uint32_t dn = rr[2 + j];
+                        const uint32_t E = dj & LO, O = (dj >> 8) & LO, En = dn & LO;
+                        const uint32_t leftE = __builtin_amdgcn_alignbit(O, prevO, 16);
+                        const uint32_t rightO = __builtin_amdgcn_alignbit(En, E, 16);
+                        const uint32_t u = tu[1 + j], dd = td[1 + j];
+                        const pkh nbE = hmax3(__builtin_elementwise_maximum(__builtin_bit_cast(pkh, leftE), __builtin_bit_cast(pkh, O)),
+                                              __builtin_bit_cast(pkh, u & LO), __builtin_bit_cast(pkh, dd & LO));
+                        const pkh nbO = hmax3(__builtin_elementwise_maximum(__builtin_bit_cast(pkh, E), __builtin_bit_cast(pkh, rightO)),
+                                              __builtin_bit_cast(pkh, (u >> 8) & LO), __builtin_bit_cast(pkh, (dd >> 8) & LO));
+                        const pk16 e16 = as_pk(E), o16 = as_pk(O);
+                        // x > y  <=>  sign(y - x) (all values are in [0,255]): survivor <=> s > every neighbour and s > t
+                        const uint32_t sE = as_u32(h_as_pk(nbE) - e16) & as_u32(tpk - e16);
+                        const uint32_t sO = as_u32(h_as_pk(nbO) - o16) & as_u32(tpk - o16);
+                        // the four sign bits (E: px0, px2; O: px1, px3) -> one nibble: gather the sign bytes in pixel
+                        // order, reduce them to 0 / 1 and weight them 1, 2, 4, 8 with one v_dot4
+                        const uint32_t sg = (__builtin_amdgcn_perm(sO, sE, 0x07030501u) >> 7) & 0x01010101u;
+                        const uint32_t nib = __builtin_amdgcn_udot4(sg, 0x08040201u, 0u, false);
+                        w[j >> 3] |= nib << (4 * (j & 7));
+                        prevO = O;
+                        dj = dn;
+                    }
+                }
+                unsigned long long a0 = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32), a1 = w[2];
+                if (o0) {  // drop the o0 leading bits
+                    a0 = (a0 >> o0) | (a1 << (64 - o0));
+                    a1 >>= o0;
+                }
+                msk[grp][0] = a0 & keep0;
+                msk[grp][1] = a1 & keep1;
+                count += __popcll(msk[grp][0]) + __popcll(msk[grp][1]);
+            }
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1)
+            count += __shfl_xor(count, off, 64);  // stays inside the 32-lane half
+        return count;
+    };
+    if (row_masks(ini_th) == 0)
+        (void)row_masks(min_th);
+
+    // every lane has read its neighbours' T rows: the block becomes the survivor list
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int base = 0;
 #pragma unroll
     for (int grp = 0; grp < FC_GROUPS; grp++) {
         if (grp >= ngroups)
             break;
         const int iy = grp * 32 + hl;
-        const unsigned long long m0 = use_ini ? mini[grp][0] : mmin[grp][0];
-        const unsigned long long m1 = use_ini ? mini[grp][1] : mmin[grp][1];
+        const unsigned long long m0 = msk[grp][0], m1 = msk[grp][1];
         const int c = __popcll(m0) + __popcll(m1);
         int inc = c;
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
-            const int t = __shfl_up(inc, off, 32);
+            const int tt = __shfl_up(inc, off, 32);
             if (hl >= off)
-                inc += t;
+                inc += tt;
         }
         int pos = base + inc - c;
         base += __shfl(inc, 31, 32);
@@ -646,7 +635,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             while (m) {
                 const int ix = xb + __ffsll((long long)m) - 1;
                 m &= m - 1ull;
-                if (pos < FC_LIST)
+                if (pos < fg.list_cap)
                     list[pos] = (uint16_t)((iy << 8) | ix);  // iy < 128, ix < 96
                 pos++;
             }
@@ -657,12 +646,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nemit = min(base, min((int)cd.cap, FC_LIST));
-    const uint8_t *sorg = smap + plane + (size_t)ys * cd.pitch + xs;
+    const int nemit = min(base, min((int)cd.cap, fg.list_cap));
+    const uint8_t *rawB = reinterpret_cast<const uint8_t *>(rawL);
     for (int k = hl; k < nemit; k += 32) {
         const int e = list[k];
         const int iy = e >> 8, ix = e & 255;
-        const int sc = sorg[(size_t)iy * cd.pitch + ix];
+        const int sc = rawB[(size_t)iy * rawp * 4 + 4 + o0 + ix];  // the staged row starts one dword in, at column sa
         out[k] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, sc - 1);
     }
     if (have && hl == 0)
@@ -1425,12 +1414,13 @@ struct orbgpu_extractor {
     int cfg_w = 0, cfg_h = 0, cfg_batch = 0;
     std::vector<LevelGeom> geom;
     std::vector<CellDesc> cells;
-    StripGeom blur_geom, fast_geom, nms_geom;
+    StripGeom blur_geom, fast_geom;
     size_t frame_pyr = 0, frame_slots = 0;
     int sel_cap_total = 0, ncap = 0, max_kp = 0;
     size_t qt_lds = 0;
+    FcnGeom fcn{};
     // device state
-    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt, d_colmask, d_rowflag, d_bits;
+    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt;
     DevBuf d_pyr, d_blur, d_smap, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
     DevBuf d_in, d_kps, d_desc, d_nout;  // staging for the host entry points
     DevBuf d_dbg;
@@ -1498,8 +1488,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     std::vector<XTab> xtab;
     std::vector<YTab> ytab;
     std::vector<ResizeStrip> rstrip;
-    std::vector<uint4> rsel, rwt, colmask;
-    std::vector<uint8_t> rowflag;
+    std::vector<uint4> rsel, rwt;
     size_t plane_off = 0;
     int slot_off = 0, sel_off = 0, max_cells_level = 0, ncap = 0;
     for (int l = 0; l < nl; l++) {
@@ -1573,33 +1562,6 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         g.sel_off = sel_off;
         sel_off += g.sel_cap;
         ncap = std::max(ncap, g.sel_cap);
-        // NMS tables: a neighbour counts only if it lies in the same cell interior.  Interiors tile
-        // [19, w-19) x [19, h-19) in steps of wCell x hCell (:769-808).
-        g.cm_off = (int)colmask.size();
-        g.rf_off = (int)rowflag.size();
-        {
-            auto hasL = [&](int x) { return x >= EDGE && x < g.w - EDGE && (x - EDGE) % g.wcell != 0; };
-            auto hasR = [&](int x) {
-                return x >= EDGE && x < g.w - EDGE && (x - EDGE) % g.wcell != g.wcell - 1 && x != g.w - EDGE - 1;
-            };
-            for (int dwc = 0; dwc < g.pitch / 4; dwc++) {
-                const int x0 = 4 * dwc - EDGE;  // image column of px0
-                uint4 m;
-                m.x = (hasL(x0) ? 0xFFFFu : 0u) | (hasL(x0 + 2) ? 0xFFFF0000u : 0u);
-                m.y = (hasR(x0) ? 0xFFFFu : 0u) | (hasR(x0 + 2) ? 0xFFFF0000u : 0u);
-                m.z = (hasL(x0 + 1) ? 0xFFFFu : 0u) | (hasL(x0 + 3) ? 0xFFFF0000u : 0u);
-                m.w = (hasR(x0 + 1) ? 0xFFFFu : 0u) | (hasR(x0 + 3) ? 0xFFFF0000u : 0u);
-                colmask.push_back(m);
-            }
-            for (int y = 0; y < g.h; y++) {
-                const bool in = y >= EDGE && y < g.h - EDGE;
-                const bool up = in && (y - EDGE) % g.hcell != 0;
-                const bool dn = in && (y - EDGE) % g.hcell != g.hcell - 1 && y != g.h - EDGE - 1;
-                rowflag.push_back((uint8_t)((up ? 1 : 0) | (dn ? 2 : 0)));
-            }
-            while (rowflag.size() % 4)
-                rowflag.push_back(0);
-        }
         // resize tables (cv::resize INTER_LINEAR 8U, A2)
         g.xtab_off = (int)xtab.size();
         g.ytab_off = (int)ytab.size();
@@ -1708,23 +1670,29 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         }
         for (int l = nl; l <= ORBGPU_MAX_LEVELS; l++)
             fg.first[l] = acc;
-        StripGeom &ng = e->nms_geom;
-        memset(&ng, 0, sizeof(ng));
-        ng.nlevels = nl;
-        acc = 0;
-        for (int l = 0; l < nl; l++) {
-            ng.first[l] = acc;
-            ng.nsx[l] = fg.nsx[l];
-            acc += fg.nsx[l] * ((geom[l].h - 2 * EDGE + NB_ROWS - 1) / NB_ROWS);
-        }
-        for (int l = nl; l <= ORBGPU_MAX_LEVELS; l++)
-            ng.first[l] = acc;
     }
     e->frame_pyr = plane_off;
     e->frame_slots = (size_t)slot_off;
     e->sel_cap_total = sel_off;
     e->ncap = ncap;
     e->qt_lds = qt_lds;
+    {
+        int max_iw = 1, max_ih = 1, max_cap = 1;
+        for (const CellDesc &c : cells) {
+            max_iw = std::max(max_iw, c.x1 - c.x0 - 6);
+            max_ih = std::max(max_ih, c.y1 - c.y0 - 6);
+            max_cap = std::max(max_cap, (int)c.cap);
+        }
+        FcnGeom fg;
+        fg.rawp = (3 + max_iw + 3) / 4 + 2;
+        fg.max_rows = max_ih;
+        fg.list_cap = max_cap;
+        // raw rows + max(T rows incl. the zero rows above / below, survivor list overlaid on them)
+        fg.hw_bytes = (int)(((size_t)fg.rawp * 4 * fg.max_rows +
+                             std::max((size_t)fg.rawp * 4 * (fg.max_rows + 2), (size_t)fg.list_cap * 2) + 15) / 16 * 16);
+        ORBGPU_REQUIRE((size_t)fg.hw_bytes * 8 <= 150 * 1024, "FAST cells too large for the LDS staging (%d B per cell)", fg.hw_bytes);
+        e->fcn = fg;
+    }
     int max_kp = 0;
     for (int l = 0; l < nl; l++)
         max_kp += geom[l].sel_cap - 1;
@@ -1744,9 +1712,6 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_pyr, e->frame_pyr * B);
     RSV(e->d_blur, e->frame_pyr * B);
     RSV(e->d_smap, e->frame_pyr * B);
-    RSV(e->d_bits, e->frame_pyr / 4 * B);
-    RSV(e->d_colmask, sizeof(uint4) * colmask.size());
-    RSV(e->d_rowflag, rowflag.size());
     RSV(e->d_slots, sizeof(uint32_t) * e->frame_slots * B);
     RSV(e->d_cellcnt, sizeof(int) * cells.size() * B);
     RSV(e->d_dkey, sizeof(uint32_t) * e->frame_slots * B);
@@ -1765,12 +1730,16 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         ORBGPU_HIP_TRY(hipMemcpy(e->d_rwt.p, rwt.data(), sizeof(uint4) * rwt.size(), hipMemcpyHostToDevice));
     }
     ORBGPU_HIP_TRY(hipMemcpy(e->d_pattern.p, k_pattern_host, 1024, hipMemcpyHostToDevice));
-    ORBGPU_HIP_TRY(hipMemcpy(e->d_colmask.p, colmask.data(), sizeof(uint4) * colmask.size(), hipMemcpyHostToDevice));
-    ORBGPU_HIP_TRY(hipMemcpy(e->d_rowflag.p, rowflag.data(), rowflag.size(), hipMemcpyHostToDevice));
     // the blurred planes are only written inside the image; define the rest once
     ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
     ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)qt_lds));
+    ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fast_cells<10>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, e->fcn.hw_bytes * 8));
+    ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fast_cells<14>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, e->fcn.hw_bytes * 8));
+    ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fast_cells<FCN_ND>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, e->fcn.hw_bytes * 8));
     e->cfg_w = w;
     e->cfg_h = h;
     e->cfg_batch = batch;
@@ -1826,12 +1795,14 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->d_smap.as<uint8_t>(), e->frame_pyr, dg, e->fast_geom);
     END(ST_FAST_SCORE, st);
     BEGIN(ST_FAST_NMS, st);
-    hipLaunchKernelGGL(k_fast_nmsbits, dim3((e->nms_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st,
-                       e->d_smap.as<uint8_t>(), e->d_bits.as<uint8_t>(), e->frame_pyr, dg, e->nms_geom,
-                       e->d_colmask.as<uint4>(), e->d_rowflag.as<uint8_t>(), e->prm.ini_th_fast, e->prm.min_th_fast);
-    hipLaunchKernelGGL(k_fast_cells, dim3(((unsigned)e->cells.size() + 7) / 8, batch), dim3(256), 0, st,
-                       e->d_smap.as<uint8_t>(), e->d_bits.as<uint8_t>(), e->frame_pyr, e->d_cells.as<CellDesc>(),
-                       (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>());
+    {
+        const int ndm = e->fcn.rawp - 2;
+        auto kfn = ndm <= 10 ? k_fast_cells<10> : ndm <= 14 ? k_fast_cells<14> : k_fast_cells<FCN_ND>;
+        hipLaunchKernelGGL(kfn, dim3(((unsigned)e->cells.size() + 7) / 8, batch), dim3(256),
+                           (size_t)e->fcn.hw_bytes * 8, st, e->d_smap.as<uint8_t>(), e->frame_pyr, e->d_cells.as<CellDesc>(),
+                           (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
+                           e->prm.ini_th_fast, e->prm.min_th_fast, e->fcn);
+    }
     END(ST_FAST_NMS, st);
     BEGIN(ST_QUADTREE, st);
     hipLaunchKernelGGL(k_quadtree, dim3(batch, nl), dim3(batch >= QT_BATCH_MIN ? QT_THREADS_BATCH : QT_THREADS), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
@@ -1914,7 +1885,7 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
     (void)hipSetDevice(e->prm.device_id);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_rstrip, &e->d_rsel,
-                      &e->d_rwt, &e->d_colmask, &e->d_rowflag, &e->d_bits, &e->d_pyr,
+                      &e->d_rwt, &e->d_pyr,
                       &e->d_blur, &e->d_smap, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
                       &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
     for (DevBuf *b : bufs)
