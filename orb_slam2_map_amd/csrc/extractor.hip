@@ -492,9 +492,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int my_groups = (ih + 31) >> 5;
     const int ngroups = max(my_groups, __shfl_xor(my_groups, 32, 64));
 
-    // zero rows above / below the cell and the halo dwords (the whole T block: (ih + 2) * rawp dwords)
-    for (int x = hl; x < (ih + 2) * rawp; x += 32)
-        TL[x] = 0u;
+    // zero T rows above / below the cell (the rows in between are written by phase 1; rawp <= 20 dwords)
+    if (hl < rawp) {
+        TL[hl] = 0u;
+        TL[(size_t)(ih + 1) * rawp + hl] = 0u;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
