@@ -1242,7 +1242,9 @@ __device__ __forceinline__ uint32_t blur_vsum(const uint32_t r0[4], const uint32
     uint32_t out = 0;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-        uint32_t s = 18u * (r0[p] + r6[p]) + 34u * (r1[p] + r5[p]) + 49u * (r2[p] + r4[p]) + 55u * r3[p];
+        // row sums are <= 255 * 257 < 2^24: 24-bit multiply-adds (full rate; a 32-bit v_mul_lo_u32 is quarter rate)
+        uint32_t s = __umul24(18u, r0[p] + r6[p]) + __umul24(34u, r1[p] + r5[p]) + __umul24(49u, r2[p] + r4[p]) +
+                     __umul24(55u, r3[p]);
         s = (s + 32768u) >> 16;
         s = s > 255u ? 255u : s;
         out |= s << (8 * p);
