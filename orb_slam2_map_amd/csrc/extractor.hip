@@ -83,6 +83,10 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len)
 // ---------------------------------------------------------------------------------------------
 // K1a: level 0 = copyMakeBorder(image, REFLECT_101)           (ORBextractor.cc:1125-1129, A6)
 // ---------------------------------------------------------------------------------------------
+// byte offset of a row inside a padded plane: rows and pitches are < 2^24, so a 24-bit multiply (full rate) is exact;
+// the 64-bit (size_t) product the obvious expression asks for costs two quarter-rate multiplies per use
+__device__ __forceinline__ uint32_t rowoff(int row, int pitch) { return __umul24((unsigned)row, (unsigned)pitch); }
+
 constexpr int PYR_ROWS = 8;  // padded rows per thread in the pyramid kernels
 
 __global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src, size_t stride,
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src
                 v |= (uint32_t)s[sx] << (8 * k);
             }
         }
-        *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + x4) = v;
+        *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + rowoff(py, g.pitch) + x4) = v;
     }
 }
 
@@ -146,9 +150,9 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
         return;
     const int dy = reflect101(py - EDGE, g.h);
     const YTab yt = ytab[g.ytab_off + dy];
-    const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + (size_t)EDGE * gs.pitch + EDGE;
-    const uint8_t *S0 = base + (size_t)yt.sy0 * gs.pitch;
-    const uint8_t *S1 = base + (size_t)yt.sy1 * gs.pitch;
+    const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + rowoff(EDGE, gs.pitch) + EDGE;
+    const uint8_t *S0 = base + rowoff(yt.sy0, gs.pitch);
+    const uint8_t *S1 = base + rowoff(yt.sy1, gs.pitch);
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
         int o = ((((int)yt.b0 * (t0 >> 4)) >> 16) + (((int)yt.b1 * (t1 >> 4)) >> 16) + 2) >> 2;
         v |= (uint32_t)(o & 0xFF) << (8 * k);
     }
-    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)py * g.pitch + x4) = v;
+    *reinterpret_cast<uint32_t *>(pyr + (size_t)f * frame_pyr + g.plane_off + rowoff(py, g.pitch) + x4) = v;
 }
 
 // Fast path of K1b: one thread per aligned output dword (4 pixels) of the padded plane.  The 8 source
@@ -202,8 +206,8 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
             break;
         const int dy = reflect101(py - EDGE, g.h);
         const YTab yt = ytab[g.ytab_off + dy];
-        const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + (size_t)(yt.sy0 + EDGE) * gs.pitch);
-        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(base + (size_t)(yt.sy1 + EDGE) * gs.pitch);
+        const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy0 + EDGE, gs.pitch));
+        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy1 + EDGE, gs.pitch));
         const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
         const uint32_t c0 = S1[0], c1 = S1[1], c2 = S1[2];
         uint32_t v = 0;
@@ -215,10 +219,10 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
             const us2 w = __builtin_bit_cast(us2, wv[k]);
             const int t0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), w, 0u, false);
             const int t1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), w, 0u, false);
-            const int o = ((((int)yt.b0 * (t0 >> 4)) >> 16) + (((int)yt.b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            const int o = ((__mul24((int)yt.b0, t0 >> 4) >> 16) + (__mul24((int)yt.b1, t1 >> 4) >> 16) + 2) >> 2;  // 12 x 15 bits
             v |= (uint32_t)(o & 0xFF) << (8 * k);
         }
-        *reinterpret_cast<uint32_t *>(dst + (size_t)py * g.pitch) = v;
+        *reinterpret_cast<uint32_t *>(dst + rowoff(py, g.pitch)) = v;
     }
 }
 
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     // zero T rows above / below the cell (the rows in between are written by phase 1; rawp <= 20 dwords)
     if (hl < rawp) {
         TL[hl] = 0u;
-        TL[(size_t)(ih + 1) * rawp + hl] = 0u;
+        TL[__umul24(ih + 1, rawp) + hl] = 0u;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     for (int grp = 0; grp < ngroups; grp++) {
         const int iy = grp * 32 + hl;
         if (iy < ih) {
-            const uint32_t *gp = reinterpret_cast<const uint32_t *>(smap + plane + (size_t)(ys + iy) * cd.pitch + sa);
+            const uint32_t *gp = reinterpret_cast<const uint32_t *>(smap + plane + rowoff(ys + iy, cd.pitch) + sa);
             uint32_t d[ND];
 #pragma unroll
             for (int j = 0; j < ND; j++)
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             for (int j = 0; j < ND; j++)
                 if (j == nd - 1)
                     d[j] &= last_keep;
-            uint32_t *rr = rawL + (size_t)iy * rawp, *tr = TL + (size_t)(iy + 1) * rawp;
+            uint32_t *rr = rawL + __umul24(iy, rawp), *tr = TL + __umul24(iy + 1, rawp);
             rr[0] = 0u;
             uint32_t prevO = 0u;
 #pragma unroll
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
             msk[grp][0] = msk[grp][1] = 0ull;
             const int iy = grp * 32 + hl;
             if (grp < ngroups && iy < ih) {
-                const uint32_t *rr = rawL + (size_t)iy * rawp, *tu = TL + (size_t)iy * rawp, *td = TL + (size_t)(iy + 2) * rawp;
+                const uint32_t *rr = rawL + __umul24(iy, rawp), *tu = TL + __umul24(iy, rawp), *td = TL + __umul24(iy + 2, rawp);
                 uint32_t w[3] = {0u, 0u, 0u};  // 96 pixel bits
                 uint32_t prevO = 0u;
                 uint32_t dj = rr[1];
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     for (int k = hl; k < nemit; k += 32) {
         const int e = list[k];
         const int iy = e >> 8, ix = e & 255;
-        const int sc = rawB[(size_t)iy * rawp * 4 + 4 + o0 + ix];  // the staged row starts one dword in, at column sa
+        const int sc = rawB[__umul24(iy, rawp * 4) + 4 + o0 + ix];  // the staged row starts one dword in, at column sa
         out[k] = pack_key(ix + 3 + cd.addx, iy + 3 + cd.addy, sc - 1);
     }
     if (have && hl == 0)
@@ -1149,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     if (hl < 31) {
         const int av = v < 0 ? -v : v;
         const uint32_t *row = reinterpret_cast<const uint32_t *>(
-            pyr + (size_t)f * frame_pyr + g.plane_off + (size_t)(y + EDGE + v) * g.pitch + (xl - a));
+            pyr + (size_t)f * frame_pyr + g.plane_off + rowoff(y + EDGE + v, g.pitch) + (xl - a));
         const uint32_t *w = &W10[(a * 16 + av) * 9], *m = &M01[(a * 16 + av) * 9];
         uint32_t sw = 0, sm = 0;
 #pragma unroll
@@ -1356,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
         const int idx = byte + 32 * k;
         if (idx < DP_ROWS * DP_DW) {
             const int r = idx / DP_DW, c = idx - r * DP_DW;
-            pl[idx] = *reinterpret_cast<const uint32_t *>(src + (size_t)r * g.pitch + c * 4);
+            pl[idx] = *reinterpret_cast<const uint32_t *>(src + (size_t)(r) * g.pitch + c * 4);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1370,8 +1374,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
         const float x1 = (float)(int8_t)((pw[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pw[k] >> 24);
         const int r0 = __float2int_rn(x0 * sb + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sb);
         const int r1 = __float2int_rn(x1 * sb + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sb);
-        const int t0 = center[r0 * (DP_DW * 4) + c0];
-        const int t1 = center[r1 * (DP_DW * 4) + c1];
+        const int t0 = center[__mul24(r0, DP_DW * 4) + c0];
+        const int t1 = center[__mul24(r1, DP_DW * 4) + c1];
         val |= (t0 < t1) << k;
     }
     desc[((size_t)f * cap + kpi) * 32 + byte] = (uint8_t)val;
