@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src
         if (py >= g.h + 2 * EDGE)
             break;
         const int sy = reflect101(py - EDGE, g.h);
-        const uint8_t *s = src + (size_t)f * frame_stride + (size_t)sy * stride;
+        const uint8_t *s = src + (size_t)f * frame_stride + __umul24((unsigned)sy, (unsigned)stride);  // stride < 2^24 (host check)
         uint32_t v = 0;
         if (interior && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
             // interior: two aligned source dwords + v_alignbyte (the 19-px border shifts rows by 3 bytes)
@@ -1956,7 +1956,8 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_gray, int3
 {
     ORBGPU_REQUIRE(e && d_gray && d_kps && d_desc && d_n_out, "null argument");
     ORBGPU_REQUIRE(batch >= 1 && w > 0 && h > 0 && cap >= 1, "bad batch/size/cap");
-    ORBGPU_REQUIRE(stride >= (size_t)w && frame_stride >= stride * (size_t)(h - 1) + (size_t)w, "bad strides");
+    ORBGPU_REQUIRE(stride >= (size_t)w && stride < ((size_t)1 << 24) && frame_stride >= stride * (size_t)(h - 1) + (size_t)w,
+                   "bad strides");
     int rc = select_device(e->prm.device_id);
     if (rc != ORBGPU_OK)
         return rc;
@@ -1979,7 +1980,7 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch
         return ORBGPU_OK;
     }
     ORBGPU_REQUIRE(kps && desc && cap >= 1, "null output / bad cap");
-    ORBGPU_REQUIRE(stride >= (size_t)w, "bad stride");
+    ORBGPU_REQUIRE(stride >= (size_t)w && stride < ((size_t)1 << 24), "bad stride");
     int rc = select_device(e->prm.device_id);
     if (rc != ORBGPU_OK)
         return rc;
