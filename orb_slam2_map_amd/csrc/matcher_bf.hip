@@ -93,15 +93,17 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 // 16 descriptor bits -> 16 signed bytes (bit 1 -> +1, bit 0 -> -1); byte j <- bit j.
-// (n * 0x00204081) & 0x01010101 spreads the 4 bits of a nibble to the low bits of 4 bytes; 0xFF - 0xFE * b = +1 / -1.
+// (n * 0x00204081) & 0x01010101 spreads the 4 bits of a nibble to the low bits of 4 bytes (a 24-bit multiply: both
+// factors are small; 32-bit integer multiplies are quarter rate), and the 0 / 1 bytes are themselves the v_perm
+// selector that picks 0xFF or 0x01 out of the constant 0x000001FF.
 __device__ __forceinline__ v4i bf_expand16(uint32_t hw)
 {
     v4i r;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t n = (hw >> (4 * q)) & 0xFu;
-        const uint32_t w01 = (n * 0x00204081u) & 0x01010101u;
-        r[q] = (int)~(w01 * 0xFEu);
+        const uint32_t w01 = __umul24(n, 0x00204081u) & 0x01010101u;
+        r[q] = (int)__builtin_amdgcn_perm(0u, 0x000001FFu, w01);
     }
     return r;
 }
