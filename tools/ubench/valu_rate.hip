@@ -1,7 +1,10 @@
-// Micro-benchmark: issue rate of the VALU instructions the FAST score kernel is made of.
+// Micro-benchmark: issue rate of the VALU instructions the hot kernels are made of (each paired with one add, except the
+// dot products and the 24-bit mad, which carry their add; the 3-input maximum carries two masking ands).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef short pk16 __attribute__((ext_vector_type(2)));
+typedef _Float16 pkh __attribute__((ext_vector_type(2)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 template <int OP> __global__ void k(unsigned *out, int iters)
 {
     unsigned a[8];
@@ -18,6 +21,10 @@ template <int OP> __global__ void k(unsigned *out, int iters)
                 if (OP == 3) { pk16 v = __builtin_bit_cast(pk16, x) - __builtin_bit_cast(pk16, y); a[i] = __builtin_bit_cast(unsigned, v) + 1; }
                 if (OP == 4) a[i] = __popc(x ^ y) + 1;
                 if (OP == 5) a[i] = __builtin_amdgcn_udot4(x, y, 1u, false);
+                if (OP == 6) { pkh v = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(pkh, x & 0x00FF00FFu), __builtin_bit_cast(pkh, y & 0x00FF00FFu)), __builtin_bit_cast(pkh, a[(i + 5) & 7] & 0x00FF00FFu)); a[i] = __builtin_bit_cast(unsigned, v) + 1; }
+                if (OP == 9) a[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x), __builtin_bit_cast(us2, y), 1u, false);
+                if (OP == 10) a[i] = __builtin_amdgcn_alignbit(x, y, 16) + 1;
+                if (OP == 11) a[i] = __builtin_amdgcn_alignbyte(x, y, 3) + 1;
             }
         }
     }
@@ -40,4 +47,5 @@ template <int OP> void run(const char *name)
     printf("%-14s %.3f ms  %.2f T lane-instr/s (op + add)\n", name, ms, inst / ms / 1e9);
     hipFree(d);
 }
-int main() { run<1>("v_min_i32"); run<0>("v_pk_min_i16"); run<3>("v_pk_sub_i16"); run<2>("v_perm_b32"); run<4>("xor+bcnt"); run<5>("v_dot4_u32_u8"); return 0; }
+int main() { run<1>("v_min_i32"); run<0>("v_pk_min_i16"); run<3>("v_pk_sub_i16"); run<2>("v_perm_b32"); run<4>("xor+bcnt"); run<5>("v_dot4_u32_u8");
+    run<9>("v_dot2_u32_u16"); run<6>("v_pk_maximum3_f16(+2 and)"); run<10>("v_alignbit"); run<11>("v_alignbyte"); return 0; }
