@@ -172,3 +172,24 @@ def test_distinctive_descriptors(gpu, oracle):
     assert list(got) == want, (list(got), want)
     assert got[0] == -1 and got[1] == 0
     assert len(gpu.distinctive_descriptors([])) == 0
+
+
+def test_argument_errors_are_statuses_not_crashes(gpu):
+    """Bad arguments come back as ORBGPU_EINVAL with a message (the shim turns them into exceptions); nothing is
+    launched and nothing crashes."""
+    import ctypes as C
+    L = gpu.lib()
+    a = np.zeros((4, 32), np.uint8)
+    out = np.zeros(4, np.int32)
+    n = C.c_int32()
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert L.orbgpu_hamming256(None, p(a), 4, p(out), 0) == gpu.EINVAL
+    assert L.orbgpu_match_bf(p(a), None, None, 5000, p(a), None, 4, 50, 0.7, 0, p(out), C.byref(n), 0) == gpu.EINVAL  # na > 4096
+    assert L.orbgpu_match_bf(p(a), None, None, 4, p(a), None, 4, 50, 0.7, 1, p(out), C.byref(n), 0) == gpu.EINVAL     # angles missing
+    assert L.orbgpu_distinctive_descriptors(1, None, p(a), p(out), 0) == gpu.EINVAL
+    off = np.array([0, 3000], np.int32)  # more descriptors in a group than supported
+    assert L.orbgpu_distinctive_descriptors(1, p(off), p(a), p(out), 0) == gpu.EINVAL
+    assert b"2048" in L.orbgpu_last_error_string()
+    h = C.c_void_p()
+    assert L.orbgpu_matcher_create(0, 0, 100, C.byref(h)) == gpu.EINVAL
+    assert L.orbgpu_cloud_create(0.0, 0, C.byref(h)) == gpu.EINVAL  # resolution must be positive
