@@ -1054,7 +1054,7 @@ struct KpAux {
     int x, y, level;
     float angle;
     float ca, sb;  // (float)cos / (float)sin of the angle in radians, evaluated in double (k_trig)
-    int pad0, pad1;
+    int plane_off, pitch;  // of the key point's level: k_describe's patch loads then depend on this record only
 };
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -1189,6 +1189,8 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         ax.x = x;
         ax.y = y;
         ax.level = level;
+        ax.plane_off = g.plane_off;
+        ax.pitch = g.pitch;
         ax.angle = angle;
         aux[(size_t)f * cap + out_off + j] = ax;
     }
@@ -1345,7 +1347,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
         return;  // whole half-wave leaves together; the other half of the wave is independent
     const int byte = threadIdx.x & 31;
     const KpAux a = aux[(size_t)f * cap + kpi];
-    const LevelGeom g = geom[a.level];
     // this lane's 8 tests = 32 pattern bytes (x0,y0,x1,y1 per test), L1-resident table
     const uint4 pq0 = reinterpret_cast<const uint4 *>(pattern)[byte * 2];
     const uint4 pq1 = reinterpret_cast<const uint4 *>(pattern)[byte * 2 + 1];
@@ -1353,14 +1354,14 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     const float ca = a.ca, sb = a.sb;
     const int xl = a.x + EDGE - DP_R;  // leftmost padded column of the patch
     const int al = xl & 3;
-    const uint8_t *src = blur + (size_t)f * frame_pyr + g.plane_off + (size_t)(a.y + EDGE - DP_R) * g.pitch + (xl - al);
+    const uint8_t *src = blur + (size_t)f * frame_pyr + a.plane_off + (size_t)(a.y + EDGE - DP_R) * a.pitch + (xl - al);
     uint32_t *pl = reinterpret_cast<uint32_t *>(patch[slot]);
 #pragma unroll
     for (int k = 0; k < (DP_ROWS * DP_DW + 31) / 32; k++) {
         const int idx = byte + 32 * k;
         if (idx < DP_ROWS * DP_DW) {
             const int r = idx / DP_DW, c = idx - r * DP_DW;
-            pl[idx] = *reinterpret_cast<const uint32_t *>(src + (size_t)(r) * g.pitch + c * 4);
+            pl[idx] = *reinterpret_cast<const uint32_t *>(src + (size_t)(r) * a.pitch + c * 4);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
