@@ -1125,8 +1125,14 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     for (int it = 0; it < iters; it++) {
     const int slot = (bx * iters + it) * 8 + (threadIdx.x >> 5);
     // locate (level, j) of this slot and the output offset
-    int level = -1, j = 0, out_off = 0, total = 0;
+    int level = -1, j = 0, out_off = 0, total = 0, cnt_l = 0;
     bool bad = false;
+    // the level's geometry is picked up while the (wave-uniform, scalar) level records are walked anyway, so the
+    // key load below does not wait for a per-lane LevelGeom fetch
+    struct {
+        int plane_off, pitch, sel_off, patch;
+        float scale;
+    } g = {0, 0, 0, 0, 1.f};
     for (int l = 0; l < nlevels; l++) {
         const int c = ns[l];
         if (c < 0)
@@ -1136,14 +1142,19 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
             level = l;
             j = slot - so;
             out_off = total;
+            cnt_l = c;
+            g.plane_off = geom[l].plane_off;
+            g.pitch = geom[l].pitch;
+            g.sel_off = so;
+            g.patch = geom[l].patch;
+            g.scale = geom[l].scale;
         }
         total += max(c, 0);
     }
     if (slot == 0 && hl == 0)
         n_out[f] = bad ? -1 - total : (total > cap ? -1 - total : total);
-    if (level < 0 || bad || total > cap || j >= ns[level])
+    if (level < 0 || bad || total > cap || j >= cnt_l)
         continue;
-    const LevelGeom g = geom[level];
     const uint32_t key = sel[(size_t)f * sel_cap_total + g.sel_off + j];
     const int x = key_x(key) + BORDER0, y = key_y(key) + BORDER0;
     const int xl = x + EDGE - HALF_PATCH;  // leftmost padded column of the disc
