@@ -199,13 +199,20 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     const uint32_t selv[4] = {sel.x, sel.y, sel.z, sel.w}, wv[4] = {wt.x, wt.y, wt.z, wt.w};
     const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + (bq & 0xFFFFu);
     uint8_t *dst = pyr + (size_t)f * frame_pyr + g.plane_off + sdw * 4;
-#pragma unroll 2
-    for (int rr = 0; rr < rows; rr++) {
+    // the row table entries of all rows of the item first (one round trip), so that the source loads of a row do
+    // not wait for a table load of their own
+    YTab yts[PYR_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < PYR_ROWS; rr++) {
+        const int py = min(rg * rows + rr, g.h + 2 * EDGE - 1);
+        yts[rr] = ytab[g.ytab_off + reflect101(py - EDGE, g.h)];
+    }
+#pragma unroll
+    for (int rr = 0; rr < PYR_ROWS; rr++) {
         const int py = rg * rows + rr;
-        if (py >= g.h + 2 * EDGE)
+        if (rr >= rows || py >= g.h + 2 * EDGE)
             break;
-        const int dy = reflect101(py - EDGE, g.h);
-        const YTab yt = ytab[g.ytab_off + dy];
+        const YTab yt = yts[rr];
         const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy0 + EDGE, gs.pitch));
         const uint32_t *S1 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy1 + EDGE, gs.pitch));
         const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
