@@ -125,6 +125,18 @@ def main():
                          "second stream next to the extraction of step i+1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start one rank per GPU as a CHILD process group before this process
+        # imports torch / loads liborbgpu.so / touches HIP (never exec from a process that saw the GPU).
+        # Rank 0 of the child prints the JSON line on the inherited stdout; the child's exit code is ours.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     import torch
     import torch.distributed as dist
     from orb_slam2_map_amd import dist as D
@@ -167,23 +179,29 @@ def main():
     s_match = torch.cuda.Stream() if args.overlap_match else s_ext
     ev_ext = [torch.cuda.Event() for _ in range(nsets)]
     ev_match = [torch.cuda.Event() for _ in range(nsets)]
+    ev_copy = [torch.cuda.Event() for _ in range(nsets)]  # slot B of set k has been carried over to the other set
 
     def step(i):
         k = i % nsets
+        p = (i - 1) % nsets  # set holding the previous step's last frame (its own slot B when nsets == 1)
         src = frames[(i * B) % POOL:(i * B) % POOL + B]
         if args.overlap_match:
+            # carry-over first: set p's slot B (extraction i-1, already ordered before on s_match) -> set k's slot 0,
+            # which extraction i never writes.  Extraction i+1 overwrites set p and waits for ev_copy[p].
+            if i > 0:
+                with torch.cuda.stream(s_match):
+                    kps[k][0].copy_(kps[p][B], non_blocking=True)
+                    desc[k][0].copy_(desc[p][B], non_blocking=True)
+                    nout[k][0:1].copy_(nout[p][B:B + 1], non_blocking=True)
+                    ev_copy[p].record(s_match)
             s_ext.wait_event(ev_match[k])  # the matcher that last read this set has finished
+            s_ext.wait_event(ev_copy[k])   # ... and its last frame has been copied out
         ext.extract_batch_device(src.data_ptr(), B, W, H, W, W * H, kps[k].data_ptr() + KP, desc[k].data_ptr() + DS,
                                  cap, nout[k].data_ptr() + 4, s_ext.cuda_stream)
         if args.overlap_match:
             ev_ext[k].record(s_ext)
             s_match.wait_event(ev_ext[k])
         with torch.cuda.stream(s_match):
-            p = (i - 1) % nsets  # set holding the previous step's last frame (its own slot B when nsets == 1)
-            if i > 0 and nsets == 2:
-                kps[k][0].copy_(kps[p][B], non_blocking=True)
-                desc[k][0].copy_(desc[p][B], non_blocking=True)
-                nout[k][0:1].copy_(nout[p][B:B + 1], non_blocking=True)
             matcher.match(B, cap, desc[k].data_ptr(), kps[k].data_ptr() + 12, None, nout[k].data_ptr(),
                           desc[k].data_ptr() + DS, kps[k].data_ptr() + KP + 12, nout[k].data_ptr() + 4, 28, 50, 0.7,
                           True, match_b.data_ptr(), nmatch.data_ptr(), s_match.cuda_stream)
@@ -232,17 +250,24 @@ def main():
     nm_host = nmatch.cpu().numpy()
     sweeps = matcher.last_sweeps(B)
     assert n_host[1:].min() > 0 and nm_host.min() >= 0, "benchmark produced empty frames"
-    if args.overlap_match:
-        # the pipelined schedule must give what the serial schedule gives: redo the last step's matching
-        # alone and compare
-        last = (args.warmup + args.steps - 1) % nsets
-        chk_b = torch.zeros_like(match_b)
-        chk_n = torch.zeros_like(nmatch)
-        matcher.match(B, cap, desc[last].data_ptr(), kps[last].data_ptr() + 12, None, nout[last].data_ptr(),
-                      desc[last].data_ptr() + DS, kps[last].data_ptr() + KP + 12, nout[last].data_ptr() + 4, 28, 50,
-                      0.7, True, chk_b.data_ptr(), chk_n.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if args.steps > 0 and args.warmup + args.steps > 1:
+        # the pipelined schedule must give what a serial schedule gives: redo the last step from the frames, one
+        # stream, fresh buffers (previous step's last frame -> slot 0, this step's frames -> slots 1..B), and compare
+        last_i = args.warmup + args.steps - 1
+        c_kps, c_desc, c_n = torch.zeros_like(kps[0]), torch.zeros_like(desc[0]), torch.zeros_like(nout[0])
+        chk_b, chk_n = torch.zeros_like(match_b), torch.zeros_like(nmatch)
+        s0 = torch.cuda.current_stream().cuda_stream
+        prev_last = ((last_i - 1) * B) % POOL + B - 1
+        ext.extract_batch_device(frames[prev_last:prev_last + 1].data_ptr(), 1, W, H, W, W * H, c_kps.data_ptr(),
+                                 c_desc.data_ptr(), cap, c_n.data_ptr(), s0)
+        cur = (last_i * B) % POOL
+        ext.extract_batch_device(frames[cur:cur + B].data_ptr(), B, W, H, W, W * H, c_kps.data_ptr() + KP,
+                                 c_desc.data_ptr() + DS, cap, c_n.data_ptr() + 4, s0)
+        matcher.match(B, cap, c_desc.data_ptr(), c_kps.data_ptr() + 12, None, c_n.data_ptr(), c_desc.data_ptr() + DS,
+                      c_kps.data_ptr() + KP + 12, c_n.data_ptr() + 4, 28, 50, 0.7, True, chk_b.data_ptr(),
+                      chk_n.data_ptr(), s0)
         torch.cuda.synchronize()
-        assert torch.equal(chk_n, nmatch) and torch.equal(chk_b, match_b), "overlapped schedule changed the matches"
+        assert torch.equal(chk_n, nmatch) and torch.equal(chk_b, match_b), "the timed schedule changed the matches"
 
     n_kp = float(n_host[1:].mean())
 

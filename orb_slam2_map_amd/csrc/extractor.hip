@@ -1509,6 +1509,9 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
 {
     if (e->cfg_w == w && e->cfg_h == h && batch <= e->cfg_batch)
         return ORBGPU_OK;
+    // a real reconfigure rewrites tables that kernels of an earlier call (on the caller's stream) may still read
+    if (e->cfg_w != 0)
+        ORBGPU_HIP_TRY(hipDeviceSynchronize());
     const int nl = e->nlevels;
     std::vector<LevelGeom> geom(nl);
     std::vector<CellDesc> cells;
@@ -2131,9 +2134,9 @@ int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms)
         ms[i] = 0.f;
     for (int c = 0; c < e->prof_calls; c++) {
         hipEvent_t *evs = &e->ev[(size_t)c * 2 * ST_COUNT];
+        ORBGPU_HIP_TRY(hipEventSynchronize(evs[ST_COUNT]));  // the last boundary event of the profiled call
         for (int i = 0; i < ST_COUNT; i++) {
             float t = 0.f;
-            ORBGPU_HIP_TRY(hipEventSynchronize(evs[2 * i + 1]));
             ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
             ms[i] += t;
         }

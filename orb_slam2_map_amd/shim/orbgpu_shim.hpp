@@ -420,11 +420,18 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
     void shutdown()  // PointCloudMap.cc:59-67
     {
         {
-            std::unique_lock<std::mutex> lck(shutDownMutex);
-            shutDownFlag = true;
+            // The flag is published under keyframeMutex, the mutex the condition variable waits on: a notify
+            // between the viewer's predicate evaluation and its block cannot be lost (the reference sets it under
+            // shutDownMutex only and can hang in join()).
+            std::unique_lock<std::mutex> lck(keyframeMutex);
+            {
+                std::unique_lock<std::mutex> lck2(shutDownMutex);
+                shutDownFlag = true;
+            }
             keyFrameUpdated.notify_one();
         }
-        viewerThread->join();
+        if (viewerThread->joinable())
+            viewerThread->join();
     }
 
     void viewer()  // PointCloudMap.cc:182-289, no-loop branch; see rebuild() for the loop-closure branch

@@ -42,3 +42,43 @@ def test_single_rank_is_a_noop():
     from orb_slam2_map_amd import dist as D
     assert D.aggregate(2.0, 7, 1) == (2.0, 7.0)
     assert D.sequence_seed(1234, 3) == 4234
+
+
+def _run_bench(extra, timeout=900):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, cwd=root,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_self_spawns_ranks_without_a_gpu():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start 2 ranks as a child process group.
+    Without a GPU every rank refuses loudly (no CPU fallback) and the parent relays the failure."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_two_ranks_on_one_gpu")
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--rehearse-on-device0", "--steps", "1", "--warmup", "0",
+                    "--batch", "2", "--pool", "2", "--no-cpu-baseline"], timeout=300)
+    assert r.returncode != 0
+    assert "no GPU visible" in r.stderr or "no HIP device" in r.stderr, r.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """The N>1 code path of bench.py on real hardware: the driver's own command form (`bench.py --gpus 2`),
+    two ranks rehearsed on device 0 with gloo carrying the barrier / reductions."""
+    import json
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--rehearse-on-device0", "--steps", "2", "--warmup", "1",
+                    "--batch", "32", "--pool", "64", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["sequences"] == 2
+    assert out["steps"] == 2 and out["scaling"] == "weak"
+    frames = out["value"] * out["ms_per_step"] * 1e-3 * out["steps"]
+    assert abs(frames - 2 * 2 * 32) < 1e-6 * frames + 1e-3  # frames summed over both ranks
+    assert "cpu_baseline" not in out
