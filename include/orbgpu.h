@@ -398,6 +398,12 @@ int orbgpu_cloud_destroy(orbgpu_cloud *h);
 int orbgpu_cloud_insert(orbgpu_cloud *h, const float *depth, size_t depth_stride, const uint8_t *rgb,
                         size_t rgb_stride, int32_t width, int32_t height, float fx, float fy, float cx, float cy,
                         const float *Tcw);
+/* Same step with the key frame's images already resident in device memory (e.g. the frame the extractor just
+ * processed): nothing but the pose crosses PCIe.  Runs on the handle's stream and returns when the map is
+ * updated. */
+int orbgpu_cloud_insert_device(orbgpu_cloud *h, const float *d_depth, size_t depth_stride, const uint8_t *d_rgb,
+                               size_t rgb_stride, int32_t width, int32_t height, float fx, float fy, float cx,
+                               float cy, const float *Tcw);
 /* Loop-closure branch (PointCloudMap.cc:217-243): drop the map, re-generate every key-frame cloud
  * with its (new) pose, filter once. Arrays of n key-frames of one size. */
 int orbgpu_cloud_rebuild(orbgpu_cloud *h, int32_t n, const float *const *depth, size_t depth_stride,
@@ -408,6 +414,10 @@ int orbgpu_cloud_size(orbgpu_cloud *h, int64_t *n);
 int orbgpu_cloud_download(orbgpu_cloud *h, orbgpu_point_xyzrgba *out, int64_t cap, int64_t *n);
 /* 1 if the last filter hit PCL's int32 voxel-index overflow and returned its input unfiltered. */
 int orbgpu_cloud_last_overflow(orbgpu_cloud *h, int32_t *overflow);
+/* Which implementation served the last insert / rebuild: 1 = merge of the new points into the sorted resident
+ * map, 2 = general path (sort of everything), 3 = merge attempted, its precondition check failed, redone by the
+ * general path.  Results are identical; this is for tests and measurements. */
+int orbgpu_cloud_last_path(orbgpu_cloud *h, int32_t *path);
 
 /* Stateless stages (host pointers), for parity tests and other callers:
  * convertToPointCloud (PointCloudMap.cc:112-138) with optional pose transform (Tcw != NULL:

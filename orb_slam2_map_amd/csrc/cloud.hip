@@ -5,11 +5,22 @@
 //   convertToPointCloud / generatePointCloud (:78-138), pcl::transformPointCloud (:105,144,172),
 //   pcl::VoxelGrid<PointXYZRGBA>::filter (:240-243, 259-262, 277-278; PCL 1.7 semantics, A7).
 //
-// Voxel filter = (1) bounding box of the finite points, (2) per-point voxel index exactly as PCL
-// computes it, (3) a stable LSD radix sort of (index, point id) -- 8-bit digits, wave-ballot
-// ranking, so equal indices keep input order and the per-voxel float sums are reproducible --
-// (4) head flags + device-wide scan, (5) one sequential float sum per voxel, output in ascending
-// index order (PCL's output order).  HBM-bound integer/float streaming; no MFMA.
+// The reference re-filters the WHOLE accumulated map at every key frame (:259-262).  PCL's result is
+// "stable sort of (old map ++ new points) by voxel index, one float sum per run, ascending output".
+// The old map is itself such an output -- sorted, one point per voxel, and that order (z-major
+// lexicographic on the lattice coordinates) does not depend on the bounding box -- so a key frame is a MERGE:
+//   k_bp         back-project + transform + compact the <= 34 k new points (one launch, look-back offsets)
+//   k_vox_keys   PCL's set-up from (box of the map, box of the new points), voxel indices of the new points
+//   k_sort_pass  x4: stable LSD radix sort of the new points only (one launch per digit, look-back)
+//   k_merge_new  runs of new points -> centroid (seeded with the map's point of that voxel if any) at its
+//                merged position
+//   k_merge_old  untouched map points shift up by the number of new voxels before them (the map is read and
+//                written once: K*16 B in, V*16 B out = the algorithmic bytes of SURVEY.md 8d)
+// 8 launches per key frame instead of 35, no full-map sort.  What the merge assumes is checked on the fly
+// (map strictly increasing under the new indices, no int32 overflow); otherwise the key frame is redone by
+// the general path = the same sort over all points + a fused head-flag / scan / reduce kernel (7 launches),
+// which also serves orbgpu_voxel_filter and the loop-closure rebuild.  Equal indices keep input order in both
+// paths, so the per-voxel float sums are reproducible.  HBM-bound integer/float streaming; no MFMA.
 #include "common.h"
 
 #include <algorithm>
@@ -29,142 +40,83 @@ struct Pose {
     int apply;
 };
 
-__device__ __forceinline__ bool depth_valid(float d)
-{
-    // PointCloudMap.cc:121  `if (d < 0.01 || d>10) continue;`  (0.01 is a double literal)
-    return !((double)d < 0.01 || d > 10);
-}
-
-// valid samples per sample-row
-__global__ __launch_bounds__(256) void k_bp_count(const float *__restrict__ depth, size_t dstride, int w, int h,
-                                                  int *__restrict__ row_cnt)
-{
-    const int row = blockIdx.x;
-    const int m = row * 3;
-    const int gw = (w + 2) / 3;
-    int c = 0;
-    for (int j = threadIdx.x; j < gw; j += 256)
-        c += depth_valid(depth[(size_t)m * dstride + (size_t)j * 3]) ? 1 : 0;
-    c = wave_reduce_add(c);
-    __shared__ int s[4];
-    if ((threadIdx.x & 63) == 0)
-        s[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        row_cnt[row] = s[0] + s[1] + s[2] + s[3];
-}
-
-// exclusive scan of the row counts (gh <= a few thousand): one workgroup
-__global__ __launch_bounds__(256) void k_bp_scan(int *__restrict__ row_cnt, int gh, long long *__restrict__ total,
-                                                 long long base)
-{
-    __shared__ int s_carry;
-    __shared__ int s_w[4];
-    if (threadIdx.x == 0)
-        s_carry = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < gh; i0 += 256) {
-        const int i = i0 + threadIdx.x;
-        const int v = i < gh ? row_cnt[i] : 0;
-        int inc = v;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(inc, off, 64);
-            if (lane >= off)
-                inc += t;
-        }
-        if (lane == 63)
-            s_w[wave] = inc;
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int k = 0; k < 4; k++) {
-            if (k < wave)
-                woff += s_w[k];
-            tot += s_w[k];
-        }
-        if (i < gh)
-            row_cnt[i] = s_carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            s_carry += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        *total = base + s_carry;
-}
-
-__global__ __launch_bounds__(256) void k_bp_write(const float *__restrict__ depth, size_t dstride,
-                                                  const uint8_t *__restrict__ rgb, size_t cstride, int w, int h,
-                                                  float fx, float fy, float cx, float cy, Pose pose,
-                                                  const int *__restrict__ row_off, Point *__restrict__ out)
-{
-    __shared__ int s_w[4];
-    __shared__ int s_base;
-    const int row = blockIdx.x;
-    const int m = row * 3;
-    const int gw = (w + 2) / 3;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0)
-        s_base = row_off[row];
-    __syncthreads();
-    for (int j0 = 0; j0 < gw; j0 += 256) {
-        const int j = j0 + threadIdx.x;
-        const int n = j * 3;
-        float d = 0.f;
-        bool ok = false;
-        if (j < gw) {
-            d = depth[(size_t)m * dstride + (size_t)n];
-            ok = depth_valid(d);
-        }
-        const unsigned long long bal = __ballot(ok);
-        if (lane == 0)
-            s_w[wave] = __popcll(bal);
-        __syncthreads();
-        int off = s_base, tot = 0;
-        for (int k = 0; k < 4; k++) {
-            if (k < wave)
-                off += s_w[k];
-            tot += s_w[k];
-        }
-        off += __popcll(bal & ((1ull << lane) - 1ull));
-        if (ok) {
-            Point p;
-            p.z = d;
-            p.x = ((float)n - cx) * p.z / fx;  // :124-125, this exact operation order
-            p.y = ((float)m - cy) * p.z / fy;
-            const uint8_t *px = rgb + (size_t)m * cstride + (size_t)n * 3;
-            p.rgba = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
-            if (pose.apply && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-                // pcl::transformPointCloud with a double matrix (A8)
-                const double x = p.x, y = p.y, z = p.z;
-                const float ox = (float)(pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0]);
-                const float oy = (float)(pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1]);
-                const float oz = (float)(pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2]);
-                p.x = ox;
-                p.y = oy;
-                p.z = oz;
-            }
-            out[off] = p;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            s_base += tot;
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// P3 voxel grid
+// Decoupled look-back (single-pass device-wide prefix sums over tiles).
+//
+// Every kernel that needs an ordered prefix over its workgroups (compaction offsets, radix-sort digit
+// offsets, voxel output positions) takes a dynamic tile id from a ticket counter -- so a tile only ever
+// waits for tiles that have already started -- publishes its aggregate, sums the published values of its
+// predecessors until it meets an inclusive prefix, and publishes its own inclusive prefix.
+// Status word: [63:32] launch epoch (stale words of earlier launches never match, nothing is cleared
+// between launches), [31:30] 1 = aggregate / 2 = inclusive prefix, [29:0] value.  The last workgroup to
+// leave re-arms the ticket counter for the next launch on the stream.
 // ------------------------------------------------------------------------------------------
-struct VoxState {
-    unsigned mn[3], mx[3];  // order-preserving encodings of float min / max
-    int nfinite;
-    int min_b[3], div_b[3], mul[3];
-    int overflow;
-    int nout;
+struct LbCtl {
+    unsigned ticket, finished;
 };
+constexpr unsigned long long LB_AGG = 1ull << 30, LB_PREFIX = 2ull << 30, LB_FLAGS = 3ull << 30;
 
+__device__ __forceinline__ void lb_publish(unsigned long long *slot, unsigned epoch, unsigned long long flag, unsigned v)
+{
+    __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | flag | (unsigned long long)v, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// exclusive prefix of channel `chan` over tiles [0, tile); `stride` = channels per tile
+__device__ __forceinline__ unsigned lb_exclusive(unsigned long long *status, int stride, int chan, int tile,
+                                                 unsigned epoch)
+{
+    unsigned sum = 0;
+    for (int t = tile - 1; t >= 0; --t) {
+        unsigned long long w;
+        for (;;) {
+            w = __hip_atomic_load(status + (size_t)t * stride + chan, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == epoch && (w & LB_FLAGS))
+                break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        sum += (unsigned)(w & 0x3FFFFFFFull);
+        if (w & LB_PREFIX)
+            break;
+    }
+    return sum;
+}
+
+// one-channel convenience for a whole workgroup: thread 0 publishes / looks back, everybody gets the base
+__device__ __forceinline__ unsigned lb_tile_base(unsigned long long *status, int tile, unsigned epoch, unsigned agg,
+                                                 unsigned *s_slot)
+{
+    if (threadIdx.x == 0) {
+        unsigned base = 0;
+        if (tile > 0) {
+            lb_publish(status + tile, epoch, LB_AGG, agg);
+            base = lb_exclusive(status, 1, 0, tile, epoch);
+        }
+        lb_publish(status + tile, epoch, LB_PREFIX, base + agg);
+        *s_slot = base;
+    }
+    __syncthreads();
+    return *s_slot;
+}
+
+__device__ __forceinline__ void lb_leave(LbCtl *ctl)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&ctl->finished, 1u) == gridDim.x - 1) {
+            ctl->ticket = 0;
+            ctl->finished = 0;
+            __threadfence();
+        }
+    }
+}
+
+constexpr int TILE = 1024;  // elements per workgroup (256 threads x 4), order inside a tile: (round, wave, lane)
+
+// ------------------------------------------------------------------------------------------
+// bounding boxes (order-preserving encodings of float min / max) and PCL's voxel index
+// ------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned f2ord(float f)
 {
     unsigned b = __float_as_uint(f);
@@ -175,123 +127,328 @@ __device__ __forceinline__ float ord2f(unsigned o)
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
 }
 
-__global__ void k_vox_init(VoxState *st)
+struct Box {  // of finite points
+    unsigned mn[3], mx[3];
+    int nfinite;
+    int pad;
+};
+
+__device__ __forceinline__ void box_init(Box &b)
 {
     for (int a = 0; a < 3; a++) {
-        st->mn[a] = 0xFFFFFFFFu;
-        st->mx[a] = 0u;
+        b.mn[a] = 0xFFFFFFFFu;
+        b.mx[a] = 0u;
     }
-    st->nfinite = 0;
-    st->overflow = 0;
-    st->nout = 0;
+    b.nfinite = 0;
+    b.pad = 0;
 }
-
-__global__ __launch_bounds__(256) void k_vox_minmax(const Point *__restrict__ pts, long long n, VoxState *st)
+__device__ __forceinline__ void box_add(Box &b, const Point &p)
 {
-    unsigned mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0, 0, 0};
-    int nf = 0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const Point p = pts[i];
-        if (!isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z))
-            continue;
-        nf++;
-        const unsigned o[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
+    if (!isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z))
+        return;
+    const unsigned o[3] = {f2ord(p.x), f2ord(p.y), f2ord(p.z)};
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            mn[a] = min(mn[a], o[a]);
-            mx[a] = max(mx[a], o[a]);
-        }
+    for (int a = 0; a < 3; a++) {
+        b.mn[a] = min(b.mn[a], o[a]);
+        b.mx[a] = max(b.mx[a], o[a]);
     }
+    b.nfinite++;
+}
+__device__ __forceinline__ void box_merge(Box &b, const Box &o)
+{
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        b.mn[a] = min(b.mn[a], o.mn[a]);
+        b.mx[a] = max(b.mx[a], o.mx[a]);
+    }
+    b.nfinite += o.nfinite;
+}
+// workgroup (256 threads) reduction; the result is valid in every thread
+__device__ __forceinline__ void box_block_reduce(Box &b, Box *s_box /* [4] */)
+{
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            mn[a] = min(mn[a], (unsigned)__shfl_xor((int)mn[a], off, 64));
-            mx[a] = max(mx[a], (unsigned)__shfl_xor((int)mx[a], off, 64));
+            b.mn[a] = min(b.mn[a], (unsigned)__shfl_xor((int)b.mn[a], off, 64));
+            b.mx[a] = max(b.mx[a], (unsigned)__shfl_xor((int)b.mx[a], off, 64));
         }
-        nf += __shfl_xor(nf, off, 64);
-    }
-    // one set of atomics per workgroup (all workgroups hit the same 7 words: keep them few)
-    __shared__ unsigned s_mn[4][3], s_mx[4][3];
-    __shared__ int s_nf[4];
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            s_mn[wave][a] = mn[a];
-            s_mx[wave][a] = mx[a];
-        }
-        s_nf[wave] = nf;
+        b.nfinite += __shfl_xor(b.nfinite, off, 64);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < 4; w++)
-            tot += s_nf[w];
-        if (tot) {
+    if ((threadIdx.x & 63) == 0)
+        s_box[threadIdx.x >> 6] = b;
+    __syncthreads();
+    b = s_box[0];
+    for (int w = 1; w < 4; w++)
+        box_merge(b, s_box[w]);
+}
+__device__ __forceinline__ void box_atomic(unsigned *box6, const Box &b)  // box6 = mn[3], mx[3]
+{
+    if (!b.nfinite)
+        return;
 #pragma unroll
-            for (int a = 0; a < 3; a++) {
-                unsigned lo = 0xFFFFFFFFu, hi = 0u;
-                for (int w = 0; w < 4; w++) {
-                    lo = min(lo, s_mn[w][a]);
-                    hi = max(hi, s_mx[w][a]);
-                }
-                atomicMin(&st->mn[a], lo);
-                atomicMax(&st->mx[a], hi);
-            }
-            atomicAdd(&st->nfinite, tot);
-        }
+    for (int a = 0; a < 3; a++) {
+        atomicMin(&box6[a], b.mn[a]);
+        atomicMax(&box6[3 + a], b.mx[a]);
     }
 }
+
+// state of one filter call, device resident; the host reads it back when the call has been queued
+struct CloudState {
+    int n_sort;    // elements in the sort (fast path: the new points; general path: the whole input)
+    int nfinite;   // finite ones among them (they sort to the front, non-finite keys are 0xFFFFFFFF)
+    int min_b[3], div_b[3], mul[3];
+    int overflow;  // PCL's int32 voxel-index overflow rule fired
+    int unsorted;  // fast path only: the old map is not strictly increasing under the new keys
+    int nout;
+};
+
+struct VoxSetup {
+    int min_b[3], mul[3];
+    int overflow, valid;
+};
 
 // PCL 1.7 VoxelGrid::applyFilter set-up (A7): overflow test, min_b, div_b, divb_mul
-__global__ void k_vox_setup(VoxState *st, float inv)
+__device__ __forceinline__ void vox_setup(const Box &b, float inv, VoxSetup &v, CloudState *st_out)
 {
-    if (st->nfinite == 0)
-        return;
-    float mn[3], mx[3];
-    for (int a = 0; a < 3; a++) {
-        mn[a] = ord2f(st->mn[a]);
-        mx[a] = ord2f(st->mx[a]);
+    v.overflow = 0;
+    v.valid = b.nfinite > 0;
+    for (int a = 0; a < 3; a++)
+        v.min_b[a] = v.mul[a] = 0;
+    int div_b[3] = {0, 0, 0};
+    if (v.valid) {
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; a++) {
+            mn[a] = ord2f(b.mn[a]);
+            mx[a] = ord2f(b.mx[a]);
+        }
+        const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1;
+        const long long dy = (long long)((mx[1] - mn[1]) * inv) + 1;
+        const long long dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+        if (dx * dy * dz > 2147483647ll) {
+            v.overflow = 1;
+        } else {
+            for (int a = 0; a < 3; a++) {
+                v.min_b[a] = (int)floorf(mn[a] * inv);
+                const int max_b = (int)floorf(mx[a] * inv);
+                div_b[a] = max_b - v.min_b[a] + 1;
+            }
+            v.mul[0] = 1;
+            v.mul[1] = div_b[0];
+            v.mul[2] = div_b[0] * div_b[1];
+        }
     }
-    const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1;
-    const long long dy = (long long)((mx[1] - mn[1]) * inv) + 1;
-    const long long dz = (long long)((mx[2] - mn[2]) * inv) + 1;
-    if (dx * dy * dz > 2147483647ll) {
-        st->overflow = 1;
-        return;
+    if (st_out) {
+        for (int a = 0; a < 3; a++) {
+            st_out->min_b[a] = v.min_b[a];
+            st_out->div_b[a] = div_b[a];
+            st_out->mul[a] = v.mul[a];
+        }
+        st_out->overflow = v.overflow;
+        st_out->nfinite = b.nfinite;
+        st_out->unsorted = 0;
+        st_out->nout = 0;
     }
-    for (int a = 0; a < 3; a++) {
-        st->min_b[a] = (int)floorf(mn[a] * inv);
-        const int max_b = (int)floorf(mx[a] * inv);
-        st->div_b[a] = max_b - st->min_b[a] + 1;
-    }
-    st->mul[0] = 1;
-    st->mul[1] = st->div_b[0];
-    st->mul[2] = st->div_b[0] * st->div_b[1];
 }
 
-__global__ __launch_bounds__(256) void k_vox_keys(const Point *__restrict__ pts, long long n, const VoxState *st,
-                                                  float inv, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals)
+__device__ __forceinline__ uint32_t vox_key(const Point &p, float inv, const int min_b[3], const int mul[3])
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || st->overflow)
-        return;
-    const Point p = pts[i];
-    uint32_t key = 0xFFFFFFFFu;  // non-finite points sort to the end and are dropped
-    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
-        const int i0 = (int)(floorf(p.x * inv) - (float)st->min_b[0]);
-        const int i1 = (int)(floorf(p.y * inv) - (float)st->min_b[1]);
-        const int i2 = (int)(floorf(p.z * inv) - (float)st->min_b[2]);
-        key = (uint32_t)(i0 * st->mul[0] + i1 * st->mul[1] + i2 * st->mul[2]);
-    }
-    keys[i] = key;
-    vals[i] = (uint32_t)i;
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z)))
+        return 0xFFFFFFFFu;  // non-finite points sort to the end and are dropped
+    const int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
+    const int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
+    const int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
+    return (uint32_t)(i0 * mul[0] + i1 * mul[1] + i2 * mul[2]);
 }
 
-// ---- stable LSD radix sort, 8-bit digits, tiles of 1024 = 4 rounds x 256 threads -----------
-constexpr int RS_TILE = 1024;
+// ------------------------------------------------------------------------------------------
+// P1/P2: stride-3 back-projection (+ SE3 transform), compacted in scan order in ONE launch
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool depth_valid(float d)
+{
+    // PointCloudMap.cc:121  `if (d < 0.01 || d>10) continue;`  (0.01 is a double literal)
+    return !((double)d < 0.01 || d > 10);
+}
 
+// A tile = 1024 consecutive samples of the (ceil(w/3) x ceil(h/3)) sample grid in raster order.  Valid samples
+// are counted with wave ballots, the tile's offset comes from the look-back, points are written in raster order
+// (the reference's push_back order).  Also: the tile's bounding box (what the voxel set-up of the next kernel
+// needs), the total count, and the re-initialisation of the accumulators later kernels of the sequence add into.
+__global__ __launch_bounds__(256) void k_bp(const float *__restrict__ depth, size_t dstride,
+                                            const uint8_t *__restrict__ rgb, size_t cstride, int w, int h, float fx,
+                                            float fy, float cx, float cy, Pose pose, Point *__restrict__ out,
+                                            LbCtl *ctl, unsigned long long *status, unsigned epoch,
+                                            Box *__restrict__ part, int *__restrict__ n_out,
+                                            unsigned *__restrict__ ghist, unsigned *__restrict__ outbox)
+{
+    __shared__ int s_tile;
+    __shared__ unsigned s_cnt[16], s_base;
+    __shared__ Box s_box[4];
+    if (threadIdx.x == 0)
+        s_tile = (int)atomicAdd(&ctl->ticket, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    const int gw = (w + 2) / 3, gh = (h + 2) / 3;
+    const int ns = gw * gh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (tile == 0) {
+        if (ghist)
+            for (int i = threadIdx.x; i < 4 * 256; i += 256)
+                ghist[i] = 0u;
+        if (outbox && threadIdx.x < 6)
+            outbox[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+    }
+    float d[4];
+    bool ok[4];
+    int mm[4], nn[4];
+    unsigned rank[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int s = tile * TILE + k * 256 + threadIdx.x;
+        ok[k] = false;
+        d[k] = 0.f;
+        mm[k] = nn[k] = 0;
+        if (s < ns) {
+            const int r = s / gw;
+            mm[k] = r * 3;
+            nn[k] = (s - r * gw) * 3;
+            d[k] = depth[(size_t)mm[k] * dstride + (size_t)nn[k]];
+            ok[k] = depth_valid(d[k]);
+        }
+        const unsigned long long bal = __ballot(ok[k]);
+        rank[k] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_cnt[k * 4 + wave] = __popcll(bal);
+    }
+    __syncthreads();
+    unsigned tot = 0, pre[4];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        if ((s & 3) == wave)
+            pre[s >> 2] = tot;
+        tot += s_cnt[s];
+    }
+    const unsigned base = lb_tile_base(status, tile, epoch, tot, &s_base);
+    Box bx;
+    box_init(bx);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!ok[k])
+            continue;
+        Point p;
+        p.z = d[k];
+        p.x = ((float)nn[k] - cx) * p.z / fx;  // :124-125, this exact operation order
+        p.y = ((float)mm[k] - cy) * p.z / fy;
+        const uint8_t *px = rgb + (size_t)mm[k] * cstride + (size_t)nn[k] * 3;
+        p.rgba = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+        if (pose.apply && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            // pcl::transformPointCloud with a double matrix (A8)
+            const double x = p.x, y = p.y, z = p.z;
+            const float ox = (float)(pose.R[0] * x + pose.R[1] * y + pose.R[2] * z + pose.t[0]);
+            const float oy = (float)(pose.R[3] * x + pose.R[4] * y + pose.R[5] * z + pose.t[1]);
+            const float oz = (float)(pose.R[6] * x + pose.R[7] * y + pose.R[8] * z + pose.t[2]);
+            p.x = ox;
+            p.y = oy;
+            p.z = oz;
+        }
+        box_add(bx, p);
+        out[base + pre[k] + rank[k]] = p;
+    }
+    box_block_reduce(bx, s_box);
+    if (threadIdx.x == 0) {
+        part[tile] = bx;
+        if (tile == (ns + TILE - 1) / TILE - 1)
+            *n_out = (int)(base + tot);
+    }
+    lb_leave(ctl);
+}
+
+// ------------------------------------------------------------------------------------------
+// P3 voxel grid
+// ------------------------------------------------------------------------------------------
+// general path, first kernel: per-workgroup bounding boxes of the whole input + accumulator re-initialisation
+__global__ __launch_bounds__(256) void k_vox_minmax(const Point *__restrict__ pts, int n, Box *__restrict__ part,
+                                                    CloudState *st, unsigned *__restrict__ ghist,
+                                                    unsigned *__restrict__ outbox)
+{
+    __shared__ Box s_box[4];
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < 4 * 256; i += 256)
+            ghist[i] = 0u;
+        if (threadIdx.x < 6)
+            outbox[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+        if (threadIdx.x == 0)
+            st->n_sort = n;
+    }
+    Box bx;
+    box_init(bx);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        box_add(bx, pts[i]);
+    box_block_reduce(bx, s_box);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = bx;
+}
+
+// Every workgroup reduces the partial boxes (plus the box of the resident map on the fast path), evaluates PCL's
+// set-up redundantly, computes the voxel index of its tile's points and adds its four 8-bit digit histograms to
+// the global ones (the radix passes need them up front).  n is read from the device (`n_dev`).
+__global__ __launch_bounds__(256) void k_vox_keys(const Point *__restrict__ pts, const int *__restrict__ n_dev,
+                                                  const Box *__restrict__ part, int nparts,
+                                                  const unsigned *__restrict__ oldbox, float inv, CloudState *st,
+                                                  uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                  unsigned *__restrict__ ghist)
+{
+    __shared__ Box s_box[4];
+    __shared__ unsigned s_h[4 * 256];
+    const int n = *n_dev;
+    if ((long long)blockIdx.x * TILE >= n && blockIdx.x != 0)
+        return;
+    Box bx;
+    box_init(bx);
+    for (int i = threadIdx.x; i < nparts; i += 256)
+        box_merge(bx, part[i]);
+    box_block_reduce(bx, s_box);
+    int nf_sort = bx.nfinite;
+    if (oldbox) {  // the resident map: all finite, its box is maintained exactly by the previous call
+        Box ob;
+        for (int a = 0; a < 3; a++) {
+            ob.mn[a] = oldbox[a];
+            ob.mx[a] = oldbox[3 + a];
+        }
+        ob.nfinite = 1;
+        box_merge(bx, ob);
+    }
+    VoxSetup vs;
+    vox_setup(bx, inv, vs, (blockIdx.x == 0 && threadIdx.x == 0) ? st : nullptr);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->n_sort = n;
+        st->nfinite = nf_sort;
+    }
+    if (vs.overflow)
+        return;
+    for (int i = threadIdx.x; i < 4 * 256; i += 256)
+        s_h[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long i = (long long)blockIdx.x * TILE + k * 256 + threadIdx.x;
+        if (i < n) {
+            const uint32_t key = vox_key(pts[i], inv, vs.min_b, vs.mul);
+            keys[i] = key;
+            vals[i] = (uint32_t)i;
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++)
+                atomicAdd(&s_h[ps * 256 + ((key >> (8 * ps)) & 255u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * 256; i += 256)
+        if (s_h[i])
+            atomicAdd(&ghist[i], s_h[i]);
+}
+
+// ---- stable LSD radix sort: one launch per 8-bit digit (look-back over tiles, wave-ballot ranking) ---------
 __device__ __forceinline__ unsigned long long match_digit(unsigned d, bool valid)
 {
     // lanes of the wave holding the same 8-bit digit (invalid lanes match nobody)
@@ -304,249 +461,430 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned d, bool valid
     return peers;
 }
 
-__global__ __launch_bounds__(256) void k_rs_hist(const uint32_t *__restrict__ keys, long long n, int shift,
-                                                 int nblocks, const VoxState *st, unsigned *__restrict__ hist)
-{
-    __shared__ unsigned h[256];
-    if (st->overflow)
-        return;
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const long long base = (long long)blockIdx.x * RS_TILE;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const long long i = base + k * 256 + threadIdx.x;
-        if (i < n)
-            atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];  // digit-major
-}
-
-// device-wide exclusive scan (three kernels): per-tile sums, scan of the sums, add back
-__global__ __launch_bounds__(256) void k_scan_tiles(unsigned *__restrict__ a, long long n,
-                                                    unsigned *__restrict__ tile_sum)
-{
-    __shared__ unsigned s_w[4];
-    const long long base = (long long)blockIdx.x * RS_TILE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned v[4], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const long long i = base + (long long)threadIdx.x * 4 + k;
-        v[k] = i < n ? a[i] : 0u;
-        sum += v[k];
-    }
-    unsigned inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        unsigned t = (unsigned)__shfl_up((int)inc, off, 64);
-        if (lane >= off)
-            inc += t;
-    }
-    if (lane == 63)
-        s_w[wave] = inc;
-    __syncthreads();
-    unsigned woff = 0, tot = 0;
-    for (int k = 0; k < 4; k++) {
-        if (k < wave)
-            woff += s_w[k];
-        tot += s_w[k];
-    }
-    unsigned run = woff + inc - sum;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const long long i = base + (long long)threadIdx.x * 4 + k;
-        if (i < n)
-            a[i] = run;
-        run += v[k];
-    }
-    if (threadIdx.x == 0)
-        tile_sum[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(256) void k_scan_sums(unsigned *__restrict__ tile_sum, int ntiles,
-                                                   unsigned *__restrict__ total)
-{
-    __shared__ unsigned s_carry;
-    __shared__ unsigned s_w[4];
-    if (threadIdx.x == 0)
-        s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i0 = 0; i0 < ntiles; i0 += 256) {
-        const int i = i0 + threadIdx.x;
-        const unsigned v = i < ntiles ? tile_sum[i] : 0u;
-        unsigned inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned t = (unsigned)__shfl_up((int)inc, off, 64);
-            if (lane >= off)
-                inc += t;
-        }
-        if (lane == 63)
-            s_w[wave] = inc;
-        __syncthreads();
-        unsigned woff = 0, tot = 0;
-        for (int k = 0; k < 4; k++) {
-            if (k < wave)
-                woff += s_w[k];
-            tot += s_w[k];
-        }
-        if (i < ntiles)
-            tile_sum[i] = s_carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            s_carry += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total)
-        *total = s_carry;
-}
-
-__global__ __launch_bounds__(256) void k_scan_add(unsigned *__restrict__ a, long long n,
-                                                  const unsigned *__restrict__ tile_sum)
-{
-    const long long base = (long long)blockIdx.x * RS_TILE;
-    const unsigned add = tile_sum[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const long long i = base + k * 256 + threadIdx.x;
-        if (i < n)
-            a[i] += add;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
-                                                    const uint32_t *__restrict__ vals_in, long long n, int shift,
-                                                    int nblocks, const VoxState *st,
-                                                    const unsigned *__restrict__ hist_scanned,
-                                                    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out)
+__global__ __launch_bounds__(256) void k_sort_pass(const uint32_t *__restrict__ keys_in,
+                                                   const uint32_t *__restrict__ vals_in,
+                                                   uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                   const CloudState *__restrict__ st, int shift,
+                                                   const unsigned *__restrict__ ghist /* this pass: [256] */,
+                                                   LbCtl *ctl, unsigned long long *status, unsigned epoch)
 {
     // h[round][wave][digit]: elements of the tile are ordered (round, wave, lane)
     __shared__ unsigned h[16 * 256];
-    if (st->overflow)
-        return;
-    for (int i = threadIdx.x; i < 16 * 256; i += 256)
-        h[i] = 0;
+    __shared__ unsigned s_scan[256];
+    __shared__ int s_tile;
+    if (threadIdx.x == 0)
+        s_tile = (int)atomicAdd(&ctl->ticket, 1u);
     __syncthreads();
-    const long long base = (long long)blockIdx.x * RS_TILE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t key[4], val[4];
-    unsigned rank[4];
-    bool valid[4];
+    const int tile = s_tile;
+    const int n = st->n_sort;
+    const int ntiles = (n + TILE - 1) / TILE;
+    if (tile < ntiles && !st->overflow) {
+        const long long base = (long long)tile * TILE;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t key[4], val[4];
+        bool valid[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const long long i = base + k * 256 + threadIdx.x;
-        valid[k] = i < n;
-        key[k] = valid[k] ? keys_in[i] : 0u;
-        val[k] = valid[k] ? vals_in[i] : 0u;
-        const unsigned d = (key[k] >> shift) & 255u;
-        const unsigned long long peers = match_digit(d, valid[k]);
-        rank[k] = __popcll(peers & ((1ull << lane) - 1ull));
-        if (valid[k] && rank[k] == 0)
-            h[(k * 4 + wave) * 256 + d] = __popcll(peers);
-    }
-    __syncthreads();
-    {  // exclusive prefix over the 16 (round, wave) slots, one digit per thread
-        unsigned run = hist_scanned[(size_t)threadIdx.x * nblocks + blockIdx.x];
-        for (int s = 0; s < 16; s++) {
-            const unsigned c = h[s * 256 + threadIdx.x];
-            h[s * 256 + threadIdx.x] = run;
-            run += c;
+        for (int k = 0; k < 4; k++) {
+            const long long i = base + k * 256 + threadIdx.x;
+            valid[k] = i < n;
+            key[k] = valid[k] ? keys_in[i] : 0u;
+            val[k] = valid[k] ? vals_in[i] : 0u;
+        }
+        // a digit every key shares (the high digits of a small grid): the pass is the identity
+        const bool trivial = ghist[(keys_in[0] >> shift) & 255u] == (unsigned)n;
+        if (trivial) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const long long i = base + k * 256 + threadIdx.x;
+                if (valid[k]) {
+                    keys_out[i] = key[k];
+                    vals_out[i] = val[k];
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < 16 * 256; i += 256)
+                h[i] = 0;
+            __syncthreads();
+            unsigned rank[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned d = (key[k] >> shift) & 255u;
+                const unsigned long long peers = match_digit(d, valid[k]);
+                rank[k] = __popcll(peers & ((1ull << lane) - 1ull));
+                if (valid[k] && rank[k] == 0)
+                    h[(k * 4 + wave) * 256 + d] = __popcll(peers);
+            }
+            __syncthreads();
+            // thread = digit: exclusive prefix over the 16 (round, wave) slots, tile total, look-back over the
+            // earlier tiles, exclusive scan of the global histogram over the digits
+            unsigned run = 0;
+            for (int s = 0; s < 16; s++) {
+                const unsigned c = h[s * 256 + threadIdx.x];
+                h[s * 256 + threadIdx.x] = run;
+                run += c;
+            }
+            unsigned long long *slot = status + (size_t)tile * 256 + threadIdx.x;
+            unsigned before = 0;
+            if (tile > 0) {
+                lb_publish(slot, epoch, LB_AGG, run);
+                before = lb_exclusive(status, 256, threadIdx.x, tile, epoch);
+            }
+            lb_publish(slot, epoch, LB_PREFIX, before + run);
+            {
+                const unsigned g = ghist[threadIdx.x];
+                unsigned inc = g;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned t = (unsigned)__shfl_up((int)inc, off, 64);
+                    if (lane >= off)
+                        inc += t;
+                }
+                if (lane == 63)
+                    s_scan[wave] = inc;
+                __syncthreads();
+                unsigned woff = 0;
+                for (int k = 0; k < wave; k++)
+                    woff += s_scan[k];
+                __syncthreads();
+                s_scan[threadIdx.x] = woff + inc - g + before;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!valid[k])
+                    continue;
+                const unsigned d = (key[k] >> shift) & 255u;
+                const unsigned pos = s_scan[d] + h[(k * 4 + wave) * 256 + d] + rank[k];
+                keys_out[pos] = key[k];
+                vals_out[pos] = val[k];
+            }
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (!valid[k])
-            continue;
-        const unsigned d = (key[k] >> shift) & 255u;
-        const unsigned pos = h[(k * 4 + wave) * 256 + d] + rank[k];
-        keys_out[pos] = key[k];
-        vals_out[pos] = val[k];
-    }
+    lb_leave(ctl);
 }
 
-// head flag of every voxel run (finite points only)
-__global__ __launch_bounds__(256) void k_vox_heads(const uint32_t *__restrict__ keys, long long n,
-                                                   const VoxState *st, unsigned *__restrict__ flag)
+// voxel centroid of a run of sorted elements [j, ...) sharing `key`, optionally seeded with the resident map's
+// point of that voxel (which precedes the new points in PCL's input order): float sums in input order (A7)
+__device__ __forceinline__ Point vox_centroid(const Point *__restrict__ pts, const uint32_t *__restrict__ keys,
+                                              const uint32_t *__restrict__ vals, int j, int nf, uint32_t key,
+                                              const Point *seed)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n)
-        return;
-    unsigned f = 0;
-    if (!st->overflow && i < st->nfinite)
-        f = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-    flag[i] = f;
-}
-
-// one thread per voxel run: float sums in sorted (= input) order, PCL's centroid + rgb packing
-__global__ __launch_bounds__(256) void k_vox_reduce(const Point *__restrict__ pts, const uint32_t *__restrict__ keys,
-                                                    const uint32_t *__restrict__ vals, long long n,
-                                                    const unsigned *__restrict__ pos, VoxState *st,
-                                                    Point *__restrict__ out)
-{
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (st->overflow) {
-        if (i < n)
-            out[i] = pts[i];  // PCL: "Leaf size is too small" -> output = input
-        if (i == 0)
-            st->nout = (int)n;
-        return;
-    }
-    const int nf = st->nfinite;
-    if (i >= nf)
-        return;
-    const uint32_t k = keys[i];
-    if (i != 0 && keys[i - 1] == k)
-        return;
     float sx = 0, sy = 0, sz = 0, sr = 0, sg = 0, sb = 0;
-    long long j = i;
-    for (; j < nf && keys[j] == k; j++) {
+    int cnt = 0;
+    if (seed) {
+        sx = seed->x; sy = seed->y; sz = seed->z;
+        sr = (float)((seed->rgba >> 16) & 255u); sg = (float)((seed->rgba >> 8) & 255u); sb = (float)(seed->rgba & 255u);
+        cnt = 1;
+    }
+    for (; j < nf && keys[j] == key; j++, cnt++) {
         const Point p = pts[vals[j]];
         const float r = (float)((p.rgba >> 16) & 255u), g = (float)((p.rgba >> 8) & 255u), b = (float)(p.rgba & 255u);
-        if (j == i) {
+        if (cnt == 0) {
             sx = p.x; sy = p.y; sz = p.z; sr = r; sg = g; sb = b;
         } else {
             sx += p.x; sy += p.y; sz += p.z; sr += r; sg += g; sb += b;
         }
     }
-    const float cnt = (float)(j - i);
+    const float c = (float)cnt;
     Point o;
-    o.x = sx / cnt;
-    o.y = sy / cnt;
-    o.z = sz / cnt;
-    const int ri = (int)(sr / cnt), gi = (int)(sg / cnt), bi = (int)(sb / cnt);
+    o.x = sx / c;
+    o.y = sy / c;
+    o.z = sz / c;
+    const int ri = (int)(sr / c), gi = (int)(sg / c), bi = (int)(sb / c);
     o.rgba = (uint32_t)((ri << 16) | (gi << 8) | bi);
-    out[pos[i]] = o;
-    if (j == nf)
-        st->nout = (int)pos[i] + 1;
+    return o;
+}
+
+// tile-local exclusive scan of one flag per element in (round, wave, lane) order; returns the tile total
+__device__ __forceinline__ unsigned tile_flag_scan(const bool f[4], unsigned excl[4], unsigned *s_cnt /* [16] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long bal = __ballot(f[k]);
+        excl[k] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_cnt[k * 4 + wave] = __popcll(bal);
+    }
+    __syncthreads();
+    unsigned tot = 0;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        if ((s & 3) == wave)
+            excl[s >> 2] += tot;
+        tot += s_cnt[s];
+    }
+    return tot;
+}
+
+// general path, last kernel: run heads of the sorted keys -> output positions (look-back) -> one thread per voxel
+// sums its run; PCL's overflow rule copies the input instead.  Also the bounding box of the output (the next
+// insert's set-up needs the box of the resident map).
+__global__ __launch_bounds__(256) void k_vox_reduce(const Point *__restrict__ pts, int n_in,
+                                                    const uint32_t *__restrict__ keys,
+                                                    const uint32_t *__restrict__ vals, CloudState *st,
+                                                    Point *__restrict__ out, LbCtl *ctl, unsigned long long *status,
+                                                    unsigned epoch, unsigned *__restrict__ outbox)
+{
+    __shared__ int s_tile;
+    __shared__ unsigned s_cnt[16], s_base;
+    __shared__ Box s_box[4];
+    if (threadIdx.x == 0)
+        s_tile = (int)atomicAdd(&ctl->ticket, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    const int ntiles = (n_in + TILE - 1) / TILE;
+    if (st->overflow) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long i = (long long)tile * TILE + k * 256 + threadIdx.x;
+            if (i < n_in)
+                out[i] = pts[i];  // PCL: "Leaf size is too small" -> output = input
+        }
+        if (tile == 0 && threadIdx.x == 0)
+            st->nout = n_in;
+    } else {
+        const int nf = st->nfinite;
+        bool head[4];
+        unsigned excl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long i = (long long)tile * TILE + k * 256 + threadIdx.x;
+            head[k] = i < nf && (i == 0 || keys[i] != keys[i - 1]);
+        }
+        const unsigned tot = tile_flag_scan(head, excl, s_cnt);
+        const unsigned base = lb_tile_base(status, tile, epoch, tot, &s_base);
+        Box bx;
+        box_init(bx);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!head[k])
+                continue;
+            const int i = tile * TILE + k * 256 + threadIdx.x;
+            const Point o = vox_centroid(pts, keys, vals, i, nf, keys[i], nullptr);
+            out[base + excl[k]] = o;
+            box_add(bx, o);
+        }
+        box_block_reduce(bx, s_box);
+        if (threadIdx.x == 0) {
+            box_atomic(outbox, bx);
+            if (tile == ntiles - 1)
+                st->nout = (int)(base + tot);
+        }
+    }
+    lb_leave(ctl);
+}
+
+// ---- fast path: merge the sorted new points into the resident (sorted, one point per voxel) map ----------------
+__device__ __forceinline__ int old_upper_bound(const Point *__restrict__ old, int K, uint32_t key, float inv,
+                                               const int min_b[3], const int mul[3])
+{
+    int lo = 0, hi = K;  // first index whose key is > key
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (vox_key(old[mid], inv, min_b, mul) <= key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int key_lower_bound(const uint32_t *__restrict__ a, int lo, int hi, uint32_t key)
+{
+    while (lo < hi) {  // first index in [lo, hi) whose key is >= key
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// new-point side: every run of equal keys among the sorted new points becomes one output voxel -- merged with the
+// resident map's point of that voxel if there is one (it comes first in PCL's input order), a new voxel otherwise.
+// cexcl[j] = new voxels opened by runs before j (look-back); a run's output position is its rank among the
+// resident points plus that count.
+__global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old, int K,
+                                                   const Point *__restrict__ newp, const uint32_t *__restrict__ skeys,
+                                                   const uint32_t *__restrict__ svals, float inv, CloudState *st,
+                                                   unsigned *__restrict__ cexcl, Point *__restrict__ out, LbCtl *ctl,
+                                                   unsigned long long *status, unsigned epoch,
+                                                   unsigned *__restrict__ outbox)
+{
+    __shared__ int s_tile;
+    __shared__ unsigned s_cnt[16], s_base;
+    __shared__ Box s_box[4];
+    if (threadIdx.x == 0)
+        s_tile = (int)atomicAdd(&ctl->ticket, 1u);
+    __syncthreads();
+    const int tile = s_tile;
+    const int nf = st->nfinite;
+    const int ntiles = max((nf + TILE - 1) / TILE, 1);
+    if (tile < ntiles && !st->overflow) {
+        int min_b[3], mul[3];
+        for (int a = 0; a < 3; a++) {
+            min_b[a] = st->min_b[a];
+            mul[a] = st->mul[a];
+        }
+        bool head[4], opens[4];
+        int rnk[4];
+        uint32_t key[4];
+        unsigned excl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = tile * TILE + k * 256 + threadIdx.x;
+            head[k] = opens[k] = false;
+            rnk[k] = 0;
+            key[k] = 0;
+            if (j < nf) {
+                key[k] = skeys[j];
+                head[k] = j == 0 || skeys[j - 1] != key[k];
+                if (head[k]) {
+                    rnk[k] = old_upper_bound(old, K, key[k], inv, min_b, mul);
+                    const bool exists = rnk[k] > 0 && vox_key(old[rnk[k] - 1], inv, min_b, mul) == key[k];
+                    opens[k] = !exists;
+                    if (exists)
+                        rnk[k] = -rnk[k];  // negative: merges into resident point -rnk-1 ... see below
+                }
+            }
+        }
+        const unsigned tot = tile_flag_scan(opens, excl, s_cnt);
+        const unsigned base = lb_tile_base(status, tile, epoch, tot, &s_base);
+        Box bx;
+        box_init(bx);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = tile * TILE + k * 256 + threadIdx.x;
+            if (j < nf)
+                cexcl[j] = base + excl[k];
+            if (!head[k])
+                continue;
+            Point o;
+            int pos;
+            if (rnk[k] < 0) {
+                const Point seed = old[-rnk[k] - 1];
+                o = vox_centroid(newp, skeys, svals, j, nf, key[k], &seed);
+                pos = (-rnk[k] - 1) + (int)(base + excl[k]);
+            } else {
+                o = vox_centroid(newp, skeys, svals, j, nf, key[k], nullptr);
+                pos = rnk[k] + (int)(base + excl[k]);
+            }
+            out[pos] = o;
+            box_add(bx, o);
+        }
+        box_block_reduce(bx, s_box);
+        if (threadIdx.x == 0) {
+            box_atomic(outbox, bx);
+            if (tile == ntiles - 1) {
+                cexcl[nf] = base + tot;
+                st->nout = K + (int)(base + tot);
+            }
+        }
+    }
+    lb_leave(ctl);
+}
+
+// resident side: a point whose voxel received no new point moves up by the number of new voxels that sort before
+// it.  Also checks that the resident map really is strictly increasing under the new keys (a centroid rounded
+// onto a voxel boundary, or a map left unfiltered by the overflow rule, is not): the host then redoes the
+// key frame through the general path.
+__global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old, int K,
+                                                   const uint32_t *__restrict__ skeys,
+                                                   const unsigned *__restrict__ cexcl, float inv, CloudState *st,
+                                                   Point *__restrict__ out, unsigned *__restrict__ outbox)
+{
+    __shared__ Box s_box[4];
+    __shared__ int s_lo, s_hi;
+    if (st->overflow)
+        return;
+    const int nf = st->nfinite;
+    int min_b[3], mul[3];
+    for (int a = 0; a < 3; a++) {
+        min_b[a] = st->min_b[a];
+        mul[a] = st->mul[a];
+    }
+    const int i0 = blockIdx.x * TILE, i1 = min(i0 + TILE, K) - 1;
+    if (threadIdx.x == 0)
+        s_lo = key_lower_bound(skeys, 0, nf, vox_key(old[i0], inv, min_b, mul));
+    if (threadIdx.x == 64)
+        s_hi = key_lower_bound(skeys, 0, nf, vox_key(old[i1], inv, min_b, mul));
+    __syncthreads();
+    const int lo = s_lo, hi = max(s_hi, s_lo);
+    Box bx;
+    box_init(bx);
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = i0 + k * 256 + threadIdx.x;
+        if (i >= K)
+            continue;
+        const Point p = old[i];
+        const uint32_t key = vox_key(p, inv, min_b, mul);
+        if (i > 0 && vox_key(old[i - 1], inv, min_b, mul) >= key)
+            bad = true;
+        int lb = key_lower_bound(skeys, lo, hi, key);
+        lb = min(max(lb, 0), nf);
+        if (lb < nf && skeys[lb] == key)
+            continue;  // merged by k_merge_new
+        out[i + (int)cexcl[lb]] = p;
+        box_add(bx, p);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0)
+        st->unsorted = 1;
+    box_block_reduce(bx, s_box);
+    if (threadIdx.x == 0)
+        box_atomic(outbox, bx);
 }
 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct VoxelWorkspace {
-    DevBuf keys[2], vals[2], hist, tile_sum, flag, state;
-    int reserve(long long n)
+    DevBuf keys[2], vals[2], status, part, cexcl, ctl, state, ghist;
+    unsigned epoch = 0;
+    bool armed = false;
+    int reserve(long long n_sort, int nparts)
     {
-        const long long nb = (n + RS_TILE - 1) / RS_TILE;
+        const long long nt = std::max<long long>((n_sort + TILE - 1) / TILE, 1);
         int rc;
         for (int k = 0; k < 2; k++) {
-            if ((rc = keys[k].reserve(sizeof(uint32_t) * (size_t)n)) != ORBGPU_OK)
+            if ((rc = keys[k].reserve(sizeof(uint32_t) * (size_t)std::max<long long>(n_sort, 1))) != ORBGPU_OK)
                 return rc;
-            if ((rc = vals[k].reserve(sizeof(uint32_t) * (size_t)n)) != ORBGPU_OK)
+            if ((rc = vals[k].reserve(sizeof(uint32_t) * (size_t)std::max<long long>(n_sort, 1))) != ORBGPU_OK)
                 return rc;
         }
-        if ((rc = hist.reserve(sizeof(unsigned) * 256 * (size_t)nb)) != ORBGPU_OK)
+        // status words: 256 channels per tile for the radix passes; never cleared (epoch-tagged), but fresh
+        // allocations must not alias a live epoch: zero them
+        const size_t sb = sizeof(unsigned long long) * 256 * (size_t)nt;
+        if (sb > status.bytes) {
+            if ((rc = status.reserve(sb)) != ORBGPU_OK)
+                return rc;
+            ORBGPU_HIP_TRY(hipMemset(status.p, 0, status.bytes));
+            ORBGPU_HIP_TRY(hipDeviceSynchronize());  // the work streams are non-blocking: not ordered behind this
+        }
+        if ((rc = part.reserve(sizeof(Box) * (size_t)std::max(nparts, 1))) != ORBGPU_OK)
             return rc;
-        const long long nt = std::max<long long>((std::max<long long>(n, 256 * nb) + RS_TILE - 1) / RS_TILE, 1);
-        if ((rc = tile_sum.reserve(sizeof(unsigned) * (size_t)nt)) != ORBGPU_OK)
+        if ((rc = cexcl.reserve(sizeof(unsigned) * (size_t)(n_sort + 1))) != ORBGPU_OK)
             return rc;
-        if ((rc = flag.reserve(sizeof(unsigned) * (size_t)n)) != ORBGPU_OK)
+        if ((rc = state.reserve(sizeof(CloudState))) != ORBGPU_OK || (rc = ghist.reserve(sizeof(unsigned) * 4 * 256)) != ORBGPU_OK)
             return rc;
-        return state.reserve(sizeof(VoxState));
+        if (!armed) {
+            if ((rc = ctl.reserve(sizeof(LbCtl))) != ORBGPU_OK)
+                return rc;
+            ORBGPU_HIP_TRY(hipMemset(ctl.p, 0, sizeof(LbCtl)));
+            ORBGPU_HIP_TRY(hipMemset(state.p, 0, sizeof(CloudState)));
+            ORBGPU_HIP_TRY(hipDeviceSynchronize());
+            epoch = 0;
+            armed = true;
+        }
+        return ORBGPU_OK;
+    }
+    unsigned next_epoch()
+    {
+        if (++epoch == 0)  // 2^32 launches later: stale words could match again -> start over with clean words
+            (void)hipMemset(status.p, 0, status.bytes), (void)hipDeviceSynchronize(), epoch = 1;
+        return epoch;
     }
     void release()
     {
@@ -554,54 +892,53 @@ struct VoxelWorkspace {
             keys[k].release();
             vals[k].release();
         }
-        hist.release();
-        tile_sum.release();
-        flag.release();
-        state.release();
+        status.release(), part.release(), cexcl.release(), ctl.release(), state.release(), ghist.release();
+        armed = false;
     }
 };
 
-static int device_scan(unsigned *a, long long n, unsigned *tile_sum, hipStream_t st)
-{
-    const int nt = (int)((n + RS_TILE - 1) / RS_TILE);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(nt), dim3(256), 0, st, a, n, tile_sum);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, tile_sum, nt, (unsigned *)nullptr);
-    hipLaunchKernelGGL(k_scan_add, dim3(nt), dim3(256), 0, st, a, n, tile_sum);
-    return ORBGPU_OK;
-}
+static inline int tiles_of(long long n) { return (int)((n + TILE - 1) / TILE); }
 
-// in[0..n) -> out (capacity >= n); the output count lands in ws.state->nout.
-static int voxel_filter_device(VoxelWorkspace &ws, const Point *in, long long n, float leaf, Point *out,
-                               hipStream_t st)
+// the four digit passes over ws.keys/vals[0] (result back in [0]); `grid_tiles` >= tiles of the device-side count
+static void radix_sort_device(VoxelWorkspace &ws, int grid_tiles, hipStream_t st)
 {
-    int rc = ws.reserve(std::max<long long>(n, 1));
-    if (rc != ORBGPU_OK)
-        return rc;
-    VoxState *S = ws.state.as<VoxState>();
-    const float inv = 1.0f / leaf;  // Eigen::Array4f::Ones() / leaf_size_
-    hipLaunchKernelGGL(k_vox_init, dim3(1), dim3(1), 0, st, S);
-    if (n == 0)
-        return ORBGPU_OK;
-    const int nb256 = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(k_vox_minmax, dim3(std::min(nb256, 256)), dim3(256), 0, st, in, n, S);
-    hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(1), 0, st, S, inv);
     uint32_t *k0 = ws.keys[0].as<uint32_t>(), *k1 = ws.keys[1].as<uint32_t>();
     uint32_t *v0 = ws.vals[0].as<uint32_t>(), *v1 = ws.vals[1].as<uint32_t>();
-    hipLaunchKernelGGL(k_vox_keys, dim3(nb256), dim3(256), 0, st, in, n, S, inv, k0, v0);
-    const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
-    unsigned *hist = ws.hist.as<unsigned>();
     for (int pass = 0; pass < 4; pass++) {
-        const int shift = pass * 8;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(256), 0, st, k0, n, shift, nblocks, S, hist);
-        device_scan(hist, 256ll * nblocks, ws.tile_sum.as<unsigned>(), st);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(256), 0, st, k0, v0, n, shift, nblocks, S, hist, k1, v1);
+        hipLaunchKernelGGL(k_sort_pass, dim3(grid_tiles), dim3(256), 0, st, k0, v0, k1, v1, ws.state.as<CloudState>(),
+                           pass * 8, ws.ghist.as<unsigned>() + pass * 256, ws.ctl.as<LbCtl>(),
+                           ws.status.as<unsigned long long>(), ws.next_epoch());
         std::swap(k0, k1);
         std::swap(v0, v1);
     }
-    unsigned *flag = ws.flag.as<unsigned>();
-    hipLaunchKernelGGL(k_vox_heads, dim3(nb256), dim3(256), 0, st, k0, n, S, flag);
-    device_scan(flag, n, ws.tile_sum.as<unsigned>(), st);
-    hipLaunchKernelGGL(k_vox_reduce, dim3(nb256), dim3(256), 0, st, in, k0, v0, n, flag, S, out);
+}
+
+// General path: in[0..n) -> out (capacity >= n): 7 launches.  The output count lands in ws.state->nout, the
+// bounding box of the output in outbox[6].
+static int voxel_filter_device(VoxelWorkspace &ws, const Point *in, long long n, float leaf, Point *out,
+                               unsigned *outbox, hipStream_t st)
+{
+    ORBGPU_REQUIRE(n < (1ll << 30), "too many points for one voxel filter (%lld)", n);
+    const int nb = (int)std::min<long long>(std::max<long long>((n + 255) / 256, 1), 256);
+    int rc = ws.reserve(n, nb);
+    if (rc != ORBGPU_OK)
+        return rc;
+    CloudState *S = ws.state.as<CloudState>();
+    const float inv = 1.0f / leaf;  // Eigen::Array4f::Ones() / leaf_size_
+    if (n == 0) {
+        ORBGPU_HIP_TRY(hipMemsetAsync(S, 0, sizeof(CloudState), st));
+        return ORBGPU_OK;
+    }
+    const int nt = tiles_of(n);
+    hipLaunchKernelGGL(k_vox_minmax, dim3(nb), dim3(256), 0, st, in, (int)n, ws.part.as<Box>(), S, ws.ghist.as<unsigned>(),
+                       outbox);
+    hipLaunchKernelGGL(k_vox_keys, dim3(nt), dim3(256), 0, st, in, &S->n_sort, ws.part.as<Box>(), nb,
+                       (const unsigned *)nullptr, inv, S, ws.keys[0].as<uint32_t>(), ws.vals[0].as<uint32_t>(),
+                       ws.ghist.as<unsigned>());
+    radix_sort_device(ws, nt, st);
+    hipLaunchKernelGGL(k_vox_reduce, dim3(nt), dim3(256), 0, st, in, (int)n, ws.keys[0].as<uint32_t>(),
+                       ws.vals[0].as<uint32_t>(), S, out, ws.ctl.as<LbCtl>(), ws.status.as<unsigned long long>(),
+                       ws.next_epoch(), outbox);
     ORBGPU_HIP_TRY(hipGetLastError());
     return ORBGPU_OK;
 }
@@ -669,32 +1006,74 @@ static void pose_inverse(const float *Tcw, Pose &P)
 }
 
 struct FrameStage {
-    DevBuf depth, rgb, row_cnt, total;
+    DevBuf depth, rgb, status, part, ctl;
+    unsigned epoch = 0;
+    bool armed = false;
+    int reserve_lb(int ntiles)
+    {
+        int rc;
+        const size_t sb = sizeof(unsigned long long) * (size_t)ntiles;
+        if (sb > status.bytes) {
+            if ((rc = status.reserve(sb)) != ORBGPU_OK)
+                return rc;
+            ORBGPU_HIP_TRY(hipMemset(status.p, 0, status.bytes));
+            ORBGPU_HIP_TRY(hipDeviceSynchronize());
+        }
+        if ((rc = part.reserve(sizeof(Box) * (size_t)ntiles)) != ORBGPU_OK)
+            return rc;
+        if (!armed) {
+            if ((rc = ctl.reserve(sizeof(LbCtl))) != ORBGPU_OK)
+                return rc;
+            ORBGPU_HIP_TRY(hipMemset(ctl.p, 0, sizeof(LbCtl)));
+            ORBGPU_HIP_TRY(hipDeviceSynchronize());
+            armed = true;
+        }
+        return ORBGPU_OK;
+    }
+    void release()
+    {
+        depth.release(), rgb.release(), status.release(), part.release(), ctl.release();
+        armed = false;
+    }
 };
 
-// depth/rgb host -> device, back-project (+ transform) appending to out[base..]; *d_total = base + count
-static int backproject_device(FrameStage &fs, const float *depth, size_t dstride, const uint8_t *rgb, size_t cstride,
-                              int w, int h, float fx, float fy, float cx, float cy, const float *Tcw, Point *out,
-                              long long base, hipStream_t st)
+static inline int bp_tiles(int w, int h) { return tiles_of((long long)((w + 2) / 3) * ((h + 2) / 3)); }
+
+// back-project device images (+ transform) into out[0..count); *d_count = count.  One launch.
+static int backproject_launch(FrameStage &fs, const float *d_depth, size_t dstride, const uint8_t *d_rgb,
+                              size_t cstride, int w, int h, float fx, float fy, float cx, float cy, const float *Tcw,
+                              Point *out, int *d_count, unsigned *ghist, unsigned *outbox, hipStream_t st)
 {
-    int rc;
-    const int gh = (h + 2) / 3;
-    if ((rc = fs.depth.reserve(sizeof(float) * (size_t)w * h)) != ORBGPU_OK ||
-        (rc = fs.rgb.reserve((size_t)w * 3 * h)) != ORBGPU_OK || (rc = fs.row_cnt.reserve(sizeof(int) * gh)) != ORBGPU_OK ||
-        (rc = fs.total.reserve(sizeof(long long))) != ORBGPU_OK)
+    const int nt = bp_tiles(w, h);
+    int rc = fs.reserve_lb(nt);
+    if (rc != ORBGPU_OK)
         return rc;
-    ORBGPU_HIP_TRY(hipMemcpy2DAsync(fs.depth.p, sizeof(float) * w, depth, sizeof(float) * dstride, sizeof(float) * w, h,
-                                    hipMemcpyHostToDevice, st));
-    ORBGPU_HIP_TRY(hipMemcpy2DAsync(fs.rgb.p, (size_t)w * 3, rgb, cstride, (size_t)w * 3, h, hipMemcpyHostToDevice, st));
     Pose P;
     P.apply = 0;
     if (Tcw)
         pose_inverse(Tcw, P);
-    hipLaunchKernelGGL(k_bp_count, dim3(gh), dim3(256), 0, st, fs.depth.as<float>(), (size_t)w, w, h, fs.row_cnt.as<int>());
-    hipLaunchKernelGGL(k_bp_scan, dim3(1), dim3(256), 0, st, fs.row_cnt.as<int>(), gh, fs.total.as<long long>(), base);
-    hipLaunchKernelGGL(k_bp_write, dim3(gh), dim3(256), 0, st, fs.depth.as<float>(), (size_t)w, fs.rgb.as<uint8_t>(),
-                       (size_t)w * 3, w, h, fx, fy, cx, cy, P, fs.row_cnt.as<int>(), out + base);
+    if (++fs.epoch == 0) {
+        ORBGPU_HIP_TRY(hipMemsetAsync(fs.status.p, 0, fs.status.bytes, st));
+        fs.epoch = 1;
+    }
+    hipLaunchKernelGGL(k_bp, dim3(nt), dim3(256), 0, st, d_depth, dstride, d_rgb, cstride, w, h, fx, fy, cx, cy, P, out,
+                       fs.ctl.as<LbCtl>(), fs.status.as<unsigned long long>(), fs.epoch, fs.part.as<Box>(), d_count,
+                       ghist, outbox);
     ORBGPU_HIP_TRY(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+// host images -> staging buffers of the frame stage
+static int upload_frame(FrameStage &fs, const float *depth, size_t dstride, const uint8_t *rgb, size_t cstride, int w,
+                        int h, hipStream_t st)
+{
+    int rc;
+    if ((rc = fs.depth.reserve(sizeof(float) * (size_t)w * h)) != ORBGPU_OK ||
+        (rc = fs.rgb.reserve((size_t)w * 3 * h)) != ORBGPU_OK)
+        return rc;
+    ORBGPU_HIP_TRY(hipMemcpy2DAsync(fs.depth.p, sizeof(float) * w, depth, sizeof(float) * dstride, sizeof(float) * w, h,
+                                    hipMemcpyHostToDevice, st));
+    ORBGPU_HIP_TRY(hipMemcpy2DAsync(fs.rgb.p, (size_t)w * 3, rgb, cstride, (size_t)w * 3, h, hipMemcpyHostToDevice, st));
     return ORBGPU_OK;
 }
 
@@ -706,9 +1085,12 @@ struct orbgpu_cloud {
     int device_id = 0;
     float leaf = 0.01f;
     DevBuf map[2];        // ping-pong: map[cur] holds the global map
+    DevBuf box;           // 2 x 6 words: bounding box of map[0] / map[1] (order-preserving float encodings)
     int cur = 0;
     long long size = 0;   // points in the global map
     int last_overflow = 0;
+    bool sorted_map = false;  // map[cur] came out of a voxel filter (sorted, one point per voxel): fast path allowed
+    int last_path = 0;    // 1 = merge (fast) path, 2 = general path, 3 = merge attempted, redone by the general path
     VoxelWorkspace ws;
     FrameStage fs;
     hipStream_t stream = nullptr;
@@ -741,22 +1123,92 @@ static int cloud_grow(orbgpu_cloud *c, int which, long long need_points, long lo
     return ORBGPU_OK;
 }
 
-// filter map[cur][0..k) into map[cur^1], swap, read the new size
+static int read_state(orbgpu_cloud *c, CloudState &hs)
+{
+    ORBGPU_HIP_TRY(hipMemcpyAsync(&hs, c->ws.state.p, sizeof(CloudState), hipMemcpyDeviceToHost, c->stream));
+    ORBGPU_HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORBGPU_OK;
+}
+
+// general path: filter map[cur][0..k) into map[cur^1], swap, read the new size
 static int cloud_filter(orbgpu_cloud *c, long long k)
 {
     int rc = cloud_grow(c, c->cur ^ 1, std::max<long long>(k, 1), 0);
     if (rc != ORBGPU_OK)
         return rc;
-    rc = voxel_filter_device(c->ws, c->map[c->cur].as<Point>(), k, c->leaf, c->map[c->cur ^ 1].as<Point>(), c->stream);
+    rc = voxel_filter_device(c->ws, c->map[c->cur].as<Point>(), k, c->leaf, c->map[c->cur ^ 1].as<Point>(),
+                             c->box.as<unsigned>() + 6 * (c->cur ^ 1), c->stream);
     if (rc != ORBGPU_OK)
         return rc;
-    VoxState hs;
-    ORBGPU_HIP_TRY(hipMemcpyAsync(&hs, c->ws.state.p, sizeof(VoxState), hipMemcpyDeviceToHost, c->stream));
-    ORBGPU_HIP_TRY(hipStreamSynchronize(c->stream));
+    CloudState hs;
+    if ((rc = read_state(c, hs)) != ORBGPU_OK)
+        return rc;
     c->cur ^= 1;
     c->size = hs.nout;
     c->last_overflow = hs.overflow;
+    c->sorted_map = !hs.overflow;
     return ORBGPU_OK;
+}
+
+// One key frame (PointCloudMap.cc:204-262): new points appended behind the resident map, then the voxel filter
+// over map + new.  Merge path (8 launches, the resident map is read and written once): back-projection, keys of
+// the new points, four digit passes, new-side merge, resident-side merge.  It assumes what a filtered map
+// guarantees -- sorted, one point per voxel -- and checks it; overflow / unsorted maps take the general path.
+static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dstride, const uint8_t *d_rgb,
+                               size_t cstride, int w, int h, float fx, float fy, float cx, float cy, const float *Tcw)
+{
+    int rc;
+    const long long K = c->size;
+    const long long maxnew = (long long)((h + 2) / 3) * ((w + 2) / 3);
+    ORBGPU_REQUIRE(K + maxnew < (1ll << 30), "dense map too large (%lld points)", K + maxnew);
+    if ((rc = cloud_grow(c, c->cur, K + maxnew, K)) != ORBGPU_OK || (rc = cloud_grow(c, c->cur ^ 1, K + maxnew, 0)) != ORBGPU_OK)
+        return rc;
+    if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK)
+        return rc;
+    if ((rc = c->box.reserve(sizeof(unsigned) * 12)) != ORBGPU_OK)
+        return rc;
+    VoxelWorkspace &ws = c->ws;
+    CloudState *S = ws.state.as<CloudState>();
+    Point *old = c->map[c->cur].as<Point>(), *newp = old + K, *out = c->map[c->cur ^ 1].as<Point>();
+    unsigned *box_in = c->box.as<unsigned>() + 6 * c->cur, *box_out = c->box.as<unsigned>() + 6 * (c->cur ^ 1);
+    const float inv = 1.0f / c->leaf;
+    const bool merge = K == 0 || c->sorted_map;
+    // globalMap += transform(convertToPointCloud(kf), Twc)   (:204-249)
+    if ((rc = backproject_launch(c->fs, d_depth, dstride, d_rgb, cstride, w, h, fx, fy, cx, cy, Tcw, newp, &S->n_sort,
+                                 ws.ghist.as<unsigned>(), box_out, c->stream)) != ORBGPU_OK)
+        return rc;
+    CloudState hs;
+    if (merge) {
+        const int ntn = tiles_of(maxnew);
+        hipLaunchKernelGGL(k_vox_keys, dim3(ntn), dim3(256), 0, c->stream, newp, &S->n_sort, c->fs.part.as<Box>(),
+                           bp_tiles(w, h), K > 0 ? box_in : (const unsigned *)nullptr, inv, S, ws.keys[0].as<uint32_t>(),
+                           ws.vals[0].as<uint32_t>(), ws.ghist.as<unsigned>());
+        radix_sort_device(ws, ntn, c->stream);
+        hipLaunchKernelGGL(k_merge_new, dim3(ntn), dim3(256), 0, c->stream, old, (int)K, newp, ws.keys[0].as<uint32_t>(),
+                           ws.vals[0].as<uint32_t>(), inv, S, ws.cexcl.as<unsigned>(), out, ws.ctl.as<LbCtl>(),
+                           ws.status.as<unsigned long long>(), ws.next_epoch(), box_out);
+        if (K > 0)
+            hipLaunchKernelGGL(k_merge_old, dim3(tiles_of(K)), dim3(256), 0, c->stream, old, (int)K,
+                               ws.keys[0].as<uint32_t>(), ws.cexcl.as<unsigned>(), inv, S, out, box_out);
+        ORBGPU_HIP_TRY(hipGetLastError());
+        if ((rc = read_state(c, hs)) != ORBGPU_OK)
+            return rc;
+        if (!hs.overflow && !hs.unsorted) {
+            c->cur ^= 1;
+            c->size = hs.nout;
+            c->last_overflow = 0;
+            c->sorted_map = true;
+            c->last_path = 1;
+            return ORBGPU_OK;
+        }
+        c->last_path = 3;
+    } else {
+        if ((rc = read_state(c, hs)) != ORBGPU_OK)
+            return rc;
+        c->last_path = 2;
+    }
+    // voxel.setInputCloud(globalMap); voxel.filter(tmp); swap   (:259-262), general path
+    return cloud_filter(c, K + hs.n_sort);
 }
 
 } // namespace orbgpu
@@ -795,21 +1247,20 @@ int orbgpu_cloud_destroy(orbgpu_cloud *c)
     (void)hipDeviceSynchronize();
     c->map[0].release();
     c->map[1].release();
+    c->box.release();
     c->ws.release();
-    c->fs.depth.release();
-    c->fs.rgb.release();
-    c->fs.row_cnt.release();
-    c->fs.total.release();
+    c->fs.release();
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
     return ORBGPU_OK;
 }
 
-static int check_frame_args(const float *depth, size_t dstride, const uint8_t *rgb, size_t cstride, int w, int h)
+static int check_frame_args(const void *depth, size_t dstride, const void *rgb, size_t cstride, int w, int h)
 {
     ORBGPU_REQUIRE(depth && rgb, "null image");
     ORBGPU_REQUIRE(w > 0 && h > 0 && dstride >= (size_t)w && cstride >= (size_t)w * 3, "bad image size / strides");
+    ORBGPU_REQUIRE((long long)w * h < (1ll << 30), "image too large");
     return ORBGPU_OK;
 }
 
@@ -822,18 +1273,23 @@ int orbgpu_cloud_insert(orbgpu_cloud *c, const float *depth, size_t dstride, con
         return rc;
     if ((rc = select_device(c->device_id)) != ORBGPU_OK)
         return rc;
-    const long long maxnew = (long long)((h + 2) / 3) * ((w + 2) / 3);
-    if ((rc = cloud_grow(c, c->cur, c->size + maxnew, c->size)) != ORBGPU_OK)
+    if ((rc = upload_frame(c->fs, depth, dstride, rgb, cstride, w, h, c->stream)) != ORBGPU_OK)
         return rc;
-    // globalMap += transform(convertToPointCloud(kf), Twc)   (:204-249)
-    if ((rc = backproject_device(c->fs, depth, dstride, rgb, cstride, w, h, fx, fy, cx, cy, Tcw,
-                                 c->map[c->cur].as<Point>(), c->size, c->stream)) != ORBGPU_OK)
+    return cloud_insert_device(c, c->fs.depth.as<float>(), (size_t)w, c->fs.rgb.as<uint8_t>(), (size_t)w * 3, w, h, fx, fy,
+                               cx, cy, Tcw);
+}
+
+int orbgpu_cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dstride, const uint8_t *d_rgb,
+                               size_t cstride, int32_t w, int32_t h, float fx, float fy, float cx, float cy,
+                               const float *Tcw)
+{
+    ORBGPU_REQUIRE(c && Tcw, "null argument");
+    int rc = check_frame_args(d_depth, dstride, d_rgb, cstride, w, h);
+    if (rc != ORBGPU_OK)
         return rc;
-    long long total = 0;
-    ORBGPU_HIP_TRY(hipMemcpyAsync(&total, c->fs.total.p, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-    ORBGPU_HIP_TRY(hipStreamSynchronize(c->stream));
-    // voxel.setInputCloud(globalMap); voxel.filter(tmp); swap   (:259-262)
-    return cloud_filter(c, total);
+    if ((rc = select_device(c->device_id)) != ORBGPU_OK)
+        return rc;
+    return cloud_insert_device(c, d_depth, dstride, d_rgb, cstride, w, h, fx, fy, cx, cy, Tcw);
 }
 
 int orbgpu_cloud_rebuild(orbgpu_cloud *c, int32_t n, const float *const *depth, size_t dstride,
@@ -845,22 +1301,34 @@ int orbgpu_cloud_rebuild(orbgpu_cloud *c, int32_t n, const float *const *depth, 
     if (rc != ORBGPU_OK)
         return rc;
     c->size = 0;  // globalMap.reset(new PointCloud)  (:225)
+    c->sorted_map = false;
     if (n == 0)
         return ORBGPU_OK;
+    ORBGPU_REQUIRE(w > 0 && h > 0, "bad image size");
     const long long maxnew = (long long)((h + 2) / 3) * ((w + 2) / 3);
+    ORBGPU_REQUIRE(maxnew * n < (1ll << 30), "too many points for one rebuild");
     if ((rc = cloud_grow(c, c->cur, maxnew * n, 0)) != ORBGPU_OK)
         return rc;
+    if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK || (rc = c->box.reserve(sizeof(unsigned) * 12)) != ORBGPU_OK)
+        return rc;
+    CloudState *S = c->ws.state.as<CloudState>();
     long long total = 0;
     for (int k = 0; k < n; k++) {
         ORBGPU_REQUIRE(Tcw[k], "null pose");
         if ((rc = check_frame_args(depth[k], dstride, rgb[k], cstride, w, h)) != ORBGPU_OK)
             return rc;
-        if ((rc = backproject_device(c->fs, depth[k], dstride, rgb[k], cstride, w, h, fx, fy, cx, cy, Tcw[k],
-                                     c->map[c->cur].as<Point>(), total, c->stream)) != ORBGPU_OK)
+        if ((rc = upload_frame(c->fs, depth[k], dstride, rgb[k], cstride, w, h, c->stream)) != ORBGPU_OK)
             return rc;
-        ORBGPU_HIP_TRY(hipMemcpyAsync(&total, c->fs.total.p, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-        ORBGPU_HIP_TRY(hipStreamSynchronize(c->stream));
+        if ((rc = backproject_launch(c->fs, c->fs.depth.as<float>(), (size_t)w, c->fs.rgb.as<uint8_t>(), (size_t)w * 3, w,
+                                     h, fx, fy, cx, cy, Tcw[k], c->map[c->cur].as<Point>() + total, &S->n_sort, nullptr,
+                                     nullptr, c->stream)) != ORBGPU_OK)
+            return rc;
+        CloudState hs;
+        if ((rc = read_state(c, hs)) != ORBGPU_OK)
+            return rc;
+        total += hs.n_sort;
     }
+    c->last_path = 2;
     return cloud_filter(c, total);
 }
 
@@ -894,6 +1362,13 @@ int orbgpu_cloud_last_overflow(orbgpu_cloud *c, int32_t *overflow)
     return ORBGPU_OK;
 }
 
+int orbgpu_cloud_last_path(orbgpu_cloud *c, int32_t *path)
+{
+    ORBGPU_REQUIRE(c && path, "null argument");
+    *path = c->last_path;
+    return ORBGPU_OK;
+}
+
 int orbgpu_backproject(const float *depth, size_t dstride, const uint8_t *rgb, size_t cstride, int32_t w, int32_t h,
                        float fx, float fy, float cx, float cy, const float *Tcw, orbgpu_point_xyzrgba *out, int64_t cap,
                        int64_t *n, int32_t device_id)
@@ -910,25 +1385,25 @@ int orbgpu_backproject(const float *depth, size_t dstride, const uint8_t *rgb, s
     if ((rc = select_device(device_id)) != ORBGPU_OK)
         return rc;
     FrameStage fs;
-    DevBuf dout;
+    DevBuf dout, dcount;
     auto cleanup = [&]() {
-        fs.depth.release();
-        fs.rgb.release();
-        fs.row_cnt.release();
-        fs.total.release();
+        fs.release();
         dout.release();
+        dcount.release();
     };
-    if ((rc = dout.reserve(sizeof(Point) * (size_t)maxnew)) != ORBGPU_OK) {
+    if ((rc = dout.reserve(sizeof(Point) * (size_t)maxnew)) != ORBGPU_OK || (rc = dcount.reserve(sizeof(int))) != ORBGPU_OK ||
+        (rc = upload_frame(fs, depth, dstride, rgb, cstride, w, h, nullptr)) != ORBGPU_OK) {
         cleanup();
         return rc;
     }
-    rc = backproject_device(fs, depth, dstride, rgb, cstride, w, h, fx, fy, cx, cy, Tcw, dout.as<Point>(), 0, nullptr);
-    long long total = 0;
+    rc = backproject_launch(fs, fs.depth.as<float>(), (size_t)w, fs.rgb.as<uint8_t>(), (size_t)w * 3, w, h, fx, fy, cx, cy,
+                            Tcw, dout.as<Point>(), dcount.as<int>(), nullptr, nullptr, nullptr);
+    int total = 0;
     hipError_t e = hipSuccess;
     if (rc == ORBGPU_OK) {
         e = hipDeviceSynchronize();
         if (e == hipSuccess)
-            e = hipMemcpy(&total, fs.total.p, sizeof(long long), hipMemcpyDeviceToHost);
+            e = hipMemcpy(&total, dcount.p, sizeof(int), hipMemcpyDeviceToHost);
         if (e == hipSuccess && total > 0)
             e = hipMemcpy(out, dout.p, sizeof(Point) * (size_t)total, hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
@@ -944,7 +1419,7 @@ int orbgpu_backproject(const float *depth, size_t dstride, const uint8_t *rgb, s
 int orbgpu_voxel_filter(const orbgpu_point_xyzrgba *in, int64_t n, double resolution, orbgpu_point_xyzrgba *out,
                         int64_t cap, int64_t *n_out, int32_t *overflow, int32_t device_id)
 {
-    ORBGPU_REQUIRE(n >= 0 && n < (1ll << 31) && (n == 0 || in) && out && n_out, "bad arguments");
+    ORBGPU_REQUIRE(n >= 0 && n < (1ll << 30) && (n == 0 || in) && out && n_out, "bad arguments");
     ORBGPU_REQUIRE(resolution > 0, "resolution must be positive");
     ORBGPU_REQUIRE(cap >= n, "cap must be >= n (the overflow path returns the input)");
     int rc = select_device(device_id);
@@ -956,24 +1431,26 @@ int orbgpu_voxel_filter(const orbgpu_point_xyzrgba *in, int64_t n, double resolu
     if (n == 0)
         return ORBGPU_OK;
     VoxelWorkspace ws;
-    DevBuf din, dout;
+    DevBuf din, dout, dbox;
     auto cleanup = [&]() {
         ws.release();
         din.release();
         dout.release();
+        dbox.release();
     };
-    if ((rc = din.reserve(sizeof(Point) * (size_t)n)) != ORBGPU_OK || (rc = dout.reserve(sizeof(Point) * (size_t)n)) != ORBGPU_OK) {
+    if ((rc = din.reserve(sizeof(Point) * (size_t)n)) != ORBGPU_OK || (rc = dout.reserve(sizeof(Point) * (size_t)n)) != ORBGPU_OK ||
+        (rc = dbox.reserve(sizeof(unsigned) * 6)) != ORBGPU_OK) {
         cleanup();
         return rc;
     }
     hipError_t e = hipMemcpy(din.p, in, sizeof(Point) * (size_t)n, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = voxel_filter_device(ws, din.as<Point>(), n, (float)resolution, dout.as<Point>(), nullptr);
+        rc = voxel_filter_device(ws, din.as<Point>(), n, (float)resolution, dout.as<Point>(), dbox.as<unsigned>(), nullptr);
         if (rc == ORBGPU_OK) {
-            VoxState hs;
+            CloudState hs;
             e = hipDeviceSynchronize();
             if (e == hipSuccess)
-                e = hipMemcpy(&hs, ws.state.p, sizeof(VoxState), hipMemcpyDeviceToHost);
+                e = hipMemcpy(&hs, ws.state.p, sizeof(CloudState), hipMemcpyDeviceToHost);
             if (e == hipSuccess && hs.nout > 0)
                 e = hipMemcpy(out, dout.p, sizeof(Point) * (size_t)hs.nout, hipMemcpyDeviceToHost);
             if (e == hipSuccess) {

@@ -107,7 +107,8 @@ ABI_SYMBOLS = [
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
     "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
-    "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_rebuild",
+    "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_insert_device",
+    "orbgpu_cloud_last_path", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
     "orbgpu_voxel_filter",
 ]
@@ -171,6 +172,8 @@ def lib():
         "orbgpu_cloud_create": [C.c_double, i32, vp],
         "orbgpu_cloud_destroy": [vp],
         "orbgpu_cloud_insert": [vp, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
+        "orbgpu_cloud_insert_device": [vp, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
+        "orbgpu_cloud_last_path": [vp, vp],
         "orbgpu_cloud_rebuild": [vp, i32, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
         "orbgpu_cloud_size": [vp, vp],
         "orbgpu_cloud_download": [vp, vp, C.c_int64, vp],
@@ -578,6 +581,17 @@ class PointCloudMapping:
         h, w = depth.shape
         check(self.L.orbgpu_cloud_insert(self.h, _p(depth), depth.strides[0] // 4, _p(rgb), rgb.strides[0], w, h, fx, fy,
                                          cx, cy, _p(T)))
+
+    def insertKeyFrameDevice(self, d_depth, depth_stride, d_rgb, rgb_stride, w, h, fx, fy, cx, cy, Tcw):
+        """Device-resident key frame (pointers into HBM, strides in floats / bytes)."""
+        T = np.ascontiguousarray(Tcw, np.float32)
+        check(self.L.orbgpu_cloud_insert_device(self.h, d_depth, depth_stride, d_rgb, rgb_stride, w, h, fx, fy, cx, cy,
+                                                _p(T)))
+
+    def last_path(self):
+        v = C.c_int32()
+        check(self.L.orbgpu_cloud_last_path(self.h, C.byref(v)))
+        return v.value
 
     def rebuild(self, depths, rgbs, fx, fy, cx, cy, Tcws):
         depths = [np.ascontiguousarray(d, np.float32) for d in depths]

@@ -168,3 +168,127 @@ def test_voxel_filter_properties_at_full_size(gpu):
     idx = ijk[:, 0] + ijk[:, 1] * dx + ijk[:, 2] * dx * dy
     assert np.all(np.diff(idx) > 0), "outputs must lie in distinct voxels in ascending index order"
     assert div[0] <= dx and div[1] <= dy
+
+
+def _oracle_step(oracle, omap, depth, rgb, camv, T, leaf):
+    R, t = oracle.pose_inverse(T)
+    new = oracle.transform_points(oracle.backproject(depth, rgb, *camv), R, t)
+    return oracle.voxel_filter(np.concatenate([omap, new]), leaf)
+
+
+@pytest.mark.parametrize("leaf", [0.01, 0.04])
+def test_cloud_merge_path_sequence(gpu, oracle, stream640, leaf):
+    """Eight key frames with a moving camera: from the second on the resident map is merged with the sorted new
+    points (path 1) instead of re-sorted; every intermediate map must equal PCL's filter over (map ++ new)."""
+    camv = cam(stream640)
+    cloud = gpu.PointCloudMapping(leaf)
+    omap = np.zeros(0, oracle.POINT_DTYPE)
+    for i in range(8):
+        _, rgb, depth = stream640.frame(9 * i)
+        if i == 3:
+            depth = depth.copy()
+            depth[60, 90] = np.nan  # a non-finite new point: dropped by the filter, never part of the map
+        T = scenario.rigid(0.006 * i, -0.009 * i, 0.003 * i, (0.06 * i, 0.01 * i, -0.02 * i))
+        cloud.insertKeyFrame(depth, rgb, *camv, T)
+        omap, ov = _oracle_step(oracle, omap, depth, rgb, camv, T, leaf)
+        assert not ov and cloud.last_path() == 1, "key frame %d took path %d" % (i, cloud.last_path())
+        assert cloud.size() == len(omap)
+        got = cloud.download()
+        assert_points_close(got, omap, "key frame %d leaf %g" % (i, leaf))
+        assert got.tobytes() == omap.tobytes()
+    cloud.close()
+
+
+def test_cloud_same_view_twice_merges_into_existing_voxels(gpu, oracle, stream640):
+    """The same key frame inserted twice: every new point falls into an occupied voxel (no new voxels, map size
+    unchanged), then a third insert from elsewhere opens new ones before / between / after the resident ones."""
+    camv = cam(stream640)
+    _, rgb, depth = stream640.frame(3)
+    T = scenario.rigid()
+    cloud = gpu.PointCloudMapping(0.02)
+    omap = np.zeros(0, oracle.POINT_DTYPE)
+    sizes = []
+    for Tk in (T, T, scenario.rigid(0.3, -0.2, 0.1, (-0.8, 0.4, 0.6))):
+        cloud.insertKeyFrame(depth, rgb, *camv, Tk)
+        omap, _ = _oracle_step(oracle, omap, depth, rgb, camv, Tk, 0.02)
+        assert cloud.last_path() == 1
+        assert cloud.download().tobytes() == omap.tobytes()
+        sizes.append(cloud.size())
+    assert sizes[0] == sizes[1] < sizes[2]
+    cloud.close()
+
+
+def test_cloud_overflow_then_recovery(gpu, oracle, stream640):
+    """A key frame far away makes dx*dy*dz overflow int32: PCL returns map ++ new unfiltered (path 3: the merge
+    notices and the general path redoes it).  The map is then unsorted, so the next key frame goes through the
+    general path (2); once filtered again the merge path (1) resumes."""
+    camv = cam(stream640)
+    leaf = 0.01
+    cloud = gpu.PointCloudMapping(leaf)
+    omap = np.zeros(0, oracle.POINT_DTYPE)
+    far = scenario.rigid(0.0, 0.0, 0.0, (400.0, -300.0, 250.0))
+    poses = [scenario.rigid(), far, scenario.rigid(0.02, 0.01, 0.0, (0.1, 0.0, 0.0))]
+    paths = []
+    for i, T in enumerate(poses):
+        _, rgb, depth = stream640.frame(5 * i)
+        cloud.insertKeyFrame(depth, rgb, *camv, T)
+        omap, ov = _oracle_step(oracle, omap, depth, rgb, camv, T, leaf)
+        paths.append((cloud.last_path(), bool(cloud.last_overflow()), bool(ov)))
+        assert cloud.size() == len(omap)
+        assert cloud.download().tobytes() == omap.tobytes(), "key frame %d" % i
+    assert paths[0] == (1, False, False) and paths[1] == (3, True, True) and paths[2][0] == 2
+    # a coarser grid does not overflow: shrink the problem by rebuilding near the origin, then merge again
+    cloud.rebuild([stream640.frame(0)[2]], [stream640.frame(0)[1]], *camv, [poses[0]])
+    _, rgb, depth = stream640.frame(20)
+    cloud.insertKeyFrame(depth, rgb, *camv, poses[2])
+    assert cloud.last_path() == 1
+    R, t = oracle.pose_inverse(poses[0])
+    base, _ = oracle.voxel_filter(oracle.transform_points(oracle.backproject(stream640.frame(0)[2], stream640.frame(0)[1], *camv), R, t), leaf)
+    want, _ = _oracle_step(oracle, base, depth, rgb, camv, poses[2], leaf)
+    assert cloud.download().tobytes() == want.tobytes()
+    cloud.close()
+
+
+def test_cloud_insert_device_resident(gpu, oracle, stream640):
+    """orbgpu_cloud_insert_device: depth / rgb already in HBM (strided views of larger device buffers)."""
+    import torch
+    camv = cam(stream640)
+    cloud = gpu.PointCloudMapping(0.01)
+    omap = np.zeros(0, oracle.POINT_DTYPE)
+    for i in range(3):
+        _, rgb, depth = stream640.frame(4 * i)
+        T = scenario.rigid(0.004 * i, 0.002 * i, 0.0, (0.05 * i, 0.0, 0.01 * i))
+        h, w = depth.shape
+        dd = torch.zeros((h, w + 16), dtype=torch.float32, device="cuda")
+        dr = torch.zeros((h, (w + 5) * 3), dtype=torch.uint8, device="cuda")
+        dd[:, :w] = torch.from_numpy(depth).cuda()
+        dr[:, :w * 3] = torch.from_numpy(rgb.reshape(h, w * 3)).cuda()
+        torch.cuda.synchronize()
+        cloud.insertKeyFrameDevice(dd.data_ptr(), w + 16, dr.data_ptr(), (w + 5) * 3, w, h, *camv, T)
+        omap, _ = _oracle_step(oracle, omap, depth, rgb, camv, T, 0.01)
+        assert cloud.download().tobytes() == omap.tobytes()
+    cloud.close()
+
+
+def test_cloud_large_frame_and_tiny_frame(gpu, oracle, stream1280):
+    """1280x960 key frames (136 k new points, 134 sort tiles) and a 7x5 image (one partial tile)."""
+    camv = cam(stream1280)
+    cloud = gpu.PointCloudMapping(0.02)
+    omap = np.zeros(0, oracle.POINT_DTYPE)
+    for i in range(2):
+        _, rgb, depth = stream1280.frame(6 * i)
+        T = scenario.rigid(0.01 * i, 0.0, 0.0, (0.1 * i, 0.0, 0.0))
+        cloud.insertKeyFrame(depth, rgb, *camv, T)
+        omap, _ = _oracle_step(oracle, omap, depth, rgb, camv, T, 0.02)
+        assert cloud.last_path() == 1 and cloud.download().tobytes() == omap.tobytes()
+    cloud.close()
+    rng = np.random.default_rng(3)
+    depth = (1.0 + rng.random((5, 7))).astype(np.float32)
+    rgb = rng.integers(0, 255, (5, 7, 3), dtype=np.uint8)
+    cloud = gpu.PointCloudMapping(0.01)
+    T = scenario.rigid()
+    cloud.insertKeyFrame(depth, rgb, 5.0, 5.0, 3.0, 2.0, T)
+    cloud.insertKeyFrame(np.zeros_like(depth), rgb, 5.0, 5.0, 3.0, 2.0, T)  # no valid depth: map unchanged
+    want, _ = _oracle_step(oracle, np.zeros(0, oracle.POINT_DTYPE), depth, rgb, (5.0, 5.0, 3.0, 2.0), T, 0.01)
+    assert cloud.last_path() == 1 and cloud.download().tobytes() == want.tobytes()
+    cloud.close()
