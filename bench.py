@@ -63,19 +63,64 @@ STAGE_KERNELS = {"pyramid": ["k_border0"] + ["k_resize_fast"] * 7, "fast_score":
                  "blur": ["k_blur"], "describe": ["k_describe"]}
 
 
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")  # newest first
+
+
 def pmc_traffic(stage, frames_per_launch):
-    """HBM bytes per launch of `stage` from the committed PMC pass (profiles/r01_pmc_traffic.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 FETCH correction). None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        k = json.load(open(path))["kernels"]
-        return float(sum(k[name]["hbm_bytes_per_frame"] for name in STAGE_KERNELS[stage])) * frames_per_launch
-    except Exception:
-        return None
+    """(HBM bytes per launch of `stage`, source) from the newest committed PMC pass under profiles/ (separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this script, gfx950 x2 FETCH correction). (None, None) if absent."""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            j = json.load(open(path))
+            k = j["kernels"]
+            per_frame = float(sum(k[kn]["hbm_bytes_per_frame"] for kn in STAGE_KERNELS[stage]))
+            return per_frame * frames_per_launch, "profiles/%s (%s)" % (name, j.get("how", "separate --pmc passes"))
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(frames, seconds_budget=18.0):
-    """Oracle (kind 'port'): extract + BF match of consecutive frames, single thread."""
+def _cpu_worker(libpath, frames, seconds_budget, want_stages):
+    """extract + BF match vs the previous frame over `frames` (cyclically) until the budget is spent.
+    ctypes releases the GIL inside the C oracle, so N of these run on N cores from N threads."""
+    import ctypes as C
+    from oracle import oracle_py as O
+    e = O.Extractor(1000, libpath=libpath)
+    L = O.lib(libpath)
+    t_match = 0.0
+    n = 0
+    prev = None
+    t0 = time.perf_counter()
+    while True:
+        img = frames[n % len(frames)]
+        k, d = e.extract(img)
+        if prev is not None:
+            pk, pd = prev
+            out = np.zeros(max(1, len(d)), np.int32)
+            tm = time.perf_counter()
+            L.ora_match_bf(pd.ctypes.data_as(C.c_void_p), np.ascontiguousarray(pk["angle"]).ctypes.data_as(C.c_void_p),
+                           None, len(pd), d.ctypes.data_as(C.c_void_p),
+                           np.ascontiguousarray(k["angle"]).ctypes.data_as(C.c_void_p), len(d), 50, 0.7, 1,
+                           out.ctypes.data_as(C.c_void_p))
+            t_match += time.perf_counter() - tm
+        prev = (k, d)
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    stages = None
+    if want_stages:
+        stages = {k: v / n * 1e3 for k, v in e.stage_seconds().items()}
+        stages["match_bf"] = t_match / max(n - 1, 1) * 1e3
+    return n, dt, stages
+
+
+def cpu_baseline(frames, seconds_budget=9.0):
+    """Oracle (kind 'port'): extract + BF match of consecutive frames.  `value` = one core (the reference runs
+    Tracking on one thread, Examples/RGB-D/rgbd_tum.cc:77-119); `all_cores` = the same loop frame-parallel on the
+    threads this process may use (capped at the GPU box's per-GPU CPU share, 16)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_py as O
     libpath = None
     try:  # -march=native build on THIS host's CPU; falls back to the portable build
@@ -84,29 +129,25 @@ def cpu_baseline(frames, seconds_budget=18.0):
         libpath = tmp
     except Exception:
         O.build()
-    e = O.Extractor(1000, libpath=libpath)
-    L = O.lib(libpath)
+    n1, dt1, stages = _cpu_worker(libpath, frames, seconds_budget, True)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nthreads = max(1, min(avail, 16))
     t0 = time.perf_counter()
-    n = 0
-    prev = None
-    import ctypes as C
-    for img in frames:
-        k, d = e.extract(img)
-        if prev is not None:
-            pk, pd = prev
-            out = np.zeros(max(1, len(d)), np.int32)
-            L.ora_match_bf(pd.ctypes.data_as(C.c_void_p), np.ascontiguousarray(pk["angle"]).ctypes.data_as(C.c_void_p),
-                           None, len(pd), d.ctypes.data_as(C.c_void_p),
-                           np.ascontiguousarray(k["angle"]).ctypes.data_as(C.c_void_p), len(d), 50, 0.7, 1,
-                           out.ctypes.data_as(C.c_void_p))
-        prev = (k, d)
-        n += 1
-        if time.perf_counter() - t0 > seconds_budget:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+    with ThreadPoolExecutor(nthreads) as ex:
+        res = list(ex.map(lambda i: _cpu_worker(libpath, frames[i::nthreads] if len(frames) >= 2 * nthreads else frames,
+                                                seconds_budget, False), range(nthreads)))
+    dt_all = time.perf_counter() - t0
+    n_all = sum(r[0] for r in res)
+    return {"value": n1 / dt1, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d synthetic 640x480 frames, 1000 features, extract + BF match vs previous frame, "
-                      "oracle built -O3 -march=native -ffp-contract=off, host has %d cores" % (n, os.cpu_count())}
+                      "oracle built -O3 -march=native -ffp-contract=off, host has %d cores" % (n1, os.cpu_count()),
+            "stage_ms_per_frame": {k: round(v, 4) for k, v in stages.items()},
+            "all_cores": {"value": n_all / dt_all, "unit": "frames/s", "cores": nthreads,
+                          "sample": "%d frames over %d threads (frame-parallel, one extractor per thread), %.1f s"
+                                    % (n_all, nthreads, dt_all)}}
 
 
 def main():
@@ -117,6 +158,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per step and per GPU")
     ap.add_argument("--pool", type=int, default=1024, help="distinct resident frames cycled through (> Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the C3 / C4 measurements and the copy-kernel roofline reported next to the contract line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--rehearse-on-device0", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
@@ -273,7 +316,8 @@ def main():
 
     if rank == 0:
         # dominant kernel of the extraction pipeline + its roofline fraction
-        n_cand = 13700.0  # typical FAST survivors per synthetic frame (tests/golden); used for the quadtree row only
+        # FAST survivors handed to the quadtree (first frame of the self-check batch); prices the NMS / quadtree rows
+        n_cand = float(sum(len(ext.debug_read(G.DBG_CANDIDATES, 0, lvl)[0]) for lvl in range(8)))
         # dominant KERNEL = longest average launch; the pyramid stage is a chain of 8 launches, orient is 2
         launches = {k: len(v) for k, v in STAGE_KERNELS.items()}
         dom = max(stage_ms, key=lambda k: stage_ms[k] / launches[k])
@@ -281,6 +325,9 @@ def main():
         per_stage = {k: {"ms": round(v, 4),
                          "GB/s": round(algorithmic_bytes(k, n_kp, n_cand) * B / (max(v, 1e-6) * 1e-3) / 1e9, 1)}
                      for k, v in stage_ms.items()}
+        traffic, traffic_src = pmc_traffic(dom, B)
+        ext_bytes = sum(algorithmic_bytes(k, n_kp, n_cand) for k in ("pyramid", "fast_score", "blur", "orient", "describe"))
+        ext_ach = ext_bytes * B / (sum(stage_ms.values()) * 1e-3) / 1e9
         out = {
             "metric": "frames/sec ORB extract+match (640x480, 1000 feat)",
             "value": total_frames / elapsed_max,
@@ -300,16 +347,37 @@ def main():
                        "schedule": "matcher of step i overlapped with extraction of step i+1 (2 streams)"
                        if args.overlap_match else "serial, 1 stream"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B),
-                         "traffic_source": "profiles/r01_pmc_traffic.json (separate --pmc passes at B=64, scaled to B)",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": algorithmic_bytes(dom, n_kp, n_cand) * B,
                          "ms_per_launch": stage_ms[dom], "frames_per_launch": B},
             "stages": per_stage,
+            "extract_ms_per_step": round(sum(stage_ms.values()), 4),
+            "extract_roofline": {"achieved": ext_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_ach / HBM_PEAK_GBS,
+                                 "algorithmic_bytes": ext_bytes * B,
+                                 "note": "all seven extraction stages of one step against SURVEY.md 8d's 5.74 MB/frame"},
+            "fast_candidates_per_frame": n_cand,
             "match_ms_per_step": None if match_ms is None else round(match_ms, 4),
             "keypoints_per_frame": n_kp,
             "matches_per_frame": float(nm_host.mean()),
             "bf_sweeps_max": int(sweeps.max()),
         }
+        if not args.no_secondary and world == 1:
+            # free the C2 working set first, then: the practical roofline (plain copy kernel over 2 x 1 GiB, far past
+            # the Infinity Cache) and the other single-GPU configurations of BASELINE.json
+            del frames, kps, desc, match_b
+            torch.cuda.empty_cache()
+            from orb_slam2_map_amd import workloads
+            copy_gbs = G.measure_copy_bandwidth(1 << 30, 10, local_rank)
+            out["roofline"]["practical_peak"] = {"copy_kernel_GB/s": copy_gbs, "frac_of_practical": ach / copy_gbs,
+                                                 "what": "16 B/lane device-to-device copy, 1 GiB, read + write bytes"}
+            out["secondary"] = {}
+            for name, fn in (("c3", workloads.c3), ("c4", workloads.c4)):
+                try:
+                    r = fn(device_id=local_rank)
+                    r.pop("per_keyframe", None)
+                    out["secondary"][name] = r
+                except Exception as ex:  # the contract line must survive a secondary failure; say so loudly
+                    out["secondary"][name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([host_pool[i] for i in range(min(POOL, 400))])
         print(json.dumps(out), flush=True)

@@ -47,6 +47,10 @@ const char *orbgpu_last_error_string(void);
 int orbgpu_abi_version(void);
 /* Number of visible HIP devices (0 if none); never fails. */
 int orbgpu_device_count(void);
+/* Measurement aid: achieved HBM GB/s (bytes read + bytes written per second) of a plain 16-byte-per-lane
+ * device-to-device copy kernel over `bytes` (>= 1 MiB; use a size well past the 256 MB Infinity Cache) --
+ * the practical roofline bench.py reports next to the nominal 8 TB/s. */
+int orbgpu_measure_copy_bandwidth(size_t bytes, int32_t reps, int32_t device_id, float *gbs);
 
 /* ======================================================================================
  * ORBextractor  (reference include/ORBextractor.h:46-110, src/ORBextractor.cc)
@@ -418,6 +422,10 @@ int orbgpu_cloud_last_overflow(orbgpu_cloud *h, int32_t *overflow);
  * map, 2 = general path (sort of everything), 3 = merge attempted, its precondition check failed, redone by the
  * general path.  Results are identical; this is for tests and measurements. */
 int orbgpu_cloud_last_path(orbgpu_cloud *h, int32_t *path);
+/* Measurement aid: HIP events on the handle's stream around the kernels of an insert (first launch to last,
+ * uploads and the final state read-back excluded); last_insert_ms fails if no profiled insert happened. */
+int orbgpu_cloud_set_profiling(orbgpu_cloud *h, int32_t enable);
+int orbgpu_cloud_last_insert_ms(orbgpu_cloud *h, float *ms);
 
 /* Stateless stages (host pointers), for parity tests and other callers:
  * convertToPointCloud (PointCloudMap.cc:112-138) with optional pose transform (Tcw != NULL:

@@ -80,6 +80,8 @@ def lib(path=None):
     L.ora_get_pattern.restype = vp
     L.ora_get_levels.argtypes = [vp]
     L.ora_extract.argtypes = [vp, vp, ci, ci, C.c_size_t, vp, vp, ci]
+    L.ora_extractor_stage_seconds.argtypes = [vp, vp, ci]
+    L.ora_extractor_stage_seconds.restype = None
     L.ora_pyramid_level.restype = vp
     L.ora_pyramid_level.argtypes = [vp, ci, vp, vp, vp]
     L.ora_blurred_level.restype = vp
@@ -158,6 +160,14 @@ class Extractor:
 
     def umax(self):
         return _arr(self.L.ora_get_umax(self.h), 16, "<i4")
+
+    STAGES = ("pyramid", "fast", "quadtree", "orient", "blur", "describe")
+
+    def stage_seconds(self, reset=True):
+        """Seconds spent per stage since creation / the last reset (CPU-baseline aid)."""
+        out = np.zeros(len(self.STAGES), np.float64)
+        self.L.ora_extractor_stage_seconds(self.h, _p(out), int(reset))
+        return dict(zip(self.STAGES, out.tolist()))
 
     def extract(self, gray):
         gray = np.ascontiguousarray(gray, dtype=np.uint8)

@@ -42,6 +42,11 @@ typedef struct {
 
 typedef struct ora_extractor ora_extractor;
 
+/* CPU-baseline aid: wall-clock seconds the extractor spent per stage (accumulated over ora_extract calls). */
+enum { ORA_STAGE_PYRAMID = 0, ORA_STAGE_FAST, ORA_STAGE_QUADTREE, ORA_STAGE_ORIENT, ORA_STAGE_BLUR,
+       ORA_STAGE_DESCRIBE, ORA_STAGE_COUNT };
+void ora_extractor_stage_seconds(ora_extractor *e, double out[ORA_STAGE_COUNT], int reset);
+
 /* ---- E0: constructor tables, ORBextractor.cc:410-470 ---- */
 ora_extractor *ora_extractor_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast,
                                     int min_th_fast);

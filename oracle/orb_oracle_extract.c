@@ -5,12 +5,14 @@
  * primitives it calls.  Compile with -ffp-contract=off.
  * Parity unpinned at the OpenCV boundary (no reference fixtures exist).
  */
+#define _POSIX_C_SOURCE 199309L /* clock_gettime under -std=c11 */
 #include "orb_oracle.h"
 
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ A1 rounding */
 /* cvRound on x86-64 = cvtsd2si under round-to-nearest-even. */
@@ -68,7 +70,16 @@ struct ora_extractor {
     int blurred[ORA_MAX_LEVELS];
     corner_vec cand[ORA_MAX_LEVELS];
     corner_vec sel[ORA_MAX_LEVELS];
+    /* CPU-baseline aid (bench.py): seconds spent per stage since creation / the last read */
+    double stage_s[ORA_STAGE_COUNT];
 };
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 /* ------------------------------------------------------------------ E0 */
 /* ORBextractor.cc:410-470 */
@@ -231,22 +242,32 @@ void ora_gauss7_u8(const uint8_t *src, int w, int h, size_t sstride, uint8_t *ds
             ki[i] = cv_round(kf[i] * 256.f);
         }
     }
+    /* same sums as the definition (row pass to int32, column pass, (s + 32768) >> 16), written so that the
+     * compiler vectorises the interior: the reflect-101 index is only evaluated at the borders */
     int *tmp = (int *)malloc(sizeof(int) * (size_t)w * (size_t)h);
     for (int y = 0; y < h; y++) {
         const uint8_t *S = src + (size_t)y * sstride;
+        int *T = tmp + (size_t)y * w;
         for (int x = 0; x < w; x++) {
+            if (x >= 3 && x < w - 3)
+                continue;
             int s = 0;
             for (int k = -3; k <= 3; k++)
                 s += ki[k + 3] * S[reflect101(x + k, w)];
-            tmp[(size_t)y * w + x] = s;
+            T[x] = s;
         }
+        for (int x = 3; x < w - 3; x++)
+            T[x] = ki[0] * S[x - 3] + ki[1] * S[x - 2] + ki[2] * S[x - 1] + ki[3] * S[x] + ki[4] * S[x + 1] +
+                   ki[5] * S[x + 2] + ki[6] * S[x + 3];
     }
     for (int y = 0; y < h; y++) {
         uint8_t *D = dst + (size_t)y * dstride;
+        const int *R[7];
+        for (int k = -3; k <= 3; k++)
+            R[k + 3] = tmp + (size_t)reflect101(y + k, h) * w;
         for (int x = 0; x < w; x++) {
-            int s = 0;
-            for (int k = -3; k <= 3; k++)
-                s += ki[k + 3] * tmp[(size_t)reflect101(y + k, h) * w + x];
+            int s = ki[0] * R[0][x] + ki[1] * R[1][x] + ki[2] * R[2][x] + ki[3] * R[3][x] + ki[4] * R[4][x] +
+                    ki[5] * R[5][x] + ki[6] * R[6][x];
             int v = (s + 32768) >> 16;
             D[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
         }
@@ -499,7 +520,7 @@ static void q_divide(qlist *L, int id, const ora_corner *keys, int *perm, int *s
     }
 }
 
-static qlist *g_sort_list;
+static _Thread_local qlist *g_sort_list; /* per thread: the CPU baseline runs one extractor per thread */
 static int q_cmp_size_seq(const void *a, const void *b)
 {
     const qnode *A = &g_sort_list->n[*(const int *)a], *B = &g_sort_list->n[*(const int *)b];
@@ -767,6 +788,7 @@ static void compute_keypoints_level(ora_extractor *e, int level)
     corner_vec *sel = &e->sel[level];
     cand->n = 0;
     sel->n = 0;
+    double t_begin = now_s();
 
     const float width = (float)(maxBorderX - minBorderX);
     const float height = (float)(maxBorderY - minBorderY);
@@ -810,6 +832,8 @@ static void compute_keypoints_level(ora_extractor *e, int level)
         }
     }
     free(cell);
+    e->stage_s[ORA_STAGE_FAST] += now_s() - t_begin;
+    t_begin = now_s();
 
     int cap = cand->n > 0 ? cand->n : 1;
     if (sel->cap < cap) {
@@ -819,6 +843,7 @@ static void compute_keypoints_level(ora_extractor *e, int level)
     int n = ora_distribute_octtree(cand->v, cand->n, minBorderX, maxBorderX, minBorderY, maxBorderY,
                                    e->quota[level], sel->v, cap);
     sel->n = n < 0 ? 0 : n;
+    e->stage_s[ORA_STAGE_QUADTREE] += now_s() - t_begin;
 }
 
 /* ------------------------------------------------------------------ E8 operator() */
@@ -827,7 +852,9 @@ int ora_extract(ora_extractor *e, const uint8_t *gray, int w, int h, size_t stri
 {
     if (w <= 0 || h <= 0 || !gray)
         return 0; /* :1046 empty image */
+    double t0 = now_s();
     compute_pyramid(e, gray, w, h, stride);
+    e->stage_s[ORA_STAGE_PYRAMID] += now_s() - t0;
     int total = 0;
     for (int level = 0; level < e->nlevels; level++) {
         compute_keypoints_level(e, level);
@@ -848,12 +875,14 @@ int ora_extract(ora_extractor *e, const uint8_t *gray, int w, int h, size_t stri
         /* :1085-1086 clone (drops the border) + GaussianBlur(7x7, 2, 2, REFLECT_101) */
         free(e->blur[level]);
         e->blur[level] = (uint8_t *)malloc((size_t)lw * (size_t)lh);
+        t0 = now_s();
         uint8_t *clone = (uint8_t *)malloc((size_t)lw * (size_t)lh);
         for (int y = 0; y < lh; y++)
             memcpy(clone + (size_t)y * lw, origin + (size_t)y * pitch, (size_t)lw);
         ora_gauss7_u8(clone, lw, lh, (size_t)lw, e->blur[level], (size_t)lw);
         free(clone);
         e->blurred[level] = 1;
+        e->stage_s[ORA_STAGE_BLUR] += now_s() - t0;
 
         const int scaledPatchSize = (int)(31 * e->scale[level]); /* :837 */
         const float scale = e->scale[level];
@@ -868,9 +897,13 @@ int ora_extract(ora_extractor *e, const uint8_t *gray, int w, int h, size_t stri
             kp.class_id = -1;
             int px = cv_round(kp.x), py = cv_round(kp.y);
             /* :851-852 orientation on the un-blurred level */
+            t0 = now_s();
             kp.angle = ora_ic_angle(origin + (size_t)py * pitch + px, pitch, e->umax);
+            const double t1 = now_s();
+            e->stage_s[ORA_STAGE_ORIENT] += t1 - t0;
             /* :1089-1090 descriptor on the blurred level */
             ora_orb_descriptor(e->blur[level] + (size_t)py * lw + px, lw, kp.angle, desc + (size_t)(offset + k) * 32);
+            e->stage_s[ORA_STAGE_DESCRIBE] += now_s() - t1;
             if (level != 0) { /* :1095-1101 */
                 kp.x *= scale;
                 kp.y *= scale;
@@ -880,6 +913,15 @@ int ora_extract(ora_extractor *e, const uint8_t *gray, int w, int h, size_t stri
         offset += n;
     }
     return total;
+}
+
+void ora_extractor_stage_seconds(ora_extractor *e, double out[ORA_STAGE_COUNT], int reset)
+{
+    for (int i = 0; i < ORA_STAGE_COUNT; i++) {
+        out[i] = e->stage_s[i];
+        if (reset)
+            e->stage_s[i] = 0.0;
+    }
 }
 
 const uint8_t *ora_pyramid_level(const ora_extractor *e, int level, int *w, int *h, int *pitch)

@@ -58,7 +58,8 @@ constexpr unsigned long long LB_AGG = 1ull << 30, LB_PREFIX = 2ull << 30, LB_FLA
 
 __device__ __forceinline__ void lb_publish(unsigned long long *slot, unsigned epoch, unsigned long long flag, unsigned v)
 {
-    __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | flag | (unsigned long long)v, __ATOMIC_RELEASE,
+    // relaxed: the word carries its own payload, no other data is handed over, so no L2 write-back / invalidate
+    __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | flag | (unsigned long long)v, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ unsigned lb_exclusive(unsigned long long *status, int
     for (int t = tile - 1; t >= 0; --t) {
         unsigned long long w;
         for (;;) {
-            w = __hip_atomic_load(status + (size_t)t * stride + chan, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            w = __hip_atomic_load(status + (size_t)t * stride + chan, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(w >> 32) == epoch && (w & LB_FLAGS))
                 break;
             __builtin_amdgcn_s_sleep(1);
@@ -103,11 +104,11 @@ __device__ __forceinline__ void lb_leave(LbCtl *ctl)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&ctl->finished, 1u) == gridDim.x - 1) {
-            ctl->ticket = 0;
-            ctl->finished = 0;
-            __threadfence();
+        // every workgroup has taken its ticket before it gets here; the stores below become visible to the next
+        // launch at the kernel boundary
+        if (__hip_atomic_fetch_add(&ctl->finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void k_bp(const float *__restrict__ depth, siz
     __shared__ unsigned s_cnt[16], s_base;
     __shared__ Box s_box[4];
     if (threadIdx.x == 0)
-        s_tile = (int)atomicAdd(&ctl->ticket, 1u);
+        s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int tile = s_tile;
     const int gw = (w + 2) / 3, gh = (h + 2) / 3;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void k_sort_pass(const uint32_t *__restrict__ 
     __shared__ unsigned s_scan[256];
     __shared__ int s_tile;
     if (threadIdx.x == 0)
-        s_tile = (int)atomicAdd(&ctl->ticket, 1u);
+        s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int tile = s_tile;
     const int n = st->n_sort;
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void k_vox_reduce(const Point *__restrict__ pt
     __shared__ unsigned s_cnt[16], s_base;
     __shared__ Box s_box[4];
     if (threadIdx.x == 0)
-        s_tile = (int)atomicAdd(&ctl->ticket, 1u);
+        s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int tile = s_tile;
     const int ntiles = (n_in + TILE - 1) / TILE;
@@ -676,11 +677,10 @@ __global__ __launch_bounds__(256) void k_vox_reduce(const Point *__restrict__ pt
 }
 
 // ---- fast path: merge the sorted new points into the resident (sorted, one point per voxel) map ----------------
-__device__ __forceinline__ int old_upper_bound(const Point *__restrict__ old, int K, uint32_t key, float inv,
+__device__ __forceinline__ int old_upper_bound(const Point *__restrict__ old, int lo, int hi, uint32_t key, float inv,
                                                const int min_b[3], const int mul[3])
 {
-    int lo = 0, hi = K;  // first index whose key is > key
-    while (lo < hi) {
+    while (lo < hi) {  // first index in [lo, hi) whose key is > key (hi if none)
         const int mid = (lo + hi) >> 1;
         if (vox_key(old[mid], inv, min_b, mul) <= key)
             lo = mid + 1;
@@ -689,7 +689,7 @@ __device__ __forceinline__ int old_upper_bound(const Point *__restrict__ old, in
     }
     return lo;
 }
-__device__ __forceinline__ int key_lower_bound(const uint32_t *__restrict__ a, int lo, int hi, uint32_t key)
+template <typename A> __device__ __forceinline__ int key_lower_bound(const A *a, int lo, int hi, uint32_t key)
 {
     while (lo < hi) {  // first index in [lo, hi) whose key is >= key
         const int mid = (lo + hi) >> 1;
@@ -700,33 +700,59 @@ __device__ __forceinline__ int key_lower_bound(const uint32_t *__restrict__ a, i
     }
     return lo;
 }
+__device__ __forceinline__ int lds_count_le(const uint32_t *a, int n, uint32_t key)
+{
+    int lo = 0, hi = n;  // number of entries <= key in the ascending array a[0..n)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+constexpr int MERGE_SAMPLES = 1024;
 
 // new-point side: every run of equal keys among the sorted new points becomes one output voxel -- merged with the
 // resident map's point of that voxel if there is one (it comes first in PCL's input order), a new voxel otherwise.
 // cexcl[j] = new voxels opened by runs before j (look-back); a run's output position is its rank among the
 // resident points plus that count.
+// The rank (number of resident points with index <= key) is found without a 20-deep chain of dependent HBM loads:
+// 1024 evenly spaced resident indices go to LDS (one load per thread), the tile's first / last key bracket the
+// range every rank of the tile lies in, that range is sampled again (or, if it has <= 1024 points, read whole),
+// and only the last few levels are a per-thread search in global memory.
+// Side job: tile_lb[b] = first sorted new key >= the index of resident point b*1024, which brackets the new keys
+// k_merge_old's workgroup b has to look at.
 __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old, int K,
                                                    const Point *__restrict__ newp, const uint32_t *__restrict__ skeys,
                                                    const uint32_t *__restrict__ svals, float inv, CloudState *st,
-                                                   unsigned *__restrict__ cexcl, Point *__restrict__ out, LbCtl *ctl,
-                                                   unsigned long long *status, unsigned epoch,
-                                                   unsigned *__restrict__ outbox)
+                                                   unsigned *__restrict__ cexcl, int *__restrict__ tile_lb,
+                                                   Point *__restrict__ out, LbCtl *ctl, unsigned long long *status,
+                                                   unsigned epoch, unsigned *__restrict__ outbox)
 {
-    __shared__ int s_tile;
+    __shared__ int s_tile, s_lo, s_hi;
     __shared__ unsigned s_cnt[16], s_base;
     __shared__ Box s_box[4];
+    __shared__ uint32_t s_samp[MERGE_SAMPLES];
     if (threadIdx.x == 0)
-        s_tile = (int)atomicAdd(&ctl->ticket, 1u);
+        s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int tile = s_tile;
     const int nf = st->nfinite;
     const int ntiles = max((nf + TILE - 1) / TILE, 1);
+    int min_b[3], mul[3];
+    for (int a = 0; a < 3; a++) {
+        min_b[a] = st->min_b[a];
+        mul[a] = st->mul[a];
+    }
+    if (!st->overflow) {
+        const int ntk = (K + TILE - 1) / TILE;
+        for (int b = tile * 256 + threadIdx.x; b < ntk; b += gridDim.x * 256)
+            tile_lb[b] = key_lower_bound(skeys, 0, nf, vox_key(old[(size_t)b * TILE], inv, min_b, mul));
+    }
     if (tile < ntiles && !st->overflow) {
-        int min_b[3], mul[3];
-        for (int a = 0; a < 3; a++) {
-            min_b[a] = st->min_b[a];
-            mul[a] = st->mul[a];
-        }
         bool head[4], opens[4];
         int rnk[4];
         uint32_t key[4];
@@ -740,14 +766,58 @@ __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old
             if (j < nf) {
                 key[k] = skeys[j];
                 head[k] = j == 0 || skeys[j - 1] != key[k];
-                if (head[k]) {
-                    rnk[k] = old_upper_bound(old, K, key[k], inv, min_b, mul);
-                    const bool exists = rnk[k] > 0 && vox_key(old[rnk[k] - 1], inv, min_b, mul) == key[k];
-                    opens[k] = !exists;
-                    if (exists)
-                        rnk[k] = -rnk[k];  // negative: merges into resident point -rnk-1 ... see below
-                }
             }
+        }
+        if (K > 0 && nf > 0) {
+            // level A: samples over the whole resident map
+            const int npa = min(K, MERGE_SAMPLES);
+            for (int s = threadIdx.x; s < npa; s += 256) {
+                const int pos = K <= MERGE_SAMPLES ? s : (int)((long long)s * K / MERGE_SAMPLES);
+                s_samp[s] = vox_key(old[pos], inv, min_b, mul);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int c = lds_count_le(s_samp, npa, skeys[tile * TILE]);
+                s_lo = c == 0 ? 0 : (K <= MERGE_SAMPLES ? c - 1 : (int)((long long)(c - 1) * K / MERGE_SAMPLES)) + 1;
+            }
+            if (threadIdx.x == 64) {
+                const int c = lds_count_le(s_samp, npa, skeys[min(tile * TILE + TILE, nf) - 1]);
+                s_hi = c == npa ? K : (K <= MERGE_SAMPLES ? c : (int)((long long)c * K / MERGE_SAMPLES));
+            }
+            __syncthreads();
+            const int lo = s_lo, hi = max(s_hi, s_lo), len = hi - lo;
+            // level B: the tile's range, whole or sampled
+            const bool exact = len <= MERGE_SAMPLES;
+            const int npb = exact ? len : MERGE_SAMPLES;
+            for (int s = threadIdx.x; s < npb; s += 256) {
+                const int pos = exact ? lo + s : lo + (int)((long long)s * len / MERGE_SAMPLES);
+                s_samp[s] = vox_key(old[pos], inv, min_b, mul);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!head[k])
+                    continue;
+                const int c = lds_count_le(s_samp, npb, key[k]);
+                int r;
+                bool exists;
+                if (exact) {
+                    r = lo + c;
+                    // (c == 0: the candidate is the point just below the staged range)
+                    exists = c > 0 ? s_samp[c - 1] == key[k] : (r > 0 && vox_key(old[r - 1], inv, min_b, mul) == key[k]);
+                } else {
+                    const int a = c == 0 ? lo : lo + (int)((long long)(c - 1) * len / MERGE_SAMPLES) + 1;
+                    const int b = c == npb ? hi : lo + (int)((long long)c * len / MERGE_SAMPLES);
+                    r = old_upper_bound(old, a, max(a, b), key[k], inv, min_b, mul);
+                    exists = r > 0 && vox_key(old[r - 1], inv, min_b, mul) == key[k];
+                }
+                opens[k] = !exists;
+                rnk[k] = exists ? -r : r;  // negative: merges into resident point r-1
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                opens[k] = head[k];
         }
         const unsigned tot = tile_flag_scan(opens, excl, s_cnt);
         const unsigned base = lb_tile_base(status, tile, epoch, tot, &s_base);
@@ -785,17 +855,21 @@ __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old
     lb_leave(ctl);
 }
 
+constexpr int MERGE_OLD_LDS = 2048;
+
 // resident side: a point whose voxel received no new point moves up by the number of new voxels that sort before
-// it.  Also checks that the resident map really is strictly increasing under the new keys (a centroid rounded
-// onto a voxel boundary, or a map left unfiltered by the overflow rule, is not): the host then redoes the
-// key frame through the general path.
+// it.  One pass: K*16 B in, (K - touched)*16 B out.  The sorted new keys a workgroup can meet are bracketed by
+// tile_lb[b], tile_lb[b+1] and staged in LDS.  Also checks that the resident map really is strictly increasing
+// under the new keys (a centroid rounded onto a voxel boundary, or a map left unfiltered by the overflow rule, is
+// not): the host then redoes the key frame through the general path.
 __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old, int K,
                                                    const uint32_t *__restrict__ skeys,
-                                                   const unsigned *__restrict__ cexcl, float inv, CloudState *st,
+                                                   const unsigned *__restrict__ cexcl,
+                                                   const int *__restrict__ tile_lb, float inv, CloudState *st,
                                                    Point *__restrict__ out, unsigned *__restrict__ outbox)
 {
     __shared__ Box s_box[4];
-    __shared__ int s_lo, s_hi;
+    __shared__ uint32_t s_keys[MERGE_OLD_LDS];
     if (st->overflow)
         return;
     const int nf = st->nfinite;
@@ -804,33 +878,52 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
         min_b[a] = st->min_b[a];
         mul[a] = st->mul[a];
     }
-    const int i0 = blockIdx.x * TILE, i1 = min(i0 + TILE, K) - 1;
-    if (threadIdx.x == 0)
-        s_lo = key_lower_bound(skeys, 0, nf, vox_key(old[i0], inv, min_b, mul));
-    if (threadIdx.x == 64)
-        s_hi = key_lower_bound(skeys, 0, nf, vox_key(old[i1], inv, min_b, mul));
+    const int ntk = (K + TILE - 1) / TILE;
+    const int i0 = blockIdx.x * TILE;
+    const int lo = min(max(tile_lb[blockIdx.x], 0), nf);
+    const int hi = min(max((int)blockIdx.x + 1 < ntk ? tile_lb[blockIdx.x + 1] : nf, lo), nf);
+    const int len = hi - lo;
+    const bool staged = len <= MERGE_OLD_LDS;
+    if (staged)
+        for (int s = threadIdx.x; s < len; s += 256)
+            s_keys[s] = skeys[lo + s];
     __syncthreads();
-    const int lo = s_lo, hi = max(s_hi, s_lo);
     Box bx;
     box_init(bx);
     bool bad = false;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int i = i0 + k * 256 + threadIdx.x;
+        Point p;
+        uint32_t key = 0;
+        if (i < K) {
+            p = old[i];
+            key = vox_key(p, inv, min_b, mul);
+        }
+        uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
         if (i >= K)
             continue;
-        const Point p = old[i];
-        const uint32_t key = vox_key(p, inv, min_b, mul);
-        if (i > 0 && vox_key(old[i - 1], inv, min_b, mul) >= key)
+        if (lane == 0 && i > 0)
+            prev = vox_key(old[i - 1], inv, min_b, mul);
+        if (i > 0 && prev >= key)
             bad = true;
-        int lb = key_lower_bound(skeys, lo, hi, key);
-        lb = min(max(lb, 0), nf);
-        if (lb < nf && skeys[lb] == key)
+        int lb;
+        bool touched;
+        if (staged) {
+            const int c = key_lower_bound(s_keys, 0, len, key);
+            lb = lo + c;
+            touched = c < len ? s_keys[c] == key : (lb < nf && skeys[lb] == key);
+        } else {
+            lb = key_lower_bound(skeys, lo, hi, key);
+            touched = lb < nf && skeys[lb] == key;
+        }
+        if (touched)
             continue;  // merged by k_merge_new
         out[i + (int)cexcl[lb]] = p;
         box_add(bx, p);
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0)
+    if (__any(bad) && lane == 0)
         st->unsorted = 1;
     box_block_reduce(bx, s_box);
     if (threadIdx.x == 0)
@@ -841,7 +934,7 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
 // host side
 // ------------------------------------------------------------------------------------------
 struct VoxelWorkspace {
-    DevBuf keys[2], vals[2], status, part, cexcl, ctl, state, ghist;
+    DevBuf keys[2], vals[2], status, part, cexcl, tile_lb, ctl, state, ghist;
     unsigned epoch = 0;
     bool armed = false;
     int reserve(long long n_sort, int nparts)
@@ -892,7 +985,7 @@ struct VoxelWorkspace {
             keys[k].release();
             vals[k].release();
         }
-        status.release(), part.release(), cexcl.release(), ctl.release(), state.release(), ghist.release();
+        status.release(), part.release(), cexcl.release(), tile_lb.release(), ctl.release(), state.release(), ghist.release();
         armed = false;
     }
 };
@@ -1094,6 +1187,9 @@ struct orbgpu_cloud {
     VoxelWorkspace ws;
     FrameStage fs;
     hipStream_t stream = nullptr;
+    bool profiling = false;  // HIP events on the handle's stream around the kernels of an insert
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    float last_ms = -1.f;
 };
 
 namespace orbgpu {
@@ -1165,7 +1261,8 @@ static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dst
         return rc;
     if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK)
         return rc;
-    if ((rc = c->box.reserve(sizeof(unsigned) * 12)) != ORBGPU_OK)
+    if ((rc = c->box.reserve(sizeof(unsigned) * 12)) != ORBGPU_OK ||
+        (rc = c->ws.tile_lb.reserve(sizeof(int) * (size_t)(tiles_of(K) + 1) * 2)) != ORBGPU_OK)
         return rc;
     VoxelWorkspace &ws = c->ws;
     CloudState *S = ws.state.as<CloudState>();
@@ -1173,6 +1270,9 @@ static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dst
     unsigned *box_in = c->box.as<unsigned>() + 6 * c->cur, *box_out = c->box.as<unsigned>() + 6 * (c->cur ^ 1);
     const float inv = 1.0f / c->leaf;
     const bool merge = K == 0 || c->sorted_map;
+    c->last_ms = -1.f;
+    if (c->profiling)
+        ORBGPU_HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     // globalMap += transform(convertToPointCloud(kf), Twc)   (:204-249)
     if ((rc = backproject_launch(c->fs, d_depth, dstride, d_rgb, cstride, w, h, fx, fy, cx, cy, Tcw, newp, &S->n_sort,
                                  ws.ghist.as<unsigned>(), box_out, c->stream)) != ORBGPU_OK)
@@ -1185,15 +1285,21 @@ static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dst
                            ws.vals[0].as<uint32_t>(), ws.ghist.as<unsigned>());
         radix_sort_device(ws, ntn, c->stream);
         hipLaunchKernelGGL(k_merge_new, dim3(ntn), dim3(256), 0, c->stream, old, (int)K, newp, ws.keys[0].as<uint32_t>(),
-                           ws.vals[0].as<uint32_t>(), inv, S, ws.cexcl.as<unsigned>(), out, ws.ctl.as<LbCtl>(),
+                           ws.vals[0].as<uint32_t>(), inv, S, ws.cexcl.as<unsigned>(), ws.tile_lb.as<int>(), out,
+                           ws.ctl.as<LbCtl>(),
                            ws.status.as<unsigned long long>(), ws.next_epoch(), box_out);
         if (K > 0)
             hipLaunchKernelGGL(k_merge_old, dim3(tiles_of(K)), dim3(256), 0, c->stream, old, (int)K,
-                               ws.keys[0].as<uint32_t>(), ws.cexcl.as<unsigned>(), inv, S, out, box_out);
+                               ws.keys[0].as<uint32_t>(), ws.cexcl.as<unsigned>(), ws.tile_lb.as<int>(), inv, S, out,
+                               box_out);
         ORBGPU_HIP_TRY(hipGetLastError());
+        if (c->profiling)
+            ORBGPU_HIP_TRY(hipEventRecord(c->ev[1], c->stream));
         if ((rc = read_state(c, hs)) != ORBGPU_OK)
             return rc;
         if (!hs.overflow && !hs.unsorted) {
+            if (c->profiling)
+                ORBGPU_HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
             c->cur ^= 1;
             c->size = hs.nout;
             c->last_overflow = 0;
@@ -1208,7 +1314,13 @@ static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dst
         c->last_path = 2;
     }
     // voxel.setInputCloud(globalMap); voxel.filter(tmp); swap   (:259-262), general path
-    return cloud_filter(c, K + hs.n_sort);
+    rc = cloud_filter(c, K + hs.n_sort);
+    if (rc == ORBGPU_OK && c->profiling) {
+        ORBGPU_HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+        ORBGPU_HIP_TRY(hipEventSynchronize(c->ev[1]));
+        ORBGPU_HIP_TRY(hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
+    }
+    return rc;
 }
 
 } // namespace orbgpu
@@ -1250,6 +1362,9 @@ int orbgpu_cloud_destroy(orbgpu_cloud *c)
     c->box.release();
     c->ws.release();
     c->fs.release();
+    for (hipEvent_t e : c->ev)
+        if (e)
+            (void)hipEventDestroy(e);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1359,6 +1474,28 @@ int orbgpu_cloud_last_overflow(orbgpu_cloud *c, int32_t *overflow)
 {
     ORBGPU_REQUIRE(c && overflow, "null argument");
     *overflow = c->last_overflow;
+    return ORBGPU_OK;
+}
+
+int orbgpu_cloud_set_profiling(orbgpu_cloud *c, int32_t enable)
+{
+    ORBGPU_REQUIRE(c, "null argument");
+    int rc = select_device(c->device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    if (enable && !c->ev[0]) {
+        ORBGPU_HIP_TRY(hipEventCreate(&c->ev[0]));
+        ORBGPU_HIP_TRY(hipEventCreate(&c->ev[1]));
+    }
+    c->profiling = enable != 0;
+    return ORBGPU_OK;
+}
+
+int orbgpu_cloud_last_insert_ms(orbgpu_cloud *c, float *ms)
+{
+    ORBGPU_REQUIRE(c && ms, "null argument");
+    ORBGPU_REQUIRE(c->last_ms >= 0.f, "no profiled insert recorded (orbgpu_cloud_set_profiling)");
+    *ms = c->last_ms;
     return ORBGPU_OK;
 }
 

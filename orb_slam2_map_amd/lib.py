@@ -95,7 +95,7 @@ _LIB = None
 
 # every symbol include/orbgpu.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
-    "orbgpu_last_error_string", "orbgpu_abi_version", "orbgpu_device_count",
+    "orbgpu_last_error_string", "orbgpu_abi_version", "orbgpu_device_count", "orbgpu_measure_copy_bandwidth",
     "orbgpu_extractor_create", "orbgpu_extractor_destroy", "orbgpu_extractor_get_levels",
     "orbgpu_extractor_get_scale_factor", "orbgpu_extractor_get_scale_factors",
     "orbgpu_extractor_get_inv_scale_factors", "orbgpu_extractor_get_sigma2", "orbgpu_extractor_get_inv_sigma2",
@@ -108,7 +108,7 @@ ABI_SYMBOLS = [
     "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_insert_device",
-    "orbgpu_cloud_last_path", "orbgpu_cloud_rebuild",
+    "orbgpu_cloud_last_path", "orbgpu_cloud_set_profiling", "orbgpu_cloud_last_insert_ms", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
     "orbgpu_voxel_filter",
 ]
@@ -174,6 +174,8 @@ def lib():
         "orbgpu_cloud_insert": [vp, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
         "orbgpu_cloud_insert_device": [vp, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
         "orbgpu_cloud_last_path": [vp, vp],
+        "orbgpu_cloud_set_profiling": [vp, i32],
+        "orbgpu_cloud_last_insert_ms": [vp, vp],
         "orbgpu_cloud_rebuild": [vp, i32, vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp],
         "orbgpu_cloud_size": [vp, vp],
         "orbgpu_cloud_download": [vp, vp, C.c_int64, vp],
@@ -201,6 +203,15 @@ def _p(a):
 
 def device_count():
     return lib().orbgpu_device_count()
+
+
+def measure_copy_bandwidth(nbytes=1 << 30, reps=10, device_id=0):
+    """Achieved GB/s (read + write) of a plain device-to-device copy kernel: the practical HBM roofline."""
+    L = lib()
+    L.orbgpu_measure_copy_bandwidth.argtypes = [C.c_size_t, C.c_int32, C.c_int32, C.c_void_p]
+    v = C.c_float()
+    check(L.orbgpu_measure_copy_bandwidth(nbytes, reps, device_id, C.byref(v)))
+    return v.value
 
 
 # --------------------------------------------------------------------------------------------
@@ -587,6 +598,14 @@ class PointCloudMapping:
         T = np.ascontiguousarray(Tcw, np.float32)
         check(self.L.orbgpu_cloud_insert_device(self.h, d_depth, depth_stride, d_rgb, rgb_stride, w, h, fx, fy, cx, cy,
                                                 _p(T)))
+
+    def set_profiling(self, on):
+        check(self.L.orbgpu_cloud_set_profiling(self.h, int(on)))
+
+    def last_insert_ms(self):
+        v = C.c_float()
+        check(self.L.orbgpu_cloud_last_insert_ms(self.h, C.byref(v)))
+        return v.value
 
     def last_path(self):
         v = C.c_int32()

@@ -1,0 +1,228 @@
+"""Secondary workloads of BASELINE.json (C3, C4) measured through the C ABI -- used by bench.py (`secondary`) and
+tools/bench_extra.py.  Inputs are synthetic and built with numpy only (no oracle, no reference); parity of the same
+entry points is the job of tests/test_gpu_matcher_proj.py and tests/test_gpu_cloud.py.
+
+Durations are HIP-event times on the stream the kernels run on; bytes are SURVEY.md 8d's algorithmic bytes.
+"""
+import time
+
+import numpy as np
+
+from . import lib as G
+from .synth import Stream
+
+HBM_PEAK_GBS = 8000.0
+
+
+def rigid(rx=0.01, ry=-0.02, rz=0.015, t=(0.03, -0.02, 0.05)):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = t
+    return T.astype(np.float32)
+
+
+def _world_points(kps, depth, shift, st, Tcw, rng, jitter=0.6):
+    """World positions for a previous frame's key points so that they project, in the current frame, onto the
+    image content they came from (the stream is a translating window of one canvas)."""
+    fx, fy, cx, cy = float(st.fx), float(st.fy), float(st.cx), float(st.cy)
+    u = kps["x"].astype(np.float64) - shift[0] + rng.normal(0, jitter, len(kps))
+    v = kps["y"].astype(np.float64) - shift[1] + rng.normal(0, jitter, len(kps))
+    d = depth[kps["y"].astype(np.int64), kps["x"].astype(np.int64)].astype(np.float64)
+    d = np.where(d > 0, d, 2.0)
+    Pc = np.stack([(u - cx) * d / fx, (v - cy) * d / fy, d], 1)
+    T = Tcw.astype(np.float64)
+    return ((Pc - T[:3, 3]) @ T[:3, :3]).astype(np.float32)
+
+
+def local_map_table(world_pos, desc, octave, scale_factors, Tcw, rng):
+    """MapPoint fields Frame::isInFrustum reads (normal, invariance distances as UpdateNormalAndDepth sets them)."""
+    sf = np.asarray(scale_factors, np.float32)
+    T = Tcw.astype(np.float64)
+    Ow = -T[:3, :3].T @ T[:3, 3]
+    P = world_pos.astype(np.float64)
+    dist = np.linalg.norm(P - Ow, axis=1)
+    normal = (P - Ow) / np.maximum(dist, 1e-9)[:, None]
+    max_d = (dist * sf[octave]).astype(np.float32)
+    min_d = (max_d / sf[-1]).astype(np.float32)
+    m = len(P)
+    return {"world_pos": np.ascontiguousarray(world_pos, np.float32), "normal": normal.astype(np.float32),
+            "min_dist": min_d, "max_dist": max_d, "desc": np.ascontiguousarray(desc, np.uint8),
+            "skip": (rng.random(m) < 0.02).astype(np.uint8), "obs_pos": np.ones(m, np.uint8)}
+
+
+def c3(reps=30, device_id=0):
+    """C3: 1280x960, 2000 features, extract + SearchByProjection against ~10 k local map points, device resident
+    (Tracking::SearchLocalPoints: isInFrustum + ORBmatcher::SearchByProjection(F, vpMapPoints, th))."""
+    import torch
+    W, H, NF = 1280, 960, 2000
+    rng = np.random.default_rng(5678)
+    st = Stream(W, H, 1234)
+    nprev, t_cur = 5, 12
+    ts = [t_cur - 1 - i for i in range(nprev)] + [t_cur]
+    frames = [st.frame(t) for t in ts]
+    ext = G.ORBextractor(NF, max_batch=nprev + 1, device_id=device_id)
+    ks, ds = ext.extract_batch(np.stack([f[0] for f in frames]))
+    sf = ext.GetScaleFactors()
+    Tcw = rigid()
+    ox, oy = st.offset(t_cur)
+    wp, dsc, octv = [], [], []
+    for i, t in enumerate(ts[:-1]):
+        px, py = st.offset(t)
+        wp.append(_world_points(ks[i], frames[i][2], (ox - px, oy - py), st, Tcw, rng))
+        dsc.append(ds[i]), octv.append(ks[i]["octave"])
+    wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
+    tab = local_map_table(wp, dsc, octv, sf, Tcw, rng)
+    M = len(wp)
+
+    dev = "cuda:%d" % device_id
+    img = torch.from_numpy(frames[-1][0][None]).to(dev)
+    depth = torch.from_numpy(frames[-1][2][None]).to(dev)
+    g1 = G.ORBextractor(NF, max_batch=1, device_id=device_id)
+    cap = g1.max_keypoints(W, H)
+    kps = torch.zeros((1, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+    nout = torch.zeros(1, dtype=torch.int32, device=dev)
+    ur, dz = (torch.zeros((1, cap), dtype=torch.float32, device=dev) for _ in range(2))
+    cs = torch.zeros((1, 64 * 48 + 1), dtype=torch.int32, device=dev)
+    items = torch.zeros((1, cap), dtype=torch.int32, device=dev)
+    dtab = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in tab.items()}
+    sfa = np.asarray(sf, np.float32)
+    fv = G.DeviceFrameView()
+    fv.cap, fv.n, fv.kps, fv.desc, fv.u_right = cap, nout.data_ptr(), kps.data_ptr(), desc.data_ptr(), ur.data_ptr()
+    fv.cell_start, fv.cell_items, fv.nlevels, fv.scale_factors = cs.data_ptr(), items.data_ptr(), len(sfa), sfa.ctypes.data
+    fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(W), 0.0, float(H)
+    tb = G.DeviceMapPointTable()
+    tb.m = M
+    for k in dtab:
+        setattr(tb, k, dtab[k].data_ptr())
+    k2m = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+    log_sf = float(np.log(np.float32(sfa[1])))
+    cam = G.make_camera(float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), W, H)
+    camv = (float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf))
+
+    def extract_glue():
+        g1.extract_batch_device(img.data_ptr(), 1, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), s)
+        G.frame_glue_batch_device(1, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), W, W * H, cam, None,
+                                  ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s, device_id)
+
+    def search():
+        G.search_local_points_device(fv, tb, Tcw, *camv, log_sf, 3.0, 0.8, k2m.data_ptr(), counts.data_ptr(), None,
+                                     stream=s, device_id=device_id)
+
+    def timed(fn, pre=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for _ in range(reps):
+            if pre:
+                pre()
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / reps
+
+    extract_glue()
+    k2m.fill_(-1)
+    search()
+    torch.cuda.synchronize()
+    n_match, n_view = int(counts[0]), int(counts[1])
+    N = int(nout[0])
+    ms_search = timed(search, pre=lambda: k2m.fill_(-1))
+    ms_extract = timed(extract_glue)
+    ms_chain = timed(lambda: (extract_glue(), search()), pre=lambda: k2m.fill_(-1))
+    sweeps, rewalked = G.projection_last_sweeps()
+    # M2 reads M*60 + N*48 + the grid (20 292 B), writes (M + N)*4
+    alg_m2 = M * 60 + N * 48 + 20292 + (M + N) * 4
+    px = [1228800, 853600, 592963, 411996, 285671, 198404, 138138, 95676]
+    alg_ext = sum(px[:-1]) + sum(px[1:]) + sum(px) + 2 * sum(px) + N * 1321  # 8d: 20 343 764 B at N = 2000
+    ach = alg_m2 / (ms_search * 1e-3) / 1e9
+    return {"workload": "C3: synthetic 1280x960, 2000 features, extract + isInFrustum + SearchByProjection(th=3) of %d "
+                        "local map points (%d in view), device resident, one frame at a time" % (M, n_view),
+            "keypoints": N, "map_points": M, "matches": n_match, "claim_sweeps": sweeps, "rewalked_rows": rewalked,
+            "search_ms": ms_search, "extract_glue_ms": ms_extract, "extract_glue_search_ms": ms_chain,
+            "frames_per_s": 1e3 / ms_chain,
+            "roofline": {"bound": "hbm", "kernel": "k_frustum_queries + k_proj_lists + k_proj_resolve", "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": alg_m2, "ms_per_launch": ms_search,
+                         "note": "one 10 k-point query set per call: gather-latency / launch bound, not a stream"},
+            "extract_roofline": {"bound": "hbm", "achieved": alg_ext / (ms_extract * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": alg_ext / (ms_extract * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "algorithmic_bytes": alg_ext, "note": "single frame: 16 dependent launches"}}
+
+
+def c4(nkf=24, device_id=0, leaf=0.01):
+    """C4: 640x480 key frames: extract + BF match against the previous key frame + dense-map insert (stride-3
+    back-projection, transform, voxel filter of map + new points at 0.01 m), images resident in HBM."""
+    import torch
+    W, H, NF = 640, 480, 1000
+    dev = "cuda:%d" % device_id
+    st = Stream(W, H, 1234)
+    frames = [st.frame(7 * i) for i in range(nkf)]
+    poses = [rigid(0.004 * i, -0.006 * i, 0.002 * i, (0.04 * i, 0.01 * i, 0.015 * i)) for i in range(nkf)]
+    cam = (float(st.fx), float(st.fy), float(st.cx), float(st.cy))
+    gray = torch.from_numpy(np.stack([f[0] for f in frames])).to(dev)
+    rgb = torch.from_numpy(np.stack([f[1] for f in frames])).to(dev)
+    depth = torch.from_numpy(np.stack([f[2] for f in frames])).to(dev)
+    n_new = [int(np.count_nonzero(~((f[2][::3, ::3].astype(np.float64) < 0.01) | (f[2][::3, ::3] > 10)))) for f in frames]
+    ext = G.ORBextractor(NF, max_batch=1, device_id=device_id)
+    cap = ext.max_keypoints(W, H)
+    matcher = G.BatchMatcher(1, cap, device_id=device_id)
+    kps = torch.zeros((2, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+    nout = torch.zeros(2, dtype=torch.int32, device=dev)
+    mb = torch.zeros((1, cap), dtype=torch.int32, device=dev)
+    nm = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+    KP, DS = cap * 28, cap * 32
+    cloud = G.PointCloudMapping(leaf, device_id)
+    cloud.set_profiling(True)
+    rows = []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i in range(nkf):
+        cur, prv = i & 1, (i & 1) ^ 1
+        k_before = cloud.size()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        ext.extract_batch_device(gray[i].data_ptr(), 1, W, H, W, W * H, kps.data_ptr() + cur * KP,
+                                 desc.data_ptr() + cur * DS, cap, nout.data_ptr() + 4 * cur, s)
+        matcher.match(1, cap, desc.data_ptr() + prv * DS, kps.data_ptr() + prv * KP + 12, None, nout.data_ptr() + 4 * prv,
+                      desc.data_ptr() + cur * DS, kps.data_ptr() + cur * KP + 12, nout.data_ptr() + 4 * cur, 28, 50, 0.7,
+                      True, mb.data_ptr(), nm.data_ptr(), s)
+        e1.record(stream)
+        cloud.insertKeyFrameDevice(depth[i].data_ptr(), W, rgb[i].data_ptr(), W * 3, W, H, *cam, poses[i])
+        e1.synchronize()
+        wall = (time.perf_counter() - t0) * 1e3
+        ins = cloud.last_insert_ms()
+        v = cloud.size()
+        alg = ((H + 2) // 3) * W * (4 + 3) + n_new[i] * 16 + k_before * 16 + v * 16  # 8d: P1 + P3
+        rows.append({"map_before": k_before, "new_points": n_new[i], "map_after": v, "insert_ms": ins,
+                     "extract_match_ms": e0.elapsed_time(e1), "wall_ms": wall, "path": cloud.last_path(),
+                     "algorithmic_bytes": alg})
+    cloud.close()
+    steady = rows[nkf // 2:]
+    ins_ms = float(np.mean([r["insert_ms"] for r in steady]))
+    alg = float(np.mean([r["algorithmic_bytes"] for r in steady]))
+    ach = alg / (ins_ms * 1e-3) / 1e9
+    last = rows[-1]
+    return {"workload": "C4: 640x480 key frames, extract + BF match vs previous key frame + dense-map insert (stride-3 "
+                        "back-projection, SE3 transform, voxel filter of map + new at %.3g m), %d key frames, device "
+                        "resident" % (leaf, nkf),
+            "keyframes": nkf, "final_map_points": last["map_after"], "paths": sorted(set(r["path"] for r in rows)),
+            "insert_ms_first": rows[0]["insert_ms"], "insert_ms_last": last["insert_ms"], "insert_ms_mean_2nd_half": ins_ms,
+            "extract_match_ms_mean": float(np.mean([r["extract_match_ms"] for r in steady])),
+            "keyframe_wall_ms_mean": float(np.mean([r["wall_ms"] for r in steady])),
+            "keyframes_per_s": 1e3 / float(np.mean([r["wall_ms"] for r in steady])),
+            "roofline": {"bound": "hbm", "kernel": "k_bp + k_vox_keys + 4 k_sort_pass + k_merge_new + k_merge_old",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": alg, "ms_per_launch": ins_ms,
+                         "note": "8 dependent launches per key frame over <= 34 k new points + one pass over the map"},
+            "per_keyframe": rows}
