@@ -289,6 +289,30 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
                                       int32_t *d_kp_to_mp, int32_t *d_counts, const orbgpu_track_scratch *d_track,
                                       int32_t device_id, void *hip_stream);
 
+/* Device-resident ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
+ * (ORBmatcher.cc:1328-1470; Tracking::TrackWithMotionModel, Tracking.cc:1169/1175): the per-frame matcher of
+ * RGB-D tracking.  cur = the frame that never left the device; last = the previous frame's key points (octave and
+ * angle are read from the records) plus, per key point, what Tracking keeps of its map point.  Both poses are HOST
+ * 4x4 row-major floats; nothing else crosses PCIe.  The projection (:1360-1376), the level window by direction of
+ * motion (:1339-1349, :1385-1390), the greedy claims, TH_HIGH and the rotation histogram are the reference's.
+ * d_kp_to_mp [cur->cap] in/out: -1 free, -2 held by a map point outside `last`, >= 0 row of `last`.
+ * d_counts [2]: [0] = nmatches, [1] = rows whose octave fell outside [0, nlevels) (left unmatched). */
+typedef struct orbgpu_device_lastframe_view { /* device pointers unless noted */
+    int32_t cap;                 /* rows (upper bound of *n) */
+    const int32_t *n;            /* LastFrame.N */
+    const orbgpu_keypoint *kps;  /* [cap] LastFrame.mvKeys (octave, angle) */
+    const uint8_t *has_mp;       /* [cap] LastFrame.mvpMapPoints[i] != NULL */
+    const uint8_t *outlier;      /* [cap] or NULL: LastFrame.mvbOutlier[i] */
+    const uint8_t *obs_pos;      /* [cap] or NULL (= all 1): Observations() > 0 */
+    const float *world_pos;      /* [cap][3] GetWorldPos() */
+    const uint8_t *desc;         /* [cap][32] GetDescriptor() of the map point */
+} orbgpu_device_lastframe_view;
+int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur, const float *cur_Tcw,
+                                            const orbgpu_device_lastframe_view *last, const float *last_Tcw, float fx,
+                                            float fy, float cx, float cy, float mbf, float mb, float th, int32_t mono,
+                                            int32_t check_orientation, int32_t *d_kp_to_mp, int32_t *d_counts,
+                                            int32_t device_id, void *hip_stream);
+
 /* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
  * vector<MapPoint*>& vpMatched, int th) (ORBmatcher.cc:290-403; loop closing, LoopClosing.cc:397).
  * kf: the key frame as a frame view (mvKeysUn, mDescriptors, mGrid; u_right is not read).  Scw: HOST 4x4 row-major

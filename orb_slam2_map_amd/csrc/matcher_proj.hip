@@ -354,6 +354,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
                                                        const int *__restrict__ claim_init,
                                                        const uint32_t *__restrict__ lists, int *__restrict__ match,
                                                        int *__restrict__ slow, const float *__restrict__ row_angle,
+                                                       int row_angle_stride,
                                                        const float *__restrict__ kp_angle, int check_orientation,
                                                        int *__restrict__ kp_to_mp, int *__restrict__ nmatches,
                                                        int *__restrict__ sweeps_out)
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
         cnt++;
         atomicMax(&last_claim[j], i);
         if (check_orientation)
-            atomicAdd(&histo[rot_bin(row_angle[i], kp_angle[j * kp_angle_stride])], 1);
+            atomicAdd(&histo[rot_bin(row_angle[(size_t)i * row_angle_stride], kp_angle[j * kp_angle_stride])], 1);
     }
     __syncthreads();
     for (int j = tid; j < n; j += nt)
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
             const int j = match[i];
             if (j < 0)
                 continue;
-            const int b = rot_bin(row_angle[i], kp_angle[j * kp_angle_stride]);
+            const int b = rot_bin(row_angle[(size_t)i * row_angle_stride], kp_angle[j * kp_angle_stride]);
             if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) {
                 kp_to_mp[j] = -1;
                 cnt--;
@@ -679,7 +680,7 @@ static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vecto
                        ws.row_desc.as<uint8_t>(), F, ws.topk.as<uint32_t>());
     hipLaunchKernelGGL(k_proj_resolve<MODE>, dim3(1), dim3(1024), (size_t)8 * n, st, m, ws.queries.as<Query>(),
                        ws.row_desc.as<uint8_t>(), F, nnratio, th_dist, ws.claim_init.as<int>(), ws.topk.as<uint32_t>(),
-                       ws.match.as<int>(), ws.slow.as<int>(), ws.row_angle.as<float>(), ws.kp_angle.as<float>(),
+                       ws.match.as<int>(), ws.slow.as<int>(), ws.row_angle.as<float>(), 1, ws.kp_angle.as<float>(),
                        check_orientation, ws.k2m.as<int>(), ws.out.as<int>(), ws.out.as<int>() + 1);
     ORBGPU_HIP_TRY(hipGetLastError());
     ORBGPU_HIP_TRY(hipMemcpyAsync(kp_to_mp, ws.k2m.p, sizeof(int) * n, hipMemcpyDeviceToHost, st));
@@ -814,6 +815,80 @@ __global__ __launch_bounds__(256) void k_frustum_queries(int m, const float *__r
         if (out.view_cos)
             out.view_cos[i] = view_cos;
     }
+}
+
+// ---- device-resident ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (:1328-1470) --------
+struct LastParams {
+    float T[12];  // rows of the current [Rcw | tcw]
+    float fx, fy, cx, cy, mbf;
+    float min_x, max_x, min_y, max_y;
+    float th;
+    int forward, backward;  // :1348-1349
+    int nlevels;
+    float scale_factors[ORBGPU_MAX_LEVELS];
+};
+
+// Thread i < rows: the query of last-frame key point i (:1353-1397): its map point projected with the current
+// pose, window th * scale[octave of the last key point], level window by the direction of motion.  Same float
+// conventions as the host entry point (products summed left to right, no contraction; invzc = 1.0 / z in double).
+// Thread j < cap: claim table entry of current key point j from the incoming association.
+__global__ __launch_bounds__(256) void k_project_last_queries(int rows, const int *__restrict__ n_last,
+                                                              const orbgpu_keypoint *__restrict__ last_kps,
+                                                              const uint8_t *__restrict__ has_mp,
+                                                              const uint8_t *__restrict__ outlier,
+                                                              const uint8_t *__restrict__ obs_pos,
+                                                              const float *__restrict__ world_pos, LastParams P,
+                                                              Query *__restrict__ q, int cap,
+                                                              const int *__restrict__ kp_to_mp,
+                                                              int *__restrict__ claim_init, int *__restrict__ bad_levels)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        const int v = kp_to_mp[i];
+        const bool held = v == -2 || (v >= 0 && v < rows && (obs_pos ? obs_pos[v] != 0 : true));
+        claim_init[i] = held ? -1 : INT_MAX;
+    }
+    if (i >= rows)
+        return;
+    Query Q{};
+    Q.blocking = obs_pos ? (obs_pos[i] != 0) : 1;
+    const int nl = min(max(*n_last, 0), rows);
+    if (i < nl && has_mp[i] && !(outlier && outlier[i])) {
+        const float X = world_pos[3 * i], Y = world_pos[3 * i + 1], Z = world_pos[3 * i + 2];
+        float xc[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            xc[r] = ((P.T[4 * r] * X + P.T[4 * r + 1] * Y) + P.T[4 * r + 2] * Z) + P.T[4 * r + 3];
+        const float invzc = (float)(1.0 / (double)xc[2]);
+        if (!(invzc < 0)) {
+            const float u = P.fx * xc[0] * invzc + P.cx;
+            const float v = P.fy * xc[1] * invzc + P.cy;
+            if (!(u < P.min_x || u > P.max_x) && !(v < P.min_y || v > P.max_y)) {
+                const int oct = last_kps[i].octave;
+                if (oct < 0 || oct >= P.nlevels) {
+                    atomicAdd(bad_levels, 1);  // the reference reads mvScaleFactors out of range here
+                } else {
+                    Q.r = P.th * P.scale_factors[oct];
+                    Q.x = u;
+                    Q.y = v;
+                    Q.ur = u - P.mbf * invzc;
+                    if (P.forward) {
+                        Q.min_level = oct;
+                        Q.max_level = -1;
+                    } else if (P.backward) {
+                        Q.min_level = 0;
+                        Q.max_level = oct;
+                    } else {
+                        Q.min_level = oct - 1;
+                        Q.max_level = oct + 1;
+                    }
+                    Q.check_ur = 1;
+                    Q.active = 1;
+                }
+            }
+        }
+    }
+    q[i] = Q;
 }
 
 } // namespace orbgpu
@@ -979,8 +1054,92 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
                        ws->topk.as<uint32_t>());
     hipLaunchKernelGGL(k_proj_resolve<0>, dim3(1), dim3(1024), (size_t)8 * cap, st, m, ws->queries.as<Query>(), mp->desc,
                        F, nnratio, (int)ORBGPU_TH_HIGH, ws->claim_init.as<int>(), ws->topk.as<uint32_t>(),
-                       ws->match.as<int>(), ws->slow.as<int>(), (const float *)nullptr, (const float *)nullptr, 0,
+                       ws->match.as<int>(), ws->slow.as<int>(), (const float *)nullptr, 1, (const float *)nullptr, 0,
                        d_kp_to_mp, d_counts, ws->out.as<int>() + 1);
+    ORBGPU_HIP_TRY(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur, const float *cur_Tcw,
+                                            const orbgpu_device_lastframe_view *last, const float *last_Tcw, float fx,
+                                            float fy, float cx, float cy, float mbf, float mb, float th, int32_t mono,
+                                            int32_t check_orientation, int32_t *d_kp_to_mp, int32_t *d_counts,
+                                            int32_t device_id, void *hip_stream)
+{
+    ORBGPU_REQUIRE(cur && last && cur_Tcw && last_Tcw && d_kp_to_mp && d_counts, "null argument");
+    ORBGPU_REQUIRE(cur->cap >= 1 && cur->cap <= 16384, "frame capacity out of range (max 16384)");
+    ORBGPU_REQUIRE(cur->n && cur->kps && cur->desc && cur->u_right && cur->cell_start && cur->cell_items, "null frame arrays");
+    ORBGPU_REQUIRE(cur->nlevels >= 1 && cur->nlevels <= ORBGPU_MAX_LEVELS && cur->scale_factors, "bad scale factors");
+    ORBGPU_REQUIRE(cur->max_x > cur->min_x && cur->max_y > cur->min_y, "empty image bounds");
+    ORBGPU_REQUIRE(last->cap >= 0 && last->cap <= 16384, "last-frame capacity out of range (max 16384)");
+    if (last->cap > 0)
+        ORBGPU_REQUIRE(last->n && last->kps && last->has_mp && last->world_pos && last->desc, "null last-frame arrays");
+    int rc = select_device(device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    ORBGPU_HIP_TRY(hipMemsetAsync(d_counts, 0, 2 * sizeof(int32_t), st));
+    if (last->cap == 0)
+        return ORBGPU_OK;
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    const int m = last->cap, cap = cur->cap;
+    PJ_TRY(ws->queries.reserve(sizeof(Query) * (size_t)m));
+    PJ_TRY(ws->claim_init.reserve(sizeof(int) * (size_t)cap));
+    PJ_TRY(ws->topk.reserve(sizeof(uint32_t) * PJ_LIST * (size_t)m));
+    PJ_TRY(ws->match.reserve(sizeof(int) * (size_t)m));
+    PJ_TRY(ws->slow.reserve(sizeof(int) * (size_t)m));
+    PJ_TRY(ws->out.reserve(4 * sizeof(int)));
+    // :1339-1349 forward / backward motion from the two poses (host: 2 x 12 floats)
+    float twc[3], tlc[3];
+    minus_rt_t(cur_Tcw, twc);
+    rt_apply(last_Tcw, twc, tlc);
+    LastParams P;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++)
+            P.T[4 * r + c] = cur_Tcw[4 * r + c];
+    P.fx = fx, P.fy = fy, P.cx = cx, P.cy = cy, P.mbf = mbf;
+    P.min_x = cur->min_x, P.max_x = cur->max_x, P.min_y = cur->min_y, P.max_y = cur->max_y;
+    P.th = th;
+    P.forward = (tlc[2] > mb && !mono) ? 1 : 0;
+    P.backward = (-tlc[2] > mb && !mono) ? 1 : 0;
+    P.nlevels = cur->nlevels;
+    for (int l = 0; l < ORBGPU_MAX_LEVELS; l++)
+        P.scale_factors[l] = l < cur->nlevels ? cur->scale_factors[l] : 0.f;
+    FrameDev F;
+    F.n = cap;
+    F.n_dev = cur->n;
+    F.kp_stride = (int)(sizeof(orbgpu_keypoint) / sizeof(float));
+    F.kp_x = reinterpret_cast<const float *>(cur->kps);
+    F.kp_y = F.kp_x + 1;
+    F.kp_octave = reinterpret_cast<const int *>(cur->kps) + 5;
+    F.u_right = cur->u_right;
+    F.desc = cur->desc;
+    F.min_x = cur->min_x;
+    F.min_y = cur->min_y;
+    F.inv_w = (float)GC / (cur->max_x - cur->min_x);  // Frame.cc:155-156
+    F.inv_h = (float)GR / (cur->max_y - cur->min_y);
+    F.cell_start = cur->cell_start;
+    F.cell_items = cur->cell_items;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+        attr_set = true;
+    }
+    const int cover = std::max(m, cap);
+    const int kstride = (int)(sizeof(orbgpu_keypoint) / sizeof(float));
+    hipLaunchKernelGGL(k_project_last_queries, dim3((cover + 255) / 256), dim3(256), 0, st, m, last->n, last->kps,
+                       last->has_mp, last->outlier, last->obs_pos, last->world_pos, P, ws->queries.as<Query>(), cap,
+                       d_kp_to_mp, ws->claim_init.as<int>(), d_counts + 1);
+    hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws->queries.as<Query>(), last->desc, F,
+                       ws->topk.as<uint32_t>());
+    hipLaunchKernelGGL(k_proj_resolve<1>, dim3(1), dim3(1024), (size_t)8 * cap, st, m, ws->queries.as<Query>(),
+                       last->desc, F, 0.f, (int)ORBGPU_TH_HIGH, ws->claim_init.as<int>(), ws->topk.as<uint32_t>(),
+                       ws->match.as<int>(), ws->slow.as<int>(), reinterpret_cast<const float *>(last->kps) + 3, kstride,
+                       reinterpret_cast<const float *>(cur->kps) + 3, check_orientation ? 1 : 0, d_kp_to_mp, d_counts,
+                       ws->out.as<int>() + 1);
     ORBGPU_HIP_TRY(hipGetLastError());
     return ORBGPU_OK;
 }

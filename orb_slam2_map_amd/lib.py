@@ -75,6 +75,11 @@ class DeviceMapPointTable(C.Structure):
                 ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("skip", C.c_void_p), ("obs_pos", C.c_void_p)]
 
 
+class DeviceLastFrameView(C.Structure):
+    _fields_ = [("cap", C.c_int32), ("n", C.c_void_p), ("kps", C.c_void_p), ("has_mp", C.c_void_p),
+                ("outlier", C.c_void_p), ("obs_pos", C.c_void_p), ("world_pos", C.c_void_p), ("desc", C.c_void_p)]
+
+
 class TrackScratch(C.Structure):
     _fields_ = [("in_view", C.c_void_p), ("proj_x", C.c_void_p), ("proj_y", C.c_void_p), ("proj_xr", C.c_void_p),
                 ("view_cos", C.c_void_p), ("level", C.c_void_p)]
@@ -105,7 +110,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
-    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
+    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_search_by_projection_last_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_insert_device",
     "orbgpu_cloud_last_path", "orbgpu_cloud_set_profiling", "orbgpu_cloud_last_insert_ms", "orbgpu_cloud_rebuild",
@@ -374,6 +379,21 @@ def search_local_points_device(frame_view, table, Tcw, fx, fy, cx, cy, mbf, log_
     check(lib().orbgpu_search_local_points_device(C.byref(frame_view), C.byref(table), _p(T), fx, fy, cx, cy, mbf, log_sf,
                                                   cos_limit, th, nnratio, d_kp_to_mp, d_counts,
                                                   C.byref(track) if track is not None else None, device_id, stream))
+
+
+def search_by_projection_last_device(cur_view, cur_Tcw, last_view, last_Tcw, fx, fy, cx, cy, mbf, mb, th, mono, check_ori,
+                                     d_kp_to_mp, d_counts, stream=0, device_id=0):
+    """TrackWithMotionModel's matcher on device-resident frames (orbgpu_search_by_projection_last_device).
+    cur_view: DeviceFrameView, last_view: DeviceLastFrameView; poses are host 4x4 arrays."""
+    Tc = np.ascontiguousarray(cur_Tcw, np.float32)
+    Tl = np.ascontiguousarray(last_Tcw, np.float32)
+    L = lib()
+    L.orbgpu_search_by_projection_last_device.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+        C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    check(L.orbgpu_search_by_projection_last_device(C.byref(cur_view), _p(Tc), C.byref(last_view), _p(Tl), fx, fy, cx, cy,
+                                                    mbf, mb, th, int(mono), int(check_ori), d_kp_to_mp, d_counts,
+                                                    device_id, stream))
 
 
 def distinctive_descriptors(groups, device_id=0):

@@ -414,3 +414,85 @@ def test_search_by_projection_sim3_loop_closing(gpu, oracle, th, scale, pre):
     assert no > 100, no
     assert ng == no and np.array_equal(kg, ko), "%d vs %d, %d key points differ" % (ng, no, int((kg != ko).sum()))
     assert np.all(kg[k0 != -1] == k0[k0 != -1])  # vpMatched entries that were set stay
+
+
+@pytest.mark.parametrize("th,mono,obs_zero,motion", [(15.0, False, 0.0, "none"), (7.0, False, 0.4, "none"),
+                                                      (15.0, True, 0.0, "none"), (15.0, False, 0.2, "forward"),
+                                                      (30.0, False, 0.2, "backward")])
+def test_search_by_projection_last_frame_device_resident(gpu, oracle, th, mono, obs_zero, motion):
+    """TrackWithMotionModel without leaving the device: two frames extracted on the GPU, the current one glued
+    (mvuRight, grid) on the GPU, the last frame's map-point table resident; only the two poses go up.  Checked
+    against the oracle's SearchByProjection(CurrentFrame, LastFrame, th, bMono) on the same data."""
+    torch = pytest.importorskip("torch")
+    from orb_slam2_map_amd.synth import Stream
+    rng = np.random.default_rng(int(th) + 3 * int(mono) + len(motion))
+    w, h = 640, 480
+    st = Stream(w, h, 1234)
+    fr = [st.frame(30), st.frame(31)]
+    ge = gpu.ORBextractor(1000, max_batch=2)
+    cap = ge.max_keypoints(w, h)
+    s = torch.cuda.current_stream().cuda_stream
+    img = torch.from_numpy(np.stack([f[0] for f in fr])).cuda()
+    depth = torch.from_numpy(np.stack([f[2] for f in fr])).cuda()
+    kps = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda")
+    desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+    nout = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ge.extract_batch_device(img.data_ptr(), 2, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), s)
+    ur = torch.zeros((2, cap), dtype=torch.float32, device="cuda")
+    dz = torch.zeros((2, cap), dtype=torch.float32, device="cuda")
+    cs = torch.zeros((2, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+    items = torch.zeros((2, cap), dtype=torch.int32, device="cuda")
+    cam = gpu.make_camera(float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), w, h)
+    gpu.frame_glue_batch_device(2, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), w, w * h, cam, None,
+                                ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s)
+    torch.cuda.synchronize()
+    n0, n1 = int(nout[0]), int(nout[1])
+    hk = kps.cpu().numpy().view(gpu.KEYPOINT_DTYPE).reshape(2, cap)
+    ks = [hk[0, :n0].copy(), hk[1, :n1].copy()]
+    ds = [desc[0, :n0].cpu().numpy(), desc[1, :n1].cpu().numpy()]
+    sf = np.asarray(ge.GetScaleFactors(), np.float32)
+    Tcw = scenario.rigid()
+    ocur = scenario.make_frame(oracle, ks[1], ds[1], fr[1][2], st, sf)
+    (px, py), (ox, oy) = st.offset(30), st.offset(31)
+    P, _ = scenario.world_points_from_prev(ks[0], fr[0][2], (ox - px, oy - py), st, Tcw, rng)
+    Tlast = Tcw.copy()
+    if motion == "forward":
+        Tlast[2, 3] += 0.5
+    elif motion == "backward":
+        Tlast[2, 3] -= 0.5
+    last = {"has_mp": (rng.random(n0) < 0.8).astype(np.uint8), "outlier": (rng.random(n0) < 0.05).astype(np.uint8),
+            "obs_pos": (rng.random(n0) >= obs_zero).astype(np.uint8), "world_pos": P, "desc": ds[0],
+            "kp_octave": ks[0]["octave"], "kp_angle": ks[0]["angle"], "Tcw": Tlast}
+    fx, fy, cx, cy, bf = (float(v) for v in (st.fx, st.fy, st.cx, st.cy, st.bf))
+    mb = bf / fx
+    k0 = np.full(n1, -1, np.int32)
+    pre = rng.choice(n1, 60, replace=False)
+    k0[pre[:30]] = rng.integers(0, n0, 30)
+    k0[pre[30:]] = -2
+    no, ko = oracle.search_by_projection_last(ocur, Tcw, fx, fy, cx, cy, bf, mb, last, th, mono, True, k0)
+    assert no > 100, no
+
+    def padded(a, shape, dtype):
+        out = np.zeros(shape, dtype)
+        out[:len(a)] = a
+        return torch.from_numpy(out).cuda()
+    d_has, d_out, d_obs = (padded(last[k], cap, np.uint8) for k in ("has_mp", "outlier", "obs_pos"))
+    d_wp = padded(P, (cap, 3), np.float32)
+    fv = gpu.DeviceFrameView()
+    fv.cap, fv.n, fv.kps, fv.desc = cap, nout.data_ptr() + 4, kps.data_ptr() + cap * 28, desc.data_ptr() + cap * 32
+    fv.u_right, fv.cell_start, fv.cell_items = ur.data_ptr() + cap * 4, cs.data_ptr() + (64 * 48 + 1) * 4, items.data_ptr() + cap * 4
+    fv.nlevels, fv.scale_factors = len(sf), sf.ctypes.data
+    fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(w), 0.0, float(h)
+    lv = gpu.DeviceLastFrameView()
+    lv.cap, lv.n, lv.kps, lv.desc = cap, nout.data_ptr(), kps.data_ptr(), desc.data_ptr()  # the key points' own descriptors
+    lv.has_mp, lv.outlier, lv.obs_pos, lv.world_pos = d_has.data_ptr(), d_out.data_ptr(), d_obs.data_ptr(), d_wp.data_ptr()
+    k2m = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+    k2m[:n1] = torch.from_numpy(k0).cuda()
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    gpu.search_by_projection_last_device(fv, Tcw, lv, Tlast, fx, fy, cx, cy, bf, mb, th, mono, True, k2m.data_ptr(),
+                                         counts.data_ptr(), stream=s)
+    torch.cuda.synchronize()
+    c = counts.cpu().numpy()
+    got = k2m.cpu().numpy()[:n1]
+    assert c[1] == 0
+    assert c[0] == no and np.array_equal(got, ko), "%d vs %d, %d differ" % (c[0], no, int((got != ko).sum()))
