@@ -403,6 +403,57 @@ int orbgpu_search_by_projection_keyframe(const orbgpu_frame_view *cur, const flo
                                          int32_t device_id);
 
 /* ======================================================================================
+ * Vocabulary tree (DBoW2, vendored in the reference): Frame::ComputeBoW (src/Frame.cc:395-402) and the node-wise
+ * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:159-288).
+ * ====================================================================================== */
+typedef struct orbgpu_vocabulary orbgpu_vocabulary;
+
+/* The tree as TemplatedVocabulary::loadFromTextFile builds it (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1348-1437):
+ * node 0 is the root, node i > 0 has parent[i] < i (file order), children of a node are visited in ascending id,
+ * leaves are numbered in node order (= word ids).  desc [n_nodes][32], weight [n_nodes] (Node::weight, doubles);
+ * weighting 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring 0 L1_NORM .. 5 DOT_PRODUCT (BowVector.h:30-54).
+ * The binary / text vocabulary FILE readers stay host code of the caller (the reference's own loader can fill
+ * these arrays from m_nodes). */
+int orbgpu_vocabulary_create(int32_t k, int32_t L, int32_t n_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                             const uint8_t *desc, const double *weight, int32_t weighting, int32_t scoring,
+                             int32_t device_id, orbgpu_vocabulary **out);
+int orbgpu_vocabulary_destroy(orbgpu_vocabulary *v);
+int orbgpu_vocabulary_size(const orbgpu_vocabulary *v, int32_t *n_words);
+
+/* TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (:1140-1207): per feature the
+ * word id, the word's weight and the id of the node `levelsup` levels above the word (:1231-1274; -1 if the word
+ * is stopped, i.e. weight <= 0: such a feature enters neither vector); the BowVector as n_bow ascending
+ * (bow_ids, bow_vals) pairs, weighted / normalised as the vocabulary's weighting and scoring types prescribe; the
+ * FeatureVector as CSR: node fv_nodes[t] (ascending) holds features fv_items[fv_start[t] .. fv_start[t+1]) in
+ * ascending feature index.  Capacities: n for every array, n + 1 for fv_start.  bow_* / fv_* may be NULL. */
+int orbgpu_bow_transform(orbgpu_vocabulary *v, const uint8_t *desc, int32_t n, int32_t levelsup, int32_t *word_id,
+                         double *word_weight, int32_t *node_id, int32_t *bow_ids, double *bow_vals, int32_t *n_bow,
+                         int32_t *fv_nodes, int32_t *fv_start, int32_t *fv_items, int32_t *n_fv);
+/* Device-resident: descriptors [batch][cap][32] straight out of the extractor, counts d_n [batch]; outputs
+ * [batch][cap].  Asynchronous on hip_stream. */
+int orbgpu_bow_transform_batch_device(orbgpu_vocabulary *v, const uint8_t *d_desc, int32_t batch, int32_t cap,
+                                      const int32_t *d_n, int32_t levelsup, int32_t *d_word_id, double *d_word_weight,
+                                      int32_t *d_node_id, void *hip_stream);
+
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches) (ORBmatcher.cc:159-288):
+ * key-frame feature i (valid_kf[i]: has a map point that is not bad) is compared with the frame features under the
+ * same vocabulary node (node_kf / node_f: orbgpu_bow_transform's node_id, -1 = not in the feature vector), greedy
+ * claims in the reference's visiting order, TH_LOW / ratio test, rotation histogram.  match_f[j] = key-frame
+ * feature whose map point frame feature j received, or -1; *nmatches = the return value. */
+int orbgpu_search_by_bow(const uint8_t *desc_kf, const float *angle_kf, const uint8_t *valid_kf,
+                         const int32_t *node_kf, int32_t n_kf, const uint8_t *desc_f, const float *angle_f,
+                         const int32_t *node_f, int32_t n_f, int32_t th_low, float nnratio, int32_t check_orientation,
+                         int32_t *match_f, int32_t *nmatches, int32_t device_id);
+/* The same for `pairs` independent (key frame, frame) pairs resident on the device; arguments as
+ * orbgpu_match_bf_batch_device plus the node arrays [pairs][cap]. */
+int orbgpu_search_by_bow_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, const uint8_t *d_desc_a,
+                                      const void *d_angle_a, const uint8_t *d_valid_a, const int32_t *d_node_a,
+                                      const int32_t *d_na, const uint8_t *d_desc_b, const void *d_angle_b,
+                                      const int32_t *d_node_b, const int32_t *d_nb, size_t angle_stride, int32_t th_low,
+                                      float nnratio, int32_t check_orientation, int32_t *d_match_b,
+                                      int32_t *d_nmatches, void *hip_stream);
+
+/* ======================================================================================
  * PointCloudMapping  (reference include/PointCloudMap.h:41-88, src/PointCloudMap.cc)
  * ====================================================================================== */
 

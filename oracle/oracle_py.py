@@ -112,6 +112,12 @@ def lib(path=None):
     L.ora_pose_inverse.argtypes = [vp, vp, vp]
     L.ora_transform_points.argtypes = [vp, ci, vp, vp, vp]
     L.ora_voxel_filter.argtypes = [vp, ci, cf, vp, vp]
+    L.ora_vocabulary_create.restype = vp
+    L.ora_vocabulary_create.argtypes = [ci, ci, ci, vp, vp, vp, vp, ci, ci]
+    L.ora_vocabulary_destroy.argtypes = [vp]
+    L.ora_vocabulary_words.argtypes = [vp]
+    L.ora_bow_transform.argtypes = [vp, vp, ci, ci] + [vp] * 10
+    L.ora_search_by_bow.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp, ci, cf, ci, vp]
     if path is None:
         _LIB = L
     return L
@@ -472,3 +478,56 @@ def voxel_filter(pts, leaf):
     ov = C.c_int(0)
     n = lib().ora_voxel_filter(_p(pts), len(pts), leaf, _p(out), C.byref(ov))
     return out[:n].copy(), bool(ov.value)
+
+
+class Vocabulary:
+    """Oracle vocabulary tree (DBoW2 TemplatedVocabulary, TemplatedVocabulary.h)."""
+
+    def __init__(self, k, L, parent, is_leaf, desc, weight, weighting=0, scoring=0):
+        self.lib = lib()
+        self.parent = np.ascontiguousarray(parent, np.int32)
+        self.is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.weight = np.ascontiguousarray(weight, np.float64)
+        self.h = self.lib.ora_vocabulary_create(k, L, len(self.parent), _p(self.parent), _p(self.is_leaf), _p(self.desc),
+                                                _p(self.weight), weighting, scoring)
+        if not self.h:
+            raise ValueError("bad vocabulary")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ora_vocabulary_destroy(self.h)
+            self.h = None
+
+    def size(self):
+        return self.lib.ora_vocabulary_words(self.h)
+
+    def transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        wid, nid = np.zeros(m, np.int32), np.zeros(m, np.int32)
+        wgt = np.zeros(m, np.float64)
+        bid, bval = np.zeros(m, np.int32), np.zeros(m, np.float64)
+        fvn, fvs, fvi = np.zeros(m, np.int32), np.zeros(m + 1, np.int32), np.zeros(m, np.int32)
+        nb, nf = C.c_int(), C.c_int()
+        self.lib.ora_bow_transform(self.h, _p(desc), n, levelsup, _p(wid), _p(wgt), _p(nid), _p(bid), _p(bval),
+                                   C.byref(nb), _p(fvn), _p(fvs), _p(fvi), C.byref(nf))
+        return {"word_id": wid[:n], "weight": wgt[:n], "node_id": nid[:n], "bow_ids": bid[:nb.value],
+                "bow_vals": bval[:nb.value], "fv_nodes": fvn[:nf.value], "fv_start": fvs[:nf.value + 1],
+                "fv_items": fvi[:fvs[nf.value]]}
+
+
+def search_by_bow(desc_kf, angle_kf, valid_kf, fv_kf, desc_f, angle_f, fv_f, th_low=50, nnratio=0.7, check_ori=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...); fv_*: dicts from Vocabulary.transform."""
+    desc_kf = np.ascontiguousarray(desc_kf, np.uint8).reshape(-1, 32)
+    desc_f = np.ascontiguousarray(desc_f, np.uint8).reshape(-1, 32)
+    akf, af = np.ascontiguousarray(angle_kf, np.float32), np.ascontiguousarray(angle_f, np.float32)
+    va = None if valid_kf is None else np.ascontiguousarray(valid_kf, np.uint8)
+    out = np.zeros(max(1, len(desc_f)), np.int32)
+    a = [np.ascontiguousarray(fv_kf[k], np.int32) for k in ("fv_nodes", "fv_start", "fv_items")]
+    b = [np.ascontiguousarray(fv_f[k], np.int32) for k in ("fv_nodes", "fv_start", "fv_items")]
+    n = lib().ora_search_by_bow(_p(desc_kf), _p(akf), _p(va), len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(desc_f), _p(af),
+                                len(desc_f), len(b[0]), _p(b[0]), _p(b[1]), _p(b[2]), th_low, nnratio, int(check_ori),
+                                _p(out))
+    return n, out[:len(desc_f)].copy()

@@ -250,6 +250,30 @@ void ora_transform_points(const ora_point *in, int n, const double R[9], const d
  * int32 the input is returned unfiltered (PCL behaviour) and *overflow is set. */
 int ora_voxel_filter(const ora_point *in, int n, float leaf, ora_point *out, int *overflow);
 
+/* ---- BoW: vocabulary tree transform + node-wise matcher (orb_oracle_bow.c) ----
+ * Nodes in the order TemplatedVocabulary::loadFromTextFile creates them (node 0 = root, a node after its parent);
+ * children of a node in ascending id; leaves numbered in node order = word ids.  weighting: 0 TF_IDF, 1 TF, 2 IDF,
+ * 3 BINARY; scoring: 0 L1_NORM .. 5 DOT_PRODUCT (BowVector.h:30-54). */
+typedef struct ora_vocabulary ora_vocabulary;
+ora_vocabulary *ora_vocabulary_create(int k, int L, int n_nodes, const int32_t *parent, const uint8_t *is_leaf,
+                                      const uint8_t *desc, const double *weight, int weighting, int scoring);
+void ora_vocabulary_destroy(ora_vocabulary *v);
+int ora_vocabulary_words(const ora_vocabulary *v);
+/* TemplatedVocabulary::transform(feature, id, weight, nid, levelsup), TemplatedVocabulary.h:1231-1274 */
+void ora_vocabulary_transform_feature(const ora_vocabulary *v, const uint8_t *feature, int levelsup, int32_t *word_id,
+                                      double *weight, int32_t *nid);
+/* TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup), :1140-1207 (Frame::ComputeBoW,
+ * Frame.cc:395-402 with levelsup 4).  bow_* / fv_items capacity n, fv_nodes n, fv_start n + 1. */
+int ora_bow_transform(const ora_vocabulary *v, const uint8_t *desc, int n, int levelsup, int32_t *word_id,
+                      double *word_weight, int32_t *node_id, int32_t *bow_ids, double *bow_vals, int32_t *n_bow,
+                      int32_t *fv_nodes, int32_t *fv_start, int32_t *fv_items, int32_t *n_fv);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches), ORBmatcher.cc:159-288 */
+int ora_search_by_bow(const uint8_t *desc_kf, const float *angle_kf, const uint8_t *valid_kf, int n_fv_kf,
+                      const int32_t *fv_nodes_kf, const int32_t *fv_start_kf, const int32_t *fv_items_kf,
+                      const uint8_t *desc_f, const float *angle_f, int nf, int n_fv_f, const int32_t *fv_nodes_f,
+                      const int32_t *fv_start_f, const int32_t *fv_items_f, int th_low, float nnratio,
+                      int check_orientation, int32_t *match_f);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,10 +108,14 @@ __device__ __forceinline__ v4i bf_expand16(uint32_t hw)
     return r;
 }
 
+// NODES: the node-wise matcher (SearchByBoW on real feature vectors): a B row is a candidate of an A row only if both
+// sit under the same vocabulary node (node_a / node_b, [pairs][cap], < 0 = not in the feature vector).
+template <bool NODES>
 __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint8_t *__restrict__ desc_a,
                                                  const int *__restrict__ na_p, const uint8_t *__restrict__ desc_b,
                                                  const int *__restrict__ nb_p, uint32_t *__restrict__ topk,
-                                                 int acc_min)
+                                                 int acc_min, const int *__restrict__ node_a,
+                                                 const int *__restrict__ node_b)
 {
     __shared__ __align__(16) uint8_t s_tile[2][BF_TILE_ROWS * BF_TILE_STRIDE];
     const int nsplit = gridDim.z;
@@ -123,6 +127,12 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int i = blockIdx.x * BF_TOPK_ROWS + wave * 32 + r;  // this lane's A row (= accumulator column)
+    int my_node = 0;
+    const int *nodes_b = nullptr;
+    if (NODES) {
+        my_node = node_a[(size_t)pair * cap + min(i, na - 1)];
+        nodes_b = node_b + (size_t)pair * cap;
+    }
     // the A rows of this wave as the MFMA's B operand: fragment s holds k = 32 s + 16 h .. + 15 = halfword 2 s + h
     v4i fa[8];
     {
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
                 if (hit) {
                     const int reg = 15 - (m & 15);
                     const int j = j0 + (reg & 3) + 8 * (reg >> 2);
-                    if (j <= jlast) {
+                    if (j <= jlast && (!NODES || nodes_b[j] == my_node)) {
                         top4_insert(t, (uint32_t)(((256 - (m >> 4)) << 11) + j));  // (2 ham) << 11 = ham << 12
                         if (t[3] != BF_KEY_NONE)
                             lim = max(lim, 256 - 2 * (int)(t[3] >> 12));  // a full list admits distances <= its last
@@ -231,13 +241,16 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
 // B rows; ties resolve to the lower index exactly as the sequential scan does).  Used only when the
 // cached top-K list cannot decide.
 __device__ __forceinline__ void bf_full_scan_wave(const uint64_t *__restrict__ ga, const uint64_t *gb, int i, int nb,
-                                  const int *claim, int &b1, int &i1, int &b2)
+                                  const int *claim, int &b1, int &i1, int &b2, const int *__restrict__ nodes_b,
+                                  int my_node)
 {
     const int lane = threadIdx.x & 63;
     uint64_t a[4] = {ga[(size_t)i * 4], ga[(size_t)i * 4 + 1], ga[(size_t)i * 4 + 2], ga[(size_t)i * 4 + 3]};
     int v1 = 256, vi = INT_MAX, v2 = 256;
     for (int j = lane; j < nb; j += 64) {
         if (claim[j] < i)
+            continue;
+        if (nodes_b && nodes_b[j] != my_node)
             continue;
         uint64_t b[4] = {gb[(size_t)j * 4], gb[(size_t)j * 4 + 1], gb[(size_t)j * 4 + 2], gb[(size_t)j * 4 + 3]};
         const int d = hamming256(a, b);
@@ -290,7 +303,8 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
                                                      const uint8_t *__restrict__ angle_b, size_t angle_stride,
                                                      int check_orientation, int *__restrict__ match_b,
                                                      int *__restrict__ nmatches, int *__restrict__ sweeps_used,
-                                                     int stage_b, int nsplit)
+                                                     int stage_b, int nsplit, const int *__restrict__ node_a,
+                                                     const int *__restrict__ node_b)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int histo[ORBGPU_HISTO_LENGTH];
@@ -307,6 +321,8 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
     const uint64_t *gb = reinterpret_cast<const uint64_t *>(desc_b + (size_t)pair * cap * 32);
     const uint32_t *tk = topk + (size_t)pair * cap * nsplit * BF_TOPK;
     const uint8_t *va = valid_a ? valid_a + (size_t)pair * cap : nullptr;
+    const int *nda = node_a ? node_a + (size_t)pair * cap : nullptr;
+    const int *ndb = node_b ? node_b + (size_t)pair * cap : nullptr;
     int *mb = match_b + (size_t)pair * cap;
 
     for (int j = tid; j < cap; j += nt) {
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
     uint8_t valid0 = 0;
     if (tid < na) {
         bf_load_keys(tk, tid, nsplit, key0);
-        valid0 = (!va || va[tid]) ? 1 : 0;
+        valid0 = ((!va || va[tid]) && (!nda || nda[tid] >= 0)) ? 1 : 0;
     }
     __syncthreads();
     int sweeps = 0;
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
         for (int i = tid; i < na; i += nt) {
             int result = -1;
             bool decided = true;
-            if (i == tid ? valid0 != 0 : (!va || va[i])) {
+            if (i == tid ? valid0 != 0 : ((!va || va[i]) && (!nda || nda[i] >= 0))) {
                 uint32_t key[4] = {key0[0], key0[1], key0[2], key0[3]};
                 if (i != tid)
                     bf_load_keys(tk, i, nsplit, key);
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(1024) void k_bf_resolve(int cap, const uint8_t *__r
             for (int r = wave; r < nslow; r += nw) {
                 const int i = slow[r];
                 int b1, i1, b2;
-                bf_full_scan_wave(ga, scan_b, i, nb, claimA, b1, i1, b2);
+                bf_full_scan_wave(ga, scan_b, i, nb, claimA, b1, i1, b2, ndb, nda ? nda[i] : 0);
                 if ((tid & 63) == 0) {
                     int result = -1;
                     if (b1 <= th_low && (float)b1 < nnratio * (float)b2)
@@ -601,11 +617,11 @@ int orbgpu_matcher_destroy(orbgpu_matcher *m)
     return ORBGPU_OK;
 }
 
-int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, const uint8_t *d_desc_a,
-                                 const void *d_angle_a, const uint8_t *d_valid_a, const int32_t *d_na,
-                                 const uint8_t *d_desc_b, const void *d_angle_b, const int32_t *d_nb,
-                                 size_t angle_stride, int32_t th_low, float nnratio, int32_t check_orientation,
-                                 int32_t *d_match_b, int32_t *d_nmatches, void *hip_stream)
+static int match_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, const uint8_t *d_desc_a,
+                              const void *d_angle_a, const uint8_t *d_valid_a, const int32_t *d_node_a, const int32_t *d_na,
+                              const uint8_t *d_desc_b, const void *d_angle_b, const int32_t *d_node_b, const int32_t *d_nb,
+                              size_t angle_stride, int32_t th_low, float nnratio, int32_t check_orientation,
+                              int32_t *d_match_b, int32_t *d_nmatches, void *hip_stream)
 {
     ORBGPU_REQUIRE(m && d_desc_a && d_desc_b && d_na && d_nb && d_match_b && d_nmatches, "null argument");
     ORBGPU_REQUIRE(pairs >= 1 && pairs <= m->max_pairs && cap >= 1 && cap <= m->cap,
@@ -628,17 +644,44 @@ int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, 
     int dmax = std::min(std::max(th_low, 0), 256);
     while (dmax < 256 && !(nnratio * (float)(dmax + 1) > (float)th_low))
         dmax++;
-    hipLaunchKernelGGL(k_bf_topk, grid, dim3(BF_TOPK_THREADS), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk, 256 - 2 * dmax);
+    if (d_node_a)
+        hipLaunchKernelGGL(k_bf_topk<true>, grid, dim3(BF_TOPK_THREADS), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk,
+                           256 - 2 * dmax, d_node_a, d_node_b);
+    else
+        hipLaunchKernelGGL(k_bf_topk<false>, grid, dim3(BF_TOPK_THREADS), 0, st, cap, d_desc_a, d_na, d_desc_b, d_nb, topk,
+                           256 - 2 * dmax, (const int *)nullptr, (const int *)nullptr);
     // claim / match / queue tables (16 B per row) + the B descriptors (32 B per row) when both fit in LDS
     const int stage_b = (size_t)48 * cap <= BF_RESOLVE_MAX_LDS ? 1 : 0;
     const size_t lds = (size_t)(stage_b ? 48 : 16) * cap;
     hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), lds, st, cap, d_desc_a, d_valid_a, d_na,
                        d_desc_b, d_nb, topk, th_low, nnratio, reinterpret_cast<const uint8_t *>(d_angle_a),
                        reinterpret_cast<const uint8_t *>(d_angle_b), angle_stride, check_orientation, d_match_b,
-                       d_nmatches, m->d_sweeps.as<int>(), stage_b, nsplit);
+                       d_nmatches, m->d_sweeps.as<int>(), stage_b, nsplit, d_node_a, d_node_b);
     ORBGPU_HIP_TRY(hipGetLastError());
     m->last_pairs = pairs;
     return ORBGPU_OK;
+}
+
+int orbgpu_match_bf_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, const uint8_t *d_desc_a,
+                                 const void *d_angle_a, const uint8_t *d_valid_a, const int32_t *d_na,
+                                 const uint8_t *d_desc_b, const void *d_angle_b, const int32_t *d_nb,
+                                 size_t angle_stride, int32_t th_low, float nnratio, int32_t check_orientation,
+                                 int32_t *d_match_b, int32_t *d_nmatches, void *hip_stream)
+{
+    return match_batch_device(m, pairs, cap, d_desc_a, d_angle_a, d_valid_a, nullptr, d_na, d_desc_b, d_angle_b, nullptr,
+                              d_nb, angle_stride, th_low, nnratio, check_orientation, d_match_b, d_nmatches, hip_stream);
+}
+
+int orbgpu_search_by_bow_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, const uint8_t *d_desc_a,
+                                      const void *d_angle_a, const uint8_t *d_valid_a, const int32_t *d_node_a,
+                                      const int32_t *d_na, const uint8_t *d_desc_b, const void *d_angle_b,
+                                      const int32_t *d_node_b, const int32_t *d_nb, size_t angle_stride, int32_t th_low,
+                                      float nnratio, int32_t check_orientation, int32_t *d_match_b,
+                                      int32_t *d_nmatches, void *hip_stream)
+{
+    ORBGPU_REQUIRE(d_node_a && d_node_b, "null node arrays");
+    return match_batch_device(m, pairs, cap, d_desc_a, d_angle_a, d_valid_a, d_node_a, d_na, d_desc_b, d_angle_b, d_node_b,
+                              d_nb, angle_stride, th_low, nnratio, check_orientation, d_match_b, d_nmatches, hip_stream);
 }
 
 int orbgpu_matcher_last_sweeps(orbgpu_matcher *m, int32_t *sweeps)
@@ -653,9 +696,10 @@ int orbgpu_matcher_last_sweeps(orbgpu_matcher *m, int32_t *sweeps)
     return ORBGPU_OK;
 }
 
-int orbgpu_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *valid_a, int32_t na,
-                    const uint8_t *desc_b, const float *angle_b, int32_t nb, int32_t th_low, float nnratio,
-                    int32_t check_orientation, int32_t *match_b, int32_t *nmatches, int32_t device_id)
+static int match_host(const uint8_t *desc_a, const float *angle_a, const uint8_t *valid_a, const int32_t *node_a,
+                      int32_t na, const uint8_t *desc_b, const float *angle_b, const int32_t *node_b, int32_t nb,
+                      int32_t th_low, float nnratio, int32_t check_orientation, int32_t *match_b, int32_t *nmatches,
+                      int32_t device_id)
 {
     ORBGPU_REQUIRE(match_b && nmatches, "null argument");
     ORBGPU_REQUIRE(na >= 0 && nb >= 0 && na <= 4096 && nb <= 4096, "na/nb must be in [0,4096]");
@@ -676,7 +720,7 @@ int orbgpu_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *
         int device = -1, cap = 0;
         orbgpu_matcher *m = nullptr;
         hipStream_t st = nullptr;
-        DevBuf da, db, aa, ab, va, cnt, mb, nm;
+        DevBuf da, db, aa, ab, va, cnt, mb, nm, nda, ndb;
     };
     static thread_local Ws ws;
     int rc = select_device(device_id);
@@ -695,7 +739,8 @@ int orbgpu_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *
         if ((rc = ws.da.reserve((size_t)cap * 32)) != ORBGPU_OK || (rc = ws.db.reserve((size_t)cap * 32)) != ORBGPU_OK ||
             (rc = ws.aa.reserve((size_t)cap * 4)) != ORBGPU_OK || (rc = ws.ab.reserve((size_t)cap * 4)) != ORBGPU_OK ||
             (rc = ws.va.reserve((size_t)cap)) != ORBGPU_OK || (rc = ws.cnt.reserve(8)) != ORBGPU_OK ||
-            (rc = ws.mb.reserve((size_t)cap * 4)) != ORBGPU_OK || (rc = ws.nm.reserve(4)) != ORBGPU_OK)
+            (rc = ws.mb.reserve((size_t)cap * 4)) != ORBGPU_OK || (rc = ws.nm.reserve(4)) != ORBGPU_OK ||
+            (rc = ws.nda.reserve((size_t)cap * 4)) != ORBGPU_OK || (rc = ws.ndb.reserve((size_t)cap * 4)) != ORBGPU_OK)
             return rc;
         ws.device = device_id;
         ws.cap = cap;
@@ -710,17 +755,39 @@ int orbgpu_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *
     }
     if (valid_a)
         ORBGPU_HIP_TRY(hipMemcpyAsync(ws.va.p, valid_a, (size_t)na, hipMemcpyHostToDevice, st));
+    if (node_a) {
+        ORBGPU_HIP_TRY(hipMemcpyAsync(ws.nda.p, node_a, (size_t)na * 4, hipMemcpyHostToDevice, st));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(ws.ndb.p, node_b, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+    }
     const int counts[2] = {na, nb};
     ORBGPU_HIP_TRY(hipMemcpyAsync(ws.cnt.p, counts, 8, hipMemcpyHostToDevice, st));
-    if ((rc = orbgpu_match_bf_batch_device(ws.m, 1, cap, ws.da.as<uint8_t>(), ws.aa.p,
-                                           valid_a ? ws.va.as<uint8_t>() : nullptr, ws.cnt.as<int>(),
-                                           ws.db.as<uint8_t>(), ws.ab.p, ws.cnt.as<int>() + 1, 4, th_low, nnratio,
-                                           check_orientation, ws.mb.as<int>(), ws.nm.as<int>(), st)) != ORBGPU_OK)
+    if ((rc = match_batch_device(ws.m, 1, cap, ws.da.as<uint8_t>(), ws.aa.p, valid_a ? ws.va.as<uint8_t>() : nullptr,
+                                 node_a ? ws.nda.as<int>() : nullptr, ws.cnt.as<int>(), ws.db.as<uint8_t>(), ws.ab.p,
+                                 node_a ? ws.ndb.as<int>() : nullptr, ws.cnt.as<int>() + 1, 4, th_low, nnratio,
+                                 check_orientation, ws.mb.as<int>(), ws.nm.as<int>(), st)) != ORBGPU_OK)
         return rc;
     ORBGPU_HIP_TRY(hipMemcpyAsync(match_b, ws.mb.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipMemcpyAsync(nmatches, ws.nm.p, 4, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipStreamSynchronize(st));
     return ORBGPU_OK;
+}
+
+int orbgpu_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *valid_a, int32_t na,
+                    const uint8_t *desc_b, const float *angle_b, int32_t nb, int32_t th_low, float nnratio,
+                    int32_t check_orientation, int32_t *match_b, int32_t *nmatches, int32_t device_id)
+{
+    return match_host(desc_a, angle_a, valid_a, nullptr, na, desc_b, angle_b, nullptr, nb, th_low, nnratio,
+                      check_orientation, match_b, nmatches, device_id);
+}
+
+int orbgpu_search_by_bow(const uint8_t *desc_kf, const float *angle_kf, const uint8_t *valid_kf,
+                         const int32_t *node_kf, int32_t n_kf, const uint8_t *desc_f, const float *angle_f,
+                         const int32_t *node_f, int32_t n_f, int32_t th_low, float nnratio, int32_t check_orientation,
+                         int32_t *match_f, int32_t *nmatches, int32_t device_id)
+{
+    ORBGPU_REQUIRE((n_kf == 0 || node_kf) && (n_f == 0 || node_f), "null node arrays");
+    return match_host(desc_kf, angle_kf, valid_kf, node_kf, n_kf, desc_f, angle_f, node_f, n_f, th_low, nnratio,
+                      check_orientation, match_f, nmatches, device_id);
 }
 
 int orbgpu_hamming256(const uint8_t *a, const uint8_t *b, int32_t n, int32_t *out, int32_t device_id)

@@ -112,6 +112,8 @@ ABI_SYMBOLS = [
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
     "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_search_by_projection_last_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
+    "orbgpu_vocabulary_create", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_size", "orbgpu_bow_transform",
+    "orbgpu_bow_transform_batch_device", "orbgpu_search_by_bow", "orbgpu_search_by_bow_batch_device",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_insert_device",
     "orbgpu_cloud_last_path", "orbgpu_cloud_set_profiling", "orbgpu_cloud_last_insert_ms", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
@@ -582,6 +584,90 @@ class BatchMatcher:
         out = np.zeros(pairs, np.int32)
         check(self.L.orbgpu_matcher_last_sweeps(self.h, _p(out)))
         return out
+
+
+# --------------------------------------------------------------------------------------------
+# ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, reference include/ORBVocabulary.h)
+# --------------------------------------------------------------------------------------------
+TF_IDF, TF, IDF, BINARY = 0, 1, 2, 3
+L1_NORM, L2_NORM, CHI_SQUARE, KL, BHATTACHARYYA, DOT_PRODUCT = range(6)
+
+
+class ORBVocabulary:
+    """The vocabulary tree on the device.  parent / is_leaf / desc / weight: one row per node in the order
+    TemplatedVocabulary::loadFromTextFile creates them (TemplatedVocabulary.h:1348-1437)."""
+
+    def __init__(self, k, L, parent, is_leaf, desc, weight, weighting=TF_IDF, scoring=L1_NORM, device_id=0):
+        self.L_ = lib()
+        self.parent = np.ascontiguousarray(parent, np.int32)
+        self.is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.weight = np.ascontiguousarray(weight, np.float64)
+        self.k, self.L, self.device_id = k, L, device_id
+        h = C.c_void_p()
+        fn = self.L_.orbgpu_vocabulary_create
+        fn.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                       C.c_int32, C.c_int32, C.c_void_p]
+        check(fn(k, L, len(self.parent), _p(self.parent), _p(self.is_leaf), _p(self.desc), _p(self.weight), weighting,
+                 scoring, device_id, C.byref(h)))
+        self.h = h
+        self.L_.orbgpu_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 10
+        self.L_.orbgpu_bow_transform_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                              C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L_.orbgpu_vocabulary_destroy.argtypes = [C.c_void_p]
+        self.L_.orbgpu_vocabulary_size.argtypes = [C.c_void_p, C.c_void_p]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L_.orbgpu_vocabulary_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def size(self):
+        n = C.c_int32()
+        check(self.L_.orbgpu_vocabulary_size(self.h, C.byref(n)))
+        return n.value
+
+    def transform(self, desc, levelsup=4):
+        """Frame::ComputeBoW: dict with word_id, weight, node_id per feature, bow (ids, values) and the
+        FeatureVector as (nodes, start, items)."""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        m = max(n, 1)
+        wid, nid = np.zeros(m, np.int32), np.zeros(m, np.int32)
+        wgt = np.zeros(m, np.float64)
+        bid, bval = np.zeros(m, np.int32), np.zeros(m, np.float64)
+        fvn, fvs, fvi = np.zeros(m, np.int32), np.zeros(m + 1, np.int32), np.zeros(m, np.int32)
+        nb, nf = C.c_int32(), C.c_int32()
+        check(self.L_.orbgpu_bow_transform(self.h, _p(desc), n, levelsup, _p(wid), _p(wgt), _p(nid), _p(bid), _p(bval),
+                                           C.byref(nb), _p(fvn), _p(fvs), _p(fvi), C.byref(nf)))
+        return {"word_id": wid[:n], "weight": wgt[:n], "node_id": nid[:n], "bow_ids": bid[:nb.value],
+                "bow_vals": bval[:nb.value], "fv_nodes": fvn[:nf.value], "fv_start": fvs[:nf.value + 1],
+                "fv_items": fvi[:fvs[nf.value]]}
+
+    def transform_batch_device(self, d_desc, batch, cap, d_n, levelsup, d_word, d_weight, d_node, stream=0):
+        check(self.L_.orbgpu_bow_transform_batch_device(self.h, d_desc, batch, cap, d_n, levelsup, d_word, d_weight,
+                                                        d_node, stream))
+
+
+def search_by_bow(desc_kf, angle_kf, valid_kf, node_kf, desc_f, angle_f, node_f, th_low=TH_LOW, nnratio=0.7,
+                  check_ori=True, device_id=0):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) on per-feature node ids (orbgpu_search_by_bow)."""
+    desc_kf = np.ascontiguousarray(desc_kf, np.uint8).reshape(-1, 32)
+    desc_f = np.ascontiguousarray(desc_f, np.uint8).reshape(-1, 32)
+    akf, af = np.ascontiguousarray(angle_kf, np.float32), np.ascontiguousarray(angle_f, np.float32)
+    nkf, nf_ = np.ascontiguousarray(node_kf, np.int32), np.ascontiguousarray(node_f, np.int32)
+    va = None if valid_kf is None else np.ascontiguousarray(valid_kf, np.uint8)
+    out = np.zeros(max(1, len(desc_f)), np.int32)
+    n = C.c_int32()
+    L = lib()
+    L.orbgpu_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_int32]
+    check(L.orbgpu_search_by_bow(_p(desc_kf), _p(akf), _p(va), _p(nkf), len(desc_kf), _p(desc_f), _p(af), _p(nf_),
+                                 len(desc_f), th_low, nnratio, int(check_ori), _p(out), C.byref(n), device_id))
+    return n.value, out[:len(desc_f)].copy()
 
 
 # --------------------------------------------------------------------------------------------

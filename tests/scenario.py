@@ -84,3 +84,40 @@ def local_map(O, stream, Tcw, world_pos, desc, octave, scale_factors, rng, obs_z
             out["proj_x"][i], out["proj_y"][i], out["proj_xr"][i] = px, py, pxr
             out["level"][i], out["view_cos"][i] = level, vc
     return out
+
+
+def synthetic_vocabulary(k, L, seed, irregular=False, stop_frac=0.0, flip_bits=40):
+    """A seeded DBoW2-shaped vocabulary tree (the reference's ORBvoc.bin is a missing blob): nodes in an order
+    TemplatedVocabulary::loadFromTextFile could have produced (parent before child), a child's descriptor = its
+    parent's with `flip_bits` random bits flipped (so that similar features descend alike), leaf weights idf-like
+    positive doubles (a fraction `stop_frac` zero = stopped words).  irregular: some inner nodes get fewer than k
+    children and some leaves sit above level L.
+    Returns dict(k, L, parent, is_leaf, desc, weight)."""
+    rng = np.random.default_rng(seed)
+    parent, level, desc = [-1], [0], [np.zeros(32, np.uint8)]
+    frontier = [0]
+    for lvl in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            nchild = k
+            if irregular and lvl > 1:
+                r = rng.random()
+                nchild = 0 if r < 0.08 else (int(rng.integers(1, k + 1)) if r < 0.4 else k)
+            for _ in range(nchild):
+                d = np.unpackbits(desc[p] if p else rng.integers(0, 256, 32, dtype=np.uint8))
+                flip = rng.choice(256, flip_bits if p else 0, replace=False)
+                d[flip] ^= 1
+                parent.append(p), level.append(lvl), desc.append(np.packbits(d))
+                nxt.append(len(parent) - 1)
+        frontier = nxt
+    n = len(parent)
+    parent = np.asarray(parent, np.int32)
+    has_child = np.zeros(n, bool)
+    has_child[parent[1:]] = True
+    is_leaf = (~has_child).astype(np.uint8)
+    is_leaf[0] = 0
+    weight = np.zeros(n, np.float64)
+    leaves = np.nonzero(is_leaf)[0]
+    weight[leaves] = np.log(1000.0 / rng.integers(1, 900, len(leaves)))
+    weight[leaves[rng.random(len(leaves)) < stop_frac]] = 0.0
+    return {"k": k, "L": L, "parent": parent, "is_leaf": is_leaf, "desc": np.stack(desc), "weight": weight}
