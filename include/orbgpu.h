@@ -453,6 +453,52 @@ int orbgpu_search_by_bow_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t 
                                       float nnratio, int32_t check_orientation, int32_t *d_match_b,
                                       int32_t *d_nmatches, void *hip_stream);
 
+/* ---- the background-thread matchers (LocalMapping / LoopClosing), SURVEY.md M6 ----------------------------- */
+
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12) (ORBmatcher.cc:522-655;
+ * LoopClosing::ComputeSim3, LoopClosing.cc:266).  valid1 / valid2: the key point has a map point that is not bad.
+ * match12[i1] = key point of key frame 2 whose map point vpMatches12[i1] receives, or -1. */
+int orbgpu_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1,
+                                   const int32_t *node1, int32_t n1, const uint8_t *desc2, const float *angle2,
+                                   const uint8_t *valid2, const int32_t *node2, int32_t n2, float nnratio,
+                                   int32_t check_orientation, int32_t *match12, int32_t *nmatches, int32_t device_id);
+
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:657-823, epipolar
+ * test :140-157; LocalMapping::CreateNewMapPoints, LocalMapping.cc:268).  kf1 / kf2: the key frames as frame views
+ * (kp_x / kp_y = mvKeysUn, u_right = mvuRight, kp_octave, kp_angle, desc; grids are not read); has_mp*: the key
+ * point already has a map point; node*: orbgpu_bow_transform's node_id; F12 row-major 3x3; (ex, ey) the epipole
+ * in image 2 (:664-670, from the poses); level_sigma2_2 = pKF2->mvLevelSigma2.  match12[i1] = i2 or -1; the pairs
+ * vector of the reference is its non-negative entries in order. */
+int orbgpu_search_for_triangulation(const orbgpu_frame_view *kf1, const uint8_t *has_mp1, const int32_t *node1,
+                                    const orbgpu_frame_view *kf2, const uint8_t *has_mp2, const int32_t *node2,
+                                    const float *F12, float ex, float ey, const float *level_sigma2_2,
+                                    int32_t only_stereo, int32_t check_orientation, int32_t *match12,
+                                    int32_t *nmatches, int32_t device_id);
+
+/* ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th) (ORBmatcher.cc:825-975;
+ * LocalMapping::SearchInNeighbors, LocalMapping.cc:489, 514): the candidate phase.  pts->bad[i] = !pMP ||
+ * pMP->isBad() || pMP->IsInKeyFrame(pKF).  best_idx[i] = the key point map point i fuses with (least distance in its
+ * window after the level and reprojection-error gates, <= TH_LOW) or -1.  The map edits of :948-968 (Replace /
+ * AddObservation / AddMapPoint) mutate the pointer graph and stay with the caller, applied in index order.
+ * ORBGPU_ELEVEL if a predicted level falls outside [0, nlevels). */
+int orbgpu_fuse(const orbgpu_frame_view *kf, const float *Tcw, float fx, float fy, float cx, float cy, float bf,
+                float log_scale_factor, const orbgpu_points_view *pts, float th, const float *inv_level_sigma2,
+                int32_t *best_idx, int32_t *n_candidates, int32_t device_id);
+/* ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:977-1100;
+ * LoopClosing::SearchAndFuse, LoopClosing.cc:597): candidate phase.  pts->bad[i] = isBad() || already in pKF. */
+int orbgpu_fuse_sim3(const orbgpu_frame_view *kf, const float *Scw, float fx, float fy, float cx, float cy,
+                     float log_scale_factor, const orbgpu_points_view *pts, float th, int32_t *best_idx,
+                     int32_t *n_candidates, int32_t device_id);
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1102-1326;
+ * LoopClosing::ComputeSim3, LoopClosing.cc:324).  pts1 / pts2: one row per key point of the key frame (bad[i] = no
+ * map point or isBad(); normal is not read); already1 / already2 = vbAlreadyMatched1 / 2 (:1133-1144) or NULL;
+ * T1w / T2w: the key-frame poses, R12 row-major 3x3.  match12[i1] = i2 where both directions agree, else -1. */
+int orbgpu_search_by_sim3(const orbgpu_frame_view *kf1, const orbgpu_frame_view *kf2, const float *T1w, const float *T2w,
+                          float s12, const float *R12, const float *t12, float fx, float fy, float cx, float cy,
+                          float log_sf1, float log_sf2, const orbgpu_points_view *pts1, const uint8_t *already1,
+                          const orbgpu_points_view *pts2, const uint8_t *already2, float th, int32_t *match12,
+                          int32_t *nfound, int32_t device_id);
+
 /* ======================================================================================
  * PointCloudMapping  (reference include/PointCloudMap.h:41-88, src/PointCloudMap.cc)
  * ====================================================================================== */

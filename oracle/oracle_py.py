@@ -531,3 +531,94 @@ def search_by_bow(desc_kf, angle_kf, valid_kf, fv_kf, desc_f, angle_f, fv_f, th_
                                 len(desc_f), len(b[0]), _p(b[0]), _p(b[1]), _p(b[2]), th_low, nnratio, int(check_ori),
                                 _p(out))
     return n, out[:len(desc_f)].copy()
+
+
+# ---- M6: background-thread matchers ---------------------------------------------------------------------------
+_PTS_FIELDS = (("bad", np.uint8), ("world_pos", np.float32), ("normal", np.float32), ("min_dist", np.float32),
+               ("max_dist", np.float32), ("desc", np.uint8))
+
+
+def _points_view(cls, pts):
+    keep = {k: np.ascontiguousarray(pts[k], dt) for k, dt in _PTS_FIELDS}
+    v = cls()
+    v.m = len(keep["bad"])
+    for k in keep:
+        setattr(v, k, _p(keep[k]))
+    return v, keep
+
+
+def fuse(kf_frame, Tcw, fx, fy, cx, cy, bf, log_sf, pts, th, inv_level_sigma2):
+    v, keep = _points_view(_PointsView, pts)
+    fv = kf_frame.view()
+    T = np.ascontiguousarray(Tcw, np.float32)
+    inv = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    out = np.full(max(v.m, 1), -1, np.int32)
+    L = lib()
+    L.ora_fuse.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    n = L.ora_fuse(C.byref(fv), _p(T), fx, fy, cx, cy, bf, log_sf, C.byref(v), th, _p(inv), _p(out))
+    return n, out[:v.m]
+
+
+def fuse_sim3(kf_frame, Scw, fx, fy, cx, cy, log_sf, pts, th):
+    v, keep = _points_view(_PointsView, pts)
+    fv = kf_frame.view()
+    S = np.ascontiguousarray(Scw, np.float32)
+    out = np.full(max(v.m, 1), -1, np.int32)
+    L = lib()
+    L.ora_fuse_sim3.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 5 + [C.c_void_p, C.c_float, C.c_void_p]
+    n = L.ora_fuse_sim3(C.byref(fv), _p(S), fx, fy, cx, cy, log_sf, C.byref(v), th, _p(out))
+    return n, out[:v.m]
+
+
+def search_by_sim3(kf1, kf2, T1w, T2w, s12, R12, t12, fx, fy, cx, cy, log_sf1, log_sf2, pts1, already1, pts2, already2, th):
+    v1, k1 = _points_view(_PointsView, pts1)
+    v2, k2 = _points_view(_PointsView, pts2)
+    f1, f2 = kf1.view(), kf2.view()
+    A = [np.ascontiguousarray(a, np.float32) for a in (T1w, T2w, R12, t12)]
+    a1 = None if already1 is None else np.ascontiguousarray(already1, np.uint8)
+    a2 = None if already2 is None else np.ascontiguousarray(already2, np.uint8)
+    out = np.full(max(v1.m, 1), -1, np.int32)
+    L = lib()
+    L.ora_search_by_sim3.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p] + [C.c_float] * 6 + \
+        [C.c_void_p] * 4 + [C.c_float, C.c_void_p]
+    n = L.ora_search_by_sim3(C.byref(f1), C.byref(f2), _p(A[0]), _p(A[1]), s12, _p(A[2]), _p(A[3]), fx, fy, cx, cy, log_sf1,
+                             log_sf2, C.byref(v1), _p(a1), C.byref(v2), _p(a2), th, _p(out))
+    return n, out[:v1.m]
+
+
+def _fv(t):
+    return [np.ascontiguousarray(t[k], np.int32) for k in ("fv_nodes", "fv_start", "fv_items")]
+
+
+def search_for_triangulation(kf1, has_mp1, fv1, kf2, has_mp2, fv2, F12, ex, ey, level_sigma2_2, only_stereo, check_ori):
+    f1, f2 = kf1.view(), kf2.view()
+    h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+    a, b = _fv(fv1), _fv(fv2)
+    F = np.ascontiguousarray(F12, np.float32)
+    sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+    out = np.full(max(kf1.n, 1), -1, np.int32)
+    L = lib()
+    L.ora_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    n = L.ora_search_for_triangulation(C.byref(f1), _p(h1), len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), C.byref(f2), _p(h2),
+                                       len(b[0]), _p(b[0]), _p(b[1]), _p(b[2]), _p(F), ex, ey, _p(sg), int(only_stereo),
+                                       int(check_ori), _p(out))
+    return n, out[:kf1.n]
+
+
+def search_by_bow_keyframes(desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nnratio=0.75, check_ori=True):
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    a1, a2 = np.ascontiguousarray(angle1, np.float32), np.ascontiguousarray(angle2, np.float32)
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    a, b = _fv(fv1), _fv(fv2)
+    out = np.full(max(len(d1), 1), -1, np.int32)
+    L = lib()
+    L.ora_search_by_bow_kf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    n = L.ora_search_by_bow_kf(_p(d1), _p(a1), _p(v1), len(d1), len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(d2), _p(a2),
+                               _p(v2), len(d2), len(b[0]), _p(b[0]), _p(b[1]), _p(b[2]), nnratio, int(check_ori), _p(out))
+    return n, out[:len(d1)]

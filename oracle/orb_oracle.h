@@ -250,6 +250,28 @@ void ora_transform_points(const ora_point *in, int n, const double R[9], const d
  * int32 the input is returned unfiltered (PCL behaviour) and *overflow is set. */
 int ora_voxel_filter(const ora_point *in, int n, float leaf, ora_point *out, int *overflow);
 
+/* ---- M6: background-thread matchers (orb_oracle_match.c); see the function comments there ---- */
+int ora_fuse(const ora_frame_view *kf, const float *Tcw, float fx, float fy, float cx, float cy, float bf,
+             float log_scale_factor, const ora_points_view *pts, float th, const float *inv_level_sigma2,
+             int32_t *best_idx);
+int ora_fuse_sim3(const ora_frame_view *kf, const float *Scw, float fx, float fy, float cx, float cy,
+                  float log_scale_factor, const ora_points_view *pts, float th, int32_t *best_idx);
+int ora_search_by_sim3(const ora_frame_view *kf1, const ora_frame_view *kf2, const float *T1w, const float *T2w,
+                       float s12, const float *R12, const float *t12, float fx, float fy, float cx, float cy,
+                       float log_sf1, float log_sf2, const ora_points_view *pts1, const uint8_t *already1,
+                       const ora_points_view *pts2, const uint8_t *already2, float th, int32_t *match12);
+int ora_search_for_triangulation(const ora_frame_view *kf1, const uint8_t *has_mp1, int n_fv1, const int32_t *fv_nodes1,
+                                 const int32_t *fv_start1, const int32_t *fv_items1, const ora_frame_view *kf2,
+                                 const uint8_t *has_mp2, int n_fv2, const int32_t *fv_nodes2,
+                                 const int32_t *fv_start2, const int32_t *fv_items2, const float *F12, float ex,
+                                 float ey, const float *level_sigma2_2, int only_stereo, int check_orientation,
+                                 int32_t *match12);
+int ora_search_by_bow_kf(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1, int n_fv1,
+                         const int32_t *fv_nodes1, const int32_t *fv_start1, const int32_t *fv_items1,
+                         const uint8_t *desc2, const float *angle2, const uint8_t *valid2, int n2, int n_fv2,
+                         const int32_t *fv_nodes2, const int32_t *fv_start2, const int32_t *fv_items2, float nnratio,
+                         int check_orientation, int32_t *match12);
+
 /* ---- BoW: vocabulary tree transform + node-wise matcher (orb_oracle_bow.c) ----
  * Nodes in the order TemplatedVocabulary::loadFromTextFile creates them (node 0 = root, a node after its parent);
  * children of a node in ascending id; leaves numbered in node order = word ids.  weighting: 0 TF_IDF, 1 TF, 2 IDF,

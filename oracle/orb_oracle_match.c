@@ -689,3 +689,416 @@ void ora_compute_stereo_from_rgbd(int n, const float *kp_x, const float *kp_y, c
         }
     }
 }
+
+/* =====================================================================================
+ * M6: the background-thread matchers (LocalMapping / LoopClosing).  Same conventions as above.
+ * ===================================================================================== */
+
+/* best key point of a window without claims: the inner loop shared by ORBmatcher::Fuse (:895-944), Fuse(Sim3)
+ * (:1056-1078) and SearchBySim3 (:1193-1221, :1273-1301).  gate: Fuse's reprojection-error tests (:908-933). */
+static int best_in_window(const ora_frame_view *kf, float u, float v, float ur, float radius, int lvl, int gate,
+                          const float *inv_level_sigma2, const uint8_t *dMP, int32_t *vIndices, int *bestDistOut)
+{
+    const int nc = ora_get_features_in_area(kf, u, v, radius, -1, -1, vIndices); /* KeyFrame.cc:607-646 */
+    int bestDist = 256, bestIdx = -1; /* (Fuse(Sim3) / SearchBySim3 start at INT_MAX: same result, a distance is <= 256) */
+    for (int c = 0; c < nc; c++) {
+        const int idx = vIndices[c];
+        const int kpLevel = kf->kp_octave[idx];
+        if (kpLevel < lvl - 1 || kpLevel > lvl)
+            continue;
+        if (gate) {
+            const float kpx = kf->kp_x[idx], kpy = kf->kp_y[idx];
+            const float ex = u - kpx, ey = v - kpy;
+            if (kf->u_right[idx] >= 0) {
+                const float er = ur - kf->u_right[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * inv_level_sigma2[kpLevel] > 7.8)
+                    continue;
+            } else {
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99)
+                    continue;
+            }
+        }
+        const int dist = ora_descriptor_distance(dMP, kf->desc + (size_t)idx * 32);
+        if (dist < bestDist) {
+            bestDist = dist;
+            bestIdx = idx;
+        }
+    }
+    *bestDistOut = bestDist;
+    return bestIdx;
+}
+
+/* ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th), ORBmatcher.cc:825-975: the candidate
+ * phase.  pts->bad[i] = !pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF) at call time.  best_idx[i] = key point the
+ * point fuses with (bestDist <= TH_LOW) or -1; the map edits (:948-968) are the caller's.  Returns the number of
+ * candidates, -1 on a predicted level outside [0, nlevels) (the reference reads mvScaleFactors out of range). */
+int ora_fuse(const ora_frame_view *kf, const float *Tcw, float fx, float fy, float cx, float cy, float bf,
+             float log_scale_factor, const ora_points_view *pts, float th, const float *inv_level_sigma2,
+             int32_t *best_idx)
+{
+    float Ow[3];
+    minus_rt_t(Tcw, Ow); /* GetCameraCenter */
+    int n = 0;
+    int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(kf->n > 0 ? kf->n : 1));
+    for (int i = 0; i < pts->m; i++) {
+        best_idx[i] = -1;
+        if (pts->bad && pts->bad[i])
+            continue;
+        const float *Pw = pts->world_pos + 3 * (size_t)i;
+        float pc[3];
+        rt_apply(Tcw, Pw, pc);
+        if (pc[2] < 0.0f)
+            continue;
+        const float invz = 1 / pc[2];
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y))
+            continue;
+        const float ur = u - bf * invz;
+        const float maxDistance = 1.2f * pts->max_dist[i], minDistance = 0.8f * pts->min_dist[i];
+        const float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
+        const float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        if (dist3D < minDistance || dist3D > maxDistance)
+            continue;
+        const float *Pn = pts->normal + 3 * (size_t)i;
+        const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+        if (dot < 0.5 * dist3D)
+            continue;
+        const float ratio = pts->max_dist[i] / dist3D;
+        const int lvl = (int)ceilf(logf(ratio) / log_scale_factor);
+        if (lvl < 0 || lvl >= kf->nlevels) {
+            n = -1;
+            break;
+        }
+        const float radius = th * kf->scale_factors[lvl];
+        int bestDist;
+        const int bestIdx = best_in_window(kf, u, v, ur, radius, lvl, 1, inv_level_sigma2,
+                                           pts->desc + (size_t)i * 32, vIndices, &bestDist);
+        if (bestIdx >= 0 && bestDist <= ORA_TH_LOW) {
+            best_idx[i] = bestIdx;
+            n++;
+        }
+    }
+    free(vIndices);
+    return n;
+}
+
+/* ORBmatcher::Fuse(KeyFrame *pKF, cv::Mat Scw, vpPoints, th, vpReplacePoint), ORBmatcher.cc:977-1100: candidate
+ * phase.  pts->bad[i] = isBad() || spAlreadyFound.count(pMP). */
+int ora_fuse_sim3(const ora_frame_view *kf, const float *Scw, float fx, float fy, float cx, float cy,
+                  float log_scale_factor, const ora_points_view *pts, float th, int32_t *best_idx)
+{
+    float T[16], Ow[3];
+    memset(T, 0, sizeof(T));
+    ora_sim3_decompose(Scw, T, Ow);
+    int n = 0;
+    int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(kf->n > 0 ? kf->n : 1));
+    for (int i = 0; i < pts->m; i++) {
+        best_idx[i] = -1;
+        if (pts->bad && pts->bad[i])
+            continue;
+        const float *Pw = pts->world_pos + 3 * (size_t)i;
+        float pc[3];
+        rt_apply(T, Pw, pc);
+        if (pc[2] < 0.0f)
+            continue;
+        const float invz = (float)(1.0 / (double)pc[2]); /* :1017 `1.0/` */
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y))
+            continue;
+        const float maxDistance = 1.2f * pts->max_dist[i], minDistance = 0.8f * pts->min_dist[i];
+        const float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
+        const float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        if (dist3D < minDistance || dist3D > maxDistance)
+            continue;
+        const float *Pn = pts->normal + 3 * (size_t)i;
+        const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+        if (dot < 0.5 * dist3D)
+            continue;
+        const float ratio = pts->max_dist[i] / dist3D;
+        const int lvl = (int)ceilf(logf(ratio) / log_scale_factor);
+        if (lvl < 0 || lvl >= kf->nlevels) {
+            n = -1;
+            break;
+        }
+        const float radius = th * kf->scale_factors[lvl];
+        int bestDist;
+        const int bestIdx = best_in_window(kf, u, v, 0.f, radius, lvl, 0, NULL, pts->desc + (size_t)i * 32, vIndices,
+                                           &bestDist);
+        if (bestIdx >= 0 && bestDist <= ORA_TH_LOW) {
+            best_idx[i] = bestIdx;
+            n++;
+        }
+    }
+    free(vIndices);
+    return n;
+}
+
+/* one direction of SearchBySim3 (:1143-1227 / :1229-1307): points of key frame A (camera frame Taw) moved into key
+ * frame B by the similarity (sR, t), best key point of B in the window, threshold TH_HIGH */
+static int sim3_direction(const ora_frame_view *kfB, const float *Taw, const float sR[9], const float t[3], float fx,
+                          float fy, float cx, float cy, float log_sfB, const ora_points_view *ptsA,
+                          const uint8_t *skipA, float th, int32_t *match)
+{
+    int32_t *vIndices = (int32_t *)malloc(sizeof(int32_t) * (size_t)(kfB->n > 0 ? kfB->n : 1));
+    int rc = 0;
+    for (int i = 0; i < ptsA->m; i++) {
+        match[i] = -1;
+        if ((ptsA->bad && ptsA->bad[i]) || (skipA && skipA[i]))
+            continue;
+        float pa[3], pb[3];
+        rt_apply(Taw, ptsA->world_pos + 3 * (size_t)i, pa);
+        for (int r = 0; r < 3; r++) {
+            const float t0 = sR[3 * r] * pa[0] + sR[3 * r + 1] * pa[1];
+            const float t1 = t0 + sR[3 * r + 2] * pa[2];
+            pb[r] = t1 + t[r];
+        }
+        if (pb[2] < 0.0)
+            continue;
+        const float invz = (float)(1.0 / (double)pb[2]);
+        const float x = pb[0] * invz, y = pb[1] * invz;
+        const float u = fx * x + cx, v = fy * y + cy;
+        if (!(u >= kfB->min_x && u < kfB->max_x && v >= kfB->min_y && v < kfB->max_y))
+            continue;
+        const float maxDistance = 1.2f * ptsA->max_dist[i], minDistance = 0.8f * ptsA->min_dist[i];
+        const float dist3D = (float)sqrt((double)pb[0] * pb[0] + (double)pb[1] * pb[1] + (double)pb[2] * pb[2]);
+        if (dist3D < minDistance || dist3D > maxDistance)
+            continue;
+        const float ratio = ptsA->max_dist[i] / dist3D;
+        const int lvl = (int)ceilf(logf(ratio) / log_sfB);
+        if (lvl < 0 || lvl >= kfB->nlevels) {
+            rc = -1;
+            break;
+        }
+        const float radius = th * kfB->scale_factors[lvl];
+        int bestDist;
+        const int bestIdx = best_in_window(kfB, u, v, 0.f, radius, lvl, 0, NULL, ptsA->desc + (size_t)i * 32, vIndices,
+                                           &bestDist);
+        if (bestIdx >= 0 && bestDist <= ORA_TH_HIGH)
+            match[i] = bestIdx;
+    }
+    free(vIndices);
+    return rc;
+}
+
+/* ORBmatcher::SearchBySim3, ORBmatcher.cc:1102-1326.  pts1 / pts2: row i = key point i of the key frame (bad[i] =
+ * no map point or isBad()); already1 / already2 = vbAlreadyMatched1 / 2 (:1133-1144).  R12 row-major 3x3, t12.
+ * match12[i1] = index in key frame 2 where both directions agree, else -1.  Returns nFound, -1 on a level error. */
+int ora_search_by_sim3(const ora_frame_view *kf1, const ora_frame_view *kf2, const float *T1w, const float *T2w,
+                       float s12, const float *R12, const float *t12, float fx, float fy, float cx, float cy,
+                       float log_sf1, float log_sf2, const ora_points_view *pts1, const uint8_t *already1,
+                       const ora_points_view *pts2, const uint8_t *already2, float th, int32_t *match12)
+{
+    float sR12[9], sR21[9], t21[3];
+    const double inv_s = 1.0 / (double)s12;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            sR12[3 * r + c] = s12 * R12[3 * r + c];                           /* :1121 */
+            sR21[3 * r + c] = (float)((double)R12[3 * c + r] * inv_s);        /* :1122 (1.0/s12)*R12.t() */
+        }
+    for (int r = 0; r < 3; r++) { /* :1123 t21 = -sR21*t12 (small-matrix product, alpha = -1) */
+        const float t0 = sR21[3 * r] * t12[0] + sR21[3 * r + 1] * t12[1];
+        const float t1 = t0 + sR21[3 * r + 2] * t12[2];
+        t21[r] = -t1;
+    }
+    int32_t *m1 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(pts1->m > 0 ? pts1->m : 1));
+    int32_t *m2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(pts2->m > 0 ? pts2->m : 1));
+    int rc = sim3_direction(kf2, T1w, sR21, t21, fx, fy, cx, cy, log_sf2, pts1, already1, th, m1);
+    if (rc == 0)
+        rc = sim3_direction(kf1, T2w, sR12, t12, fx, fy, cx, cy, log_sf1, pts2, already2, th, m2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < pts1->m; i1++) {
+        match12[i1] = -1;
+        if (rc != 0)
+            continue;
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && m2[idx2] == i1) { /* :1312-1322 */
+            match12[i1] = idx2;
+            nFound++;
+        }
+    }
+    free(m1);
+    free(m2);
+    return rc != 0 ? -1 : nFound;
+}
+
+/* ORBmatcher::CheckDistEpipolarLine, ORBmatcher.cc:140-157 (F12 row-major 3x3) */
+static int check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float *F12, float sigma2_kp2)
+{
+    const float a = x1 * F12[0] + y1 * F12[3] + F12[6];
+    const float b = x1 * F12[1] + y1 * F12[4] + F12[7];
+    const float c = x1 * F12[2] + y1 * F12[5] + F12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0)
+        return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2_kp2;
+}
+
+/* ORBmatcher::SearchForTriangulation, ORBmatcher.cc:657-823.  Key frames as frame views (kp_x/kp_y = mvKeysUn,
+ * u_right = mvuRight), has_mp* = GetMapPoint(idx) != NULL, feature vectors as CSR.  (ex, ey) = the epipole in the
+ * second image (:664-670, computed by the caller from the poses), level_sigma2 / scale factors of key frame 2.
+ * vbMatched2 is never set in the reference (:676, 724): rows are independent.  match12[i1] = idx2 or -1. */
+int ora_search_for_triangulation(const ora_frame_view *kf1, const uint8_t *has_mp1, int n_fv1, const int32_t *fv_nodes1,
+                                 const int32_t *fv_start1, const int32_t *fv_items1, const ora_frame_view *kf2,
+                                 const uint8_t *has_mp2, int n_fv2, const int32_t *fv_nodes2,
+                                 const int32_t *fv_start2, const int32_t *fv_items2, const float *F12, float ex,
+                                 float ey, const float *level_sigma2_2, int only_stereo, int check_orientation,
+                                 int32_t *match12)
+{
+    int nmatches = 0;
+    int histo[ORA_HISTO_LENGTH];
+    memset(histo, 0, sizeof(histo));
+    int *bin_of = (int *)malloc(sizeof(int) * (size_t)(kf1->n > 0 ? kf1->n : 1));
+    for (int i = 0; i < kf1->n; i++) {
+        match12[i] = -1;
+        bin_of[i] = -1;
+    }
+    int a = 0, b = 0;
+    while (a < n_fv1 && b < n_fv2) {
+        if (fv_nodes1[a] == fv_nodes2[b]) {
+            for (int p1 = fv_start1[a]; p1 < fv_start1[a + 1]; p1++) {
+                const int idx1 = fv_items1[p1];
+                if (has_mp1[idx1])
+                    continue;
+                const int bStereo1 = kf1->u_right[idx1] >= 0;
+                if (only_stereo && !bStereo1)
+                    continue;
+                int bestDist = ORA_TH_LOW, bestIdx2 = -1;
+                for (int p2 = fv_start2[b]; p2 < fv_start2[b + 1]; p2++) {
+                    const int idx2 = fv_items2[p2];
+                    if (has_mp2[idx2])
+                        continue;
+                    const int bStereo2 = kf2->u_right[idx2] >= 0;
+                    if (only_stereo && !bStereo2)
+                        continue;
+                    const int dist = ora_descriptor_distance(kf1->desc + (size_t)idx1 * 32, kf2->desc + (size_t)idx2 * 32);
+                    if (dist > ORA_TH_LOW || dist > bestDist)
+                        continue;
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kf2->kp_x[idx2], distey = ey - kf2->kp_y[idx2];
+                        if (distex * distex + distey * distey < 100 * kf2->scale_factors[kf2->kp_octave[idx2]])
+                            continue;
+                    }
+                    if (check_dist_epipolar_line(kf1->kp_x[idx1], kf1->kp_y[idx1], kf2->kp_x[idx2], kf2->kp_y[idx2], F12,
+                                                 level_sigma2_2[kf2->kp_octave[idx2]])) {
+                        bestIdx2 = idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    match12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        const int bin = rot_bin(kf1->kp_angle[idx1], kf2->kp_angle[bestIdx2]);
+                        bin_of[idx1] = bin;
+                        histo[bin]++;
+                    }
+                }
+            }
+            a++;
+            b++;
+        } else if (fv_nodes1[a] < fv_nodes2[b]) {
+            while (a < n_fv1 && fv_nodes1[a] < fv_nodes2[b])
+                a++;
+        } else {
+            while (b < n_fv2 && fv_nodes2[b] < fv_nodes1[a])
+                b++;
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        three_maxima(histo, ORA_HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < kf1->n; i++) {
+            const int bn = bin_of[i];
+            if (bn < 0 || bn == i1 || bn == i2 || bn == i3)
+                continue;
+            match12[i] = -1;
+            nmatches--;
+        }
+    }
+    free(bin_of);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12), ORBmatcher.cc:522-655.  valid1 / valid2:
+ * the key point has a map point that is not bad.  match12[idx1] = idx2 (the index whose map point vpMatches12 gets)
+ * or -1.  Note the strict `bestDist1 < TH_LOW` (:592), unlike the frame version. */
+int ora_search_by_bow_kf(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1, int n_fv1,
+                         const int32_t *fv_nodes1, const int32_t *fv_start1, const int32_t *fv_items1,
+                         const uint8_t *desc2, const float *angle2, const uint8_t *valid2, int n2, int n_fv2,
+                         const int32_t *fv_nodes2, const int32_t *fv_start2, const int32_t *fv_items2, float nnratio,
+                         int check_orientation, int32_t *match12)
+{
+    int nmatches = 0;
+    int histo[ORA_HISTO_LENGTH];
+    memset(histo, 0, sizeof(histo));
+    int *bin_of = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1));
+    uint8_t *matched2 = (uint8_t *)calloc((size_t)(n2 > 0 ? n2 : 1), 1);
+    for (int i = 0; i < n1; i++) {
+        match12[i] = -1;
+        bin_of[i] = -1;
+    }
+    int a = 0, b = 0;
+    while (a < n_fv1 && b < n_fv2) {
+        if (fv_nodes1[a] == fv_nodes2[b]) {
+            for (int p1 = fv_start1[a]; p1 < fv_start1[a + 1]; p1++) {
+                const int idx1 = fv_items1[p1];
+                if (valid1 && !valid1[idx1])
+                    continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int p2 = fv_start2[b]; p2 < fv_start2[b + 1]; p2++) {
+                    const int idx2 = fv_items2[p2];
+                    if (matched2[idx2] || (valid2 && !valid2[idx2]))
+                        continue;
+                    const int dist = ora_descriptor_distance(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 < ORA_TH_LOW) {
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        match12[idx1] = bestIdx2;
+                        matched2[bestIdx2] = 1;
+                        if (check_orientation) {
+                            const int bin = rot_bin(angle1[idx1], angle2[bestIdx2]);
+                            bin_of[idx1] = bin;
+                            histo[bin]++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++;
+            b++;
+        } else if (fv_nodes1[a] < fv_nodes2[b]) {
+            while (a < n_fv1 && fv_nodes1[a] < fv_nodes2[b])
+                a++;
+        } else {
+            while (b < n_fv2 && fv_nodes2[b] < fv_nodes1[a])
+                b++;
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        three_maxima(histo, ORA_HISTO_LENGTH, &i1, &i2, &i3);
+        for (int i = 0; i < n1; i++) {
+            const int bn = bin_of[i];
+            if (bn < 0 || bn == i1 || bn == i2 || bn == i3)
+                continue;
+            match12[i] = -1;
+            nmatches--;
+        }
+    }
+    free(bin_of);
+    free(matched2);
+    return nmatches;
+}

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <climits>
 #include <new>
+#include <vector>
 
 namespace orbgpu {
 
@@ -788,6 +789,32 @@ int orbgpu_search_by_bow(const uint8_t *desc_kf, const float *angle_kf, const ui
     ORBGPU_REQUIRE((n_kf == 0 || node_kf) && (n_f == 0 || node_f), "null node arrays");
     return match_host(desc_kf, angle_kf, valid_kf, node_kf, n_kf, desc_f, angle_f, node_f, n_f, th_low, nnratio,
                       check_orientation, match_f, nmatches, device_id);
+}
+
+int orbgpu_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, const uint8_t *valid1,
+                                   const int32_t *node1, int32_t n1, const uint8_t *desc2, const float *angle2,
+                                   const uint8_t *valid2, const int32_t *node2, int32_t n2, float nnratio,
+                                   int32_t check_orientation, int32_t *match12, int32_t *nmatches, int32_t device_id)
+{
+    // ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:522-655) is the frame version with
+    // (a) candidates restricted to key points of key frame 2 that have a good map point (:569-575): they get a node
+    // id no valid row carries, (b) a STRICT threshold `bestDist1 < TH_LOW` (:592) = `<= TH_LOW - 1` on integers,
+    // (c) the result indexed by key frame 1: matches are one to one (vbMatched2), so the B-indexed table inverts.
+    ORBGPU_REQUIRE(match12 && nmatches, "null argument");
+    ORBGPU_REQUIRE(n1 >= 0 && n2 >= 0 && (n1 == 0 || node1) && (n2 == 0 || node2), "bad arguments");
+    std::vector<int32_t> nd2((size_t)std::max(n2, 1)), mb((size_t)std::max(n2, 1), -1);
+    for (int j = 0; j < n2; j++)
+        nd2[j] = (!valid2 || valid2[j]) ? node2[j] : -2;
+    int rc = match_host(desc1, angle1, valid1, node1, n1, desc2, angle2, nd2.data(), n2, ORBGPU_TH_LOW - 1, nnratio,
+                        check_orientation, mb.data(), nmatches, device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    for (int i = 0; i < n1; i++)
+        match12[i] = -1;
+    for (int j = 0; j < n2; j++)
+        if (mb[j] >= 0)
+            match12[mb[j]] = j;
+    return ORBGPU_OK;
 }
 
 int orbgpu_hamming256(const uint8_t *a, const uint8_t *b, int32_t n, int32_t *out, int32_t device_id)

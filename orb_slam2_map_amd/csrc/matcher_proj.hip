@@ -32,7 +32,7 @@ struct Query {  // one row of the matcher: a projected map point
     int active;         // 0: the reference `continue`s before the candidate loop
     int blocking;       // a claim by this row hides the key point from later rows
     int check_ur;       // apply the mvuRight gate (ORBmatcher.cc:91-96 / 1407-1413); off for :1472-1599
-    int pad;
+    int gate;           // 1: Fuse's reprojection-error gates (ORBmatcher.cc:908-933) against F.inv_sigma2
 };
 
 struct FrameDev {
@@ -45,6 +45,7 @@ struct FrameDev {
     const uint8_t *desc;
     float min_x, min_y, inv_w, inv_h;
     const int *cell_start, *cell_items;
+    const float *inv_sigma2;  // [nlevels] mvInvLevelSigma2, only read when a query has gate set
 };
 
 constexpr uint64_t KEY_NONE = ((uint64_t)256 << 44) | 0xFFFFFFFFFFFull;
@@ -121,6 +122,19 @@ __device__ __forceinline__ void proj_walk_each(const Query &Q, const uint64_t a[
                 const float er = fabsf(Q.ur - ur);
                 if (er > Q.r)
                     continue;
+            }
+            if (Q.gate) {  // ORBmatcher.cc:908-933: chi-square gates on the reprojection error (float e2, double bound)
+                const float ex = -dx, ey = -dy;  // u - kpx, v - kpy
+                if (ur >= 0) {
+                    const float er = Q.ur - ur;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if ((double)(e2 * F.inv_sigma2[oct]) > 7.8)
+                        continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if ((double)(e2 * F.inv_sigma2[oct]) > 5.99)
+                        continue;
+                }
             }
             const uint64_t *db = reinterpret_cast<const uint64_t *>(F.desc) + (size_t)idx * 4;
             uint64_t b[4] = {db[0], db[1], db[2], db[3]};
@@ -555,7 +569,7 @@ struct ProjWorkspace {
     int device = -1;
     hipStream_t stream = nullptr;
     DevBuf kp_x, kp_y, kp_octave, u_right, desc, cell_start, cell_items, kp_angle;
-    DevBuf queries, row_desc, row_angle, claim_init, topk, match, slow, k2m, out;
+    DevBuf queries, row_desc, row_angle, claim_init, topk, match, slow, k2m, out, inv_sigma2, tri;
     ~ProjWorkspace()
     {
         // device memory is released with the process; the HIP runtime may already be gone here
@@ -640,6 +654,7 @@ static int upload_frame(ProjWorkspace &ws, const orbgpu_frame_view *f, FrameDev 
     F.inv_h = f->grid_inv_h;
     F.cell_start = ws.cell_start.as<int>();
     F.cell_items = ws.cell_items.as<int>();
+    F.inv_sigma2 = nullptr;
     return ORBGPU_OK;
 }
 
@@ -648,11 +663,13 @@ template <int MODE>
 static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vector<Query> &queries,
                           const uint8_t *row_desc_host, const float *row_angle_host, const float *kp_angle_host,
                           const std::vector<int> &claim_init, float nnratio, int th_dist, int check_orientation,
-                          int32_t *kp_to_mp, int32_t *nmatches)
+                          int32_t *kp_to_mp, int32_t *nmatches, int32_t *row_match = nullptr)
 {
     const int m = (int)queries.size(), n = F.n;
     if (m == 0 || n == 0) {
         *nmatches = 0;
+        for (int i = 0; row_match && i < m; i++)
+            row_match[i] = -1;
         return ORBGPU_OK;
     }
     hipStream_t st = ws.stream;
@@ -685,6 +702,8 @@ static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vecto
     ORBGPU_HIP_TRY(hipGetLastError());
     ORBGPU_HIP_TRY(hipMemcpyAsync(kp_to_mp, ws.k2m.p, sizeof(int) * n, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipMemcpyAsync(nmatches, ws.out.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (row_match)  // the decision of every row (key point index or -1): what the claim-free matchers return
+        ORBGPU_HIP_TRY(hipMemcpyAsync(row_match, ws.match.p, sizeof(int) * m, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipStreamSynchronize(st));
     return ORBGPU_OK;
 }
@@ -891,6 +910,130 @@ __global__ __launch_bounds__(256) void k_project_last_queries(int rows, const in
     q[i] = Q;
 }
 
+// ---- ORBmatcher::SearchForTriangulation (ORBmatcher.cc:657-823) ---------------------------------------------
+struct TriParams {
+    float F12[9];
+    float ex, ey;  // epipole in the second image (:664-670)
+    int only_stereo;
+    float sigma2[ORBGPU_MAX_LEVELS], scale[ORBGPU_MAX_LEVELS];  // of key frame 2
+};
+
+// One wave per key point of key frame 1 without a map point: its candidates are the key points of key frame 2 under
+// the same vocabulary node (node2 == node1 >= 0) without a map point; Hamming <= TH_LOW, the epipole distance test
+// for monocular pairs, the epipolar-line test (:140-157), least distance, the LAST among equals in the node's list
+// (`dist > bestDist` is the skip, :739), i.e. the largest index.  The reference never sets vbMatched2, so rows do
+// not interact.  Rotation histogram: k_tri_finish.
+__global__ __launch_bounds__(256) void k_tri_match(int n1, const float *__restrict__ x1, const float *__restrict__ y1,
+                                                   const float *__restrict__ ur1, const uint8_t *__restrict__ has_mp1,
+                                                   const int *__restrict__ node1, const uint8_t *__restrict__ desc1,
+                                                   int n2, const float *__restrict__ x2, const float *__restrict__ y2,
+                                                   const int *__restrict__ oct2, const float *__restrict__ ur2,
+                                                   const uint8_t *__restrict__ has_mp2, const int *__restrict__ node2,
+                                                   const uint8_t *__restrict__ desc2, TriParams P,
+                                                   int *__restrict__ match12)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n1)
+        return;
+    int best = -1;
+    const int nd = node1[i];
+    const bool stereo1 = ur1[i] >= 0;
+    if (nd >= 0 && !has_mp1[i] && !(P.only_stereo && !stereo1)) {
+        const uint64_t *pa = reinterpret_cast<const uint64_t *>(desc1) + (size_t)i * 4;
+        const uint64_t a[4] = {pa[0], pa[1], pa[2], pa[3]};
+        const float kx = x1[i], ky = y1[i];
+        // epipolar line in the second image l = x1' F12 (:143-145)
+        const float la = kx * P.F12[0] + ky * P.F12[3] + P.F12[6];
+        const float lb = kx * P.F12[1] + ky * P.F12[4] + P.F12[7];
+        const float lc = kx * P.F12[2] + ky * P.F12[5] + P.F12[8];
+        const float den = la * la + lb * lb;
+        uint32_t key = 0xFFFFFFFFu;  // distance << 16 | (65535 - idx2): least distance, then largest index
+        for (int j = lane; j < n2; j += 64) {
+            if (node2[j] != nd || has_mp2[j])
+                continue;
+            const bool stereo2 = ur2[j] >= 0;
+            if (P.only_stereo && !stereo2)
+                continue;
+            const uint64_t *pb = reinterpret_cast<const uint64_t *>(desc2) + (size_t)j * 4;
+            const uint64_t b[4] = {pb[0], pb[1], pb[2], pb[3]};
+            const int dist = hamming256(a, b);
+            if (dist > ORBGPU_TH_LOW)
+                continue;
+            const float px = x2[j], py = y2[j];
+            const int o = oct2[j];
+            if (!stereo1 && !stereo2) {
+                const float dex = P.ex - px, dey = P.ey - py;
+                if (dex * dex + dey * dey < 100 * P.scale[o])
+                    continue;
+            }
+            const float num = la * px + lb * py + lc;
+            if (den == 0)
+                continue;
+            const float dsqr = num * num / den;
+            if (!((double)dsqr < 3.84 * (double)P.sigma2[o]))
+                continue;
+            key = min(key, ((uint32_t)dist << 16) | (uint32_t)(65535 - j));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            key = min(key, (uint32_t)__shfl_xor((int)key, off, 64));
+        if (key != 0xFFFFFFFFu)
+            best = 65535 - (int)(key & 0xFFFFu);
+    }
+    if (lane == 0)
+        match12[i] = best;
+}
+
+// rotation consistency of the accepted pairs (:772-795) and the count; one workgroup
+__global__ __launch_bounds__(1024) void k_tri_finish(int n1, const float *__restrict__ angle1,
+                                                     const float *__restrict__ angle2, int check_orientation,
+                                                     int *__restrict__ match12, int *__restrict__ nmatches)
+{
+    __shared__ int histo[ORBGPU_HISTO_LENGTH];
+    __shared__ int s_keep[3], s_count;
+    const int tid = threadIdx.x;
+    if (tid < ORBGPU_HISTO_LENGTH)
+        histo[tid] = 0;
+    if (tid == 0)
+        s_count = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < n1; i += 1024) {
+        const int j = match12[i];
+        if (j < 0)
+            continue;
+        cnt++;
+        if (check_orientation)
+            atomicAdd(&histo[rot_bin(angle1[i], angle2[j])], 1);
+    }
+    __syncthreads();
+    if (check_orientation) {
+        if (tid == 0) {
+            int i1, i2, i3;
+            three_maxima(histo, ORBGPU_HISTO_LENGTH, i1, i2, i3);
+            s_keep[0] = i1, s_keep[1] = i2, s_keep[2] = i3;
+        }
+        __syncthreads();
+        for (int i = tid; i < n1; i += 1024) {
+            const int j = match12[i];
+            if (j < 0)
+                continue;
+            const int b = rot_bin(angle1[i], angle2[j]);
+            if (b != s_keep[0] && b != s_keep[1] && b != s_keep[2]) {
+                match12[i] = -1;
+                cnt--;
+            }
+        }
+    }
+    cnt = wave_reduce_add(cnt);
+    if ((tid & 63) == 0)
+        atomicAdd(&s_count, cnt);
+    __syncthreads();
+    if (tid == 0)
+        *nmatches = s_count;
+}
+
 } // namespace orbgpu
 
 using namespace orbgpu;
@@ -1039,6 +1182,7 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     F.inv_h = (float)GR / (f->max_y - f->min_y);
     F.cell_start = f->cell_start;
     F.cell_items = f->cell_items;
+    F.inv_sigma2 = nullptr;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<0>),
@@ -1122,6 +1266,7 @@ int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur,
     F.inv_h = (float)GR / (cur->max_y - cur->min_y);
     F.cell_start = cur->cell_start;
     F.cell_items = cur->cell_items;
+    F.inv_sigma2 = nullptr;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<1>),
@@ -1416,6 +1561,357 @@ int orbgpu_search_by_projection_sim3(const orbgpu_frame_view *kf, const float *S
     if ((rc = upload_frame(*ws, kf, F)) != ORBGPU_OK)
         return rc;
     return run_projection<1>(*ws, F, q, pts->desc, nullptr, nullptr, init, 0.f, ORBGPU_TH_LOW, 0, kp_to_mp, nmatches);
+}
+
+// ---- claim-free "best key point in the window" matchers: Fuse, Fuse(Sim3), SearchBySim3 ---------------------
+// Host side = the O(m) projection of the boundary in the reference's float conventions; device side = the same
+// window walk / ranking as the projection matchers with rows that never block, so every row keeps the first
+// candidate of least distance (`dist < bestDist`), subject to the distance threshold.
+namespace {
+
+struct PointGate {  // outcome of the per-point tests up to the window search
+    bool ok = false;
+    float u = 0, v = 0, ur = 0;
+    int lvl = 0;
+};
+
+// common tail of the per-point tests: image bounds (KeyFrame::IsInImage), scale-invariance range, viewing angle
+// (optional), PredictScale.  Returns ORBGPU_ELEVEL through rc when the level is out of range.
+static PointGate point_gate(const float pc[3], float invz, float fx, float fy, float cx, float cy, float bf,
+                            const orbgpu_frame_view *kf, float dist3D, const float *PO, const float *Pn, float min_dist,
+                            float max_dist, float log_sf, int &rc, int i)
+{
+    PointGate g;
+    volatile float x = pc[0] * invz, y = pc[1] * invz;
+    volatile float ux = fx * x, vy = fy * y;
+    const float u = ux + cx, v = vy + cy;
+    if (!(u >= kf->min_x && u < kf->max_x && v >= kf->min_y && v < kf->max_y))
+        return g;
+    const float maxDistance = 1.2f * max_dist, minDistance = 0.8f * min_dist;
+    if (dist3D < minDistance || dist3D > maxDistance)
+        return g;
+    if (Pn) {
+        const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+        if (dot < 0.5 * dist3D)
+            return g;
+    }
+    const float ratio = max_dist / dist3D;
+    const int lvl = (int)ceilf(logf(ratio) / log_sf);  // MapPoint::PredictScale
+    if (lvl < 0 || lvl >= kf->nlevels) {
+        set_error("point %d: predicted level %d outside [0,%d)", i, lvl, kf->nlevels);
+        rc = ORBGPU_ELEVEL;
+        return g;
+    }
+    volatile float bz = bf * invz;
+    g.ok = true;
+    g.u = u, g.v = v, g.ur = u - bz, g.lvl = lvl;
+    return g;
+}
+
+static int validate_points(const orbgpu_points_view *pts, bool need_normal)
+{
+    ORBGPU_REQUIRE(pts && pts->m >= 0, "bad point view");
+    if (pts->m > 0)
+        ORBGPU_REQUIRE(pts->world_pos && pts->min_dist && pts->max_dist && pts->desc && (!need_normal || pts->normal),
+                       "null point arrays");
+    return ORBGPU_OK;
+}
+
+// queries -> best key point per row (first of least distance, <= th_dist), -1 otherwise
+static int best_rows(const orbgpu_frame_view *kf, std::vector<Query> &q, const uint8_t *row_desc, int th_dist,
+                     const float *inv_sigma2, int32_t *best_idx, int32_t device_id)
+{
+    ProjWorkspace *ws = nullptr;
+    int rc = workspace(device_id, &ws);
+    if (rc != ORBGPU_OK)
+        return rc;
+    FrameDev F;
+    if ((rc = upload_frame(*ws, kf, F)) != ORBGPU_OK)
+        return rc;
+    if (inv_sigma2) {
+        PJ_TRY(put(ws->inv_sigma2, inv_sigma2, sizeof(float) * kf->nlevels, ws->stream));
+        F.inv_sigma2 = ws->inv_sigma2.as<float>();
+    }
+    std::vector<int> init((size_t)std::max(kf->n, 1), INT_MAX);  // nothing is claimed, nobody blocks
+    std::vector<int32_t> k2m((size_t)std::max(kf->n, 1), -1);
+    int32_t nm = 0;
+    return run_projection<1>(*ws, F, q, row_desc, nullptr, nullptr, init, 0.f, th_dist, 0, k2m.data(), &nm, best_idx);
+}
+
+} // namespace
+
+int orbgpu_fuse(const orbgpu_frame_view *kf, const float *Tcw, float fx, float fy, float cx, float cy, float bf,
+                float log_scale_factor, const orbgpu_points_view *pts, float th, const float *inv_level_sigma2,
+                int32_t *best_idx, int32_t *n_candidates, int32_t device_id)
+{
+    ORBGPU_REQUIRE(Tcw && best_idx && n_candidates && inv_level_sigma2, "null argument");
+    int rc = validate_frame(kf);
+    if (rc != ORBGPU_OK || (rc = validate_points(pts, true)) != ORBGPU_OK)
+        return rc;
+    ORBGPU_REQUIRE(log_scale_factor > 0, "log_scale_factor must be positive");
+    if ((rc = select_device(device_id)) != ORBGPU_OK)
+        return rc;
+    float Ow[3];
+    minus_rt_t(Tcw, Ow);
+    std::vector<Query> q((size_t)pts->m);
+    for (int i = 0; i < pts->m; i++) {
+        Query &Q = q[i];
+        Q = Query{};
+        if (pts->bad && pts->bad[i])
+            continue;
+        const float *Pw = pts->world_pos + 3 * (size_t)i;
+        float pc[3];
+        rt_apply(Tcw, Pw, pc);
+        if (pc[2] < 0.0f)
+            continue;
+        const float invz = 1 / pc[2];  // :857 (float division)
+        const float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
+        const float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        const PointGate g = point_gate(pc, invz, fx, fy, cx, cy, bf, kf, dist3D, PO, pts->normal + 3 * (size_t)i,
+                                       pts->min_dist[i], pts->max_dist[i], log_scale_factor, rc, i);
+        if (rc != ORBGPU_OK)
+            return rc;
+        if (!g.ok)
+            continue;
+        Q.r = th * kf->scale_factors[g.lvl];
+        Q.x = g.u, Q.y = g.v, Q.ur = g.ur;
+        Q.min_level = g.lvl - 1, Q.max_level = g.lvl;
+        Q.gate = 1;
+        Q.active = 1;
+    }
+    if ((rc = best_rows(kf, q, pts->desc, ORBGPU_TH_LOW, inv_level_sigma2, best_idx, device_id)) != ORBGPU_OK)
+        return rc;
+    int n = 0;
+    for (int i = 0; i < pts->m; i++)
+        n += best_idx[i] >= 0;
+    *n_candidates = n;
+    return ORBGPU_OK;
+}
+
+int orbgpu_fuse_sim3(const orbgpu_frame_view *kf, const float *Scw, float fx, float fy, float cx, float cy,
+                     float log_scale_factor, const orbgpu_points_view *pts, float th, int32_t *best_idx,
+                     int32_t *n_candidates, int32_t device_id)
+{
+    ORBGPU_REQUIRE(Scw && best_idx && n_candidates, "null argument");
+    int rc = validate_frame(kf);
+    if (rc != ORBGPU_OK || (rc = validate_points(pts, true)) != ORBGPU_OK)
+        return rc;
+    ORBGPU_REQUIRE(log_scale_factor > 0, "log_scale_factor must be positive");
+    if ((rc = select_device(device_id)) != ORBGPU_OK)
+        return rc;
+    float T[16] = {0}, Ow[3];
+    {  // :985-989, as orbgpu_search_by_projection_sim3
+        const double d = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+        const float scw = (float)sqrt(d);
+        ORBGPU_REQUIRE(scw > 0.f, "degenerate Scw");
+        const float alpha = (float)(1.0 / (double)scw);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) {
+                volatile float v = Scw[4 * r + c] * alpha;
+                T[4 * r + c] = v;
+            }
+        minus_rt_t(T, Ow);
+    }
+    std::vector<Query> q((size_t)pts->m);
+    for (int i = 0; i < pts->m; i++) {
+        Query &Q = q[i];
+        Q = Query{};
+        if (pts->bad && pts->bad[i])
+            continue;
+        const float *Pw = pts->world_pos + 3 * (size_t)i;
+        float pc[3];
+        rt_apply(T, Pw, pc);
+        if (pc[2] < 0.0f)
+            continue;
+        const float invz = (float)(1.0 / (double)pc[2]);  // :1017
+        const float PO[3] = {Pw[0] - Ow[0], Pw[1] - Ow[1], Pw[2] - Ow[2]};
+        const float dist3D = (float)sqrt((double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2]);
+        const PointGate g = point_gate(pc, invz, fx, fy, cx, cy, 0.f, kf, dist3D, PO, pts->normal + 3 * (size_t)i,
+                                       pts->min_dist[i], pts->max_dist[i], log_scale_factor, rc, i);
+        if (rc != ORBGPU_OK)
+            return rc;
+        if (!g.ok)
+            continue;
+        Q.r = th * kf->scale_factors[g.lvl];
+        Q.x = g.u, Q.y = g.v;
+        Q.min_level = g.lvl - 1, Q.max_level = g.lvl;
+        Q.active = 1;
+    }
+    if ((rc = best_rows(kf, q, pts->desc, ORBGPU_TH_LOW, nullptr, best_idx, device_id)) != ORBGPU_OK)
+        return rc;
+    int n = 0;
+    for (int i = 0; i < pts->m; i++)
+        n += best_idx[i] >= 0;
+    *n_candidates = n;
+    return ORBGPU_OK;
+}
+
+// one direction of SearchBySim3 (:1143-1227 / :1229-1307)
+static int sim3_direction(const orbgpu_frame_view *kfB, const float *Taw, const float sR[9], const float t[3], float fx,
+                          float fy, float cx, float cy, float log_sfB, const orbgpu_points_view *ptsA,
+                          const uint8_t *skipA, float th, int32_t *match, int32_t device_id)
+{
+    int rc = ORBGPU_OK;
+    std::vector<Query> q((size_t)ptsA->m);
+    for (int i = 0; i < ptsA->m; i++) {
+        Query &Q = q[i];
+        Q = Query{};
+        if ((ptsA->bad && ptsA->bad[i]) || (skipA && skipA[i]))
+            continue;
+        float pa[3], pb[3];
+        rt_apply(Taw, ptsA->world_pos + 3 * (size_t)i, pa);
+        for (int r = 0; r < 3; r++) {
+            volatile float a = sR[3 * r] * pa[0], b = sR[3 * r + 1] * pa[1], c = sR[3 * r + 2] * pa[2];
+            volatile float t0 = a + b;
+            volatile float t1 = t0 + c;
+            pb[r] = t1 + t[r];
+        }
+        if ((double)pb[2] < 0.0)
+            continue;
+        const float invz = (float)(1.0 / (double)pb[2]);
+        const float dist3D = (float)sqrt((double)pb[0] * pb[0] + (double)pb[1] * pb[1] + (double)pb[2] * pb[2]);
+        const PointGate g = point_gate(pb, invz, fx, fy, cx, cy, 0.f, kfB, dist3D, nullptr, nullptr, ptsA->min_dist[i],
+                                       ptsA->max_dist[i], log_sfB, rc, i);
+        if (rc != ORBGPU_OK)
+            return rc;
+        if (!g.ok)
+            continue;
+        Q.r = th * kfB->scale_factors[g.lvl];
+        Q.x = g.u, Q.y = g.v;
+        Q.min_level = g.lvl - 1, Q.max_level = g.lvl;
+        Q.active = 1;
+    }
+    return best_rows(kfB, q, ptsA->desc, ORBGPU_TH_HIGH, nullptr, match, device_id);
+}
+
+int orbgpu_search_by_sim3(const orbgpu_frame_view *kf1, const orbgpu_frame_view *kf2, const float *T1w, const float *T2w,
+                          float s12, const float *R12, const float *t12, float fx, float fy, float cx, float cy,
+                          float log_sf1, float log_sf2, const orbgpu_points_view *pts1, const uint8_t *already1,
+                          const orbgpu_points_view *pts2, const uint8_t *already2, float th, int32_t *match12,
+                          int32_t *nfound, int32_t device_id)
+{
+    ORBGPU_REQUIRE(T1w && T2w && R12 && t12 && match12 && nfound, "null argument");
+    int rc = validate_frame(kf1);
+    if (rc != ORBGPU_OK || (rc = validate_frame(kf2)) != ORBGPU_OK || (rc = validate_points(pts1, false)) != ORBGPU_OK ||
+        (rc = validate_points(pts2, false)) != ORBGPU_OK)
+        return rc;
+    ORBGPU_REQUIRE(pts1->m == kf1->n && pts2->m == kf2->n, "points views must have one row per key point");
+    ORBGPU_REQUIRE(s12 > 0 && log_sf1 > 0 && log_sf2 > 0, "bad scale");
+    if ((rc = select_device(device_id)) != ORBGPU_OK)
+        return rc;
+    float sR12[9], sR21[9], t21[3];
+    const double inv_s = 1.0 / (double)s12;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            volatile float a = s12 * R12[3 * r + c];  // :1121
+            sR12[3 * r + c] = a;
+            sR21[3 * r + c] = (float)((double)R12[3 * c + r] * inv_s);  // :1122 (1.0/s12)*R12.t()
+        }
+    for (int r = 0; r < 3; r++) {  // :1123 t21 = -sR21*t12
+        volatile float a = sR21[3 * r] * t12[0], b = sR21[3 * r + 1] * t12[1], c = sR21[3 * r + 2] * t12[2];
+        volatile float t0 = a + b;
+        volatile float t1 = t0 + c;
+        t21[r] = -t1;
+    }
+    std::vector<int32_t> m1((size_t)std::max(pts1->m, 1), -1), m2((size_t)std::max(pts2->m, 1), -1);
+    if ((rc = sim3_direction(kf2, T1w, sR21, t21, fx, fy, cx, cy, log_sf2, pts1, already1, th, m1.data(), device_id)) != ORBGPU_OK)
+        return rc;
+    if ((rc = sim3_direction(kf1, T2w, sR12, t12, fx, fy, cx, cy, log_sf1, pts2, already2, th, m2.data(), device_id)) != ORBGPU_OK)
+        return rc;
+    int n = 0;
+    for (int i1 = 0; i1 < pts1->m; i1++) {  // :1309-1323 agreement of the two directions
+        const int idx2 = m1[i1];
+        match12[i1] = (idx2 >= 0 && m2[idx2] == i1) ? idx2 : -1;
+        n += match12[i1] >= 0;
+    }
+    *nfound = n;
+    return ORBGPU_OK;
+}
+
+int orbgpu_search_for_triangulation(const orbgpu_frame_view *kf1, const uint8_t *has_mp1, const int32_t *node1,
+                                    const orbgpu_frame_view *kf2, const uint8_t *has_mp2, const int32_t *node2,
+                                    const float *F12, float ex, float ey, const float *level_sigma2_2,
+                                    int32_t only_stereo, int32_t check_orientation, int32_t *match12,
+                                    int32_t *nmatches, int32_t device_id)
+{
+    ORBGPU_REQUIRE(kf1 && kf2 && F12 && level_sigma2_2 && match12 && nmatches, "null argument");
+    ORBGPU_REQUIRE(kf1->n >= 0 && kf1->n <= 65535 && kf2->n >= 0 && kf2->n <= 65535, "key point count out of range");
+    ORBGPU_REQUIRE(kf2->nlevels >= 1 && kf2->nlevels <= ORBGPU_MAX_LEVELS && kf2->scale_factors, "bad scale factors");
+    if (kf1->n > 0)
+        ORBGPU_REQUIRE(kf1->kp_x && kf1->kp_y && kf1->u_right && kf1->desc && has_mp1 && node1, "null key-frame 1 arrays");
+    if (kf2->n > 0)
+        ORBGPU_REQUIRE(kf2->kp_x && kf2->kp_y && kf2->kp_octave && kf2->u_right && kf2->desc && has_mp2 && node2,
+                       "null key-frame 2 arrays");
+    ORBGPU_REQUIRE(!check_orientation || ((kf1->n == 0 || kf1->kp_angle) && (kf2->n == 0 || kf2->kp_angle)),
+                   "orientation check needs angles");
+    int rc = select_device(device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    *nmatches = 0;
+    const int n1 = kf1->n, n2 = kf2->n;
+    if (n1 == 0)
+        return ORBGPU_OK;
+    if (n2 == 0) {
+        for (int i = 0; i < n1; i++)
+            match12[i] = -1;
+        return ORBGPU_OK;
+    }
+    for (int j = 0; j < n2; j++)
+        ORBGPU_REQUIRE(kf2->kp_octave[j] >= 0 && kf2->kp_octave[j] < kf2->nlevels, "key point %d: octave out of range", j);
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    hipStream_t st = ws->stream;
+    // one staging buffer: descriptors (32-byte rows) first, then the 4-byte arrays, the flags, the outputs
+    const size_t w1 = (size_t)n1, w2 = (size_t)n2;
+    const size_t off_desc1 = 0, off_desc2 = 32 * w1, off_arr = 32 * (w1 + w2), off_f1 = off_arr + 4 * (5 * w1 + 6 * w2),
+                 off_f2 = off_f1 + w1, off_out = ((off_f2 + w2 + 15) / 16) * 16, total = off_out + 4 * w1 + 16;
+    PJ_TRY(ws->tri.reserve(total));
+    uint8_t *base = ws->tri.as<uint8_t>();
+    auto up = [&](size_t off, const void *src, size_t bytes) -> int {
+        ORBGPU_HIP_TRY(hipMemcpyAsync(base + off, src, bytes, hipMemcpyHostToDevice, st));
+        return ORBGPU_OK;
+    };
+    std::vector<float> zeros(std::max(w1, w2), 0.f);
+    size_t o = off_arr;
+    const size_t o_x1 = o; PJ_TRY(up(o, kf1->kp_x, 4 * w1)); o += 4 * w1;
+    const size_t o_y1 = o; PJ_TRY(up(o, kf1->kp_y, 4 * w1)); o += 4 * w1;
+    const size_t o_u1 = o; PJ_TRY(up(o, kf1->u_right, 4 * w1)); o += 4 * w1;
+    const size_t o_n1 = o; PJ_TRY(up(o, node1, 4 * w1)); o += 4 * w1;
+    const size_t o_a1 = o; PJ_TRY(up(o, check_orientation ? kf1->kp_angle : zeros.data(), 4 * w1)); o += 4 * w1;
+    const size_t o_x2 = o; PJ_TRY(up(o, kf2->kp_x, 4 * w2)); o += 4 * w2;
+    const size_t o_y2 = o; PJ_TRY(up(o, kf2->kp_y, 4 * w2)); o += 4 * w2;
+    const size_t o_u2 = o; PJ_TRY(up(o, kf2->u_right, 4 * w2)); o += 4 * w2;
+    const size_t o_n2 = o; PJ_TRY(up(o, node2, 4 * w2)); o += 4 * w2;
+    const size_t o_o2 = o; PJ_TRY(up(o, kf2->kp_octave, 4 * w2)); o += 4 * w2;
+    const size_t o_a2 = o; PJ_TRY(up(o, check_orientation ? kf2->kp_angle : zeros.data(), 4 * w2)); o += 4 * w2;
+    PJ_TRY(up(off_desc1, kf1->desc, 32 * w1));
+    PJ_TRY(up(off_desc2, kf2->desc, 32 * w2));
+    PJ_TRY(up(off_f1, has_mp1, w1));
+    PJ_TRY(up(off_f2, has_mp2, w2));
+    TriParams P;
+    for (int k = 0; k < 9; k++)
+        P.F12[k] = F12[k];
+    P.ex = ex, P.ey = ey, P.only_stereo = only_stereo ? 1 : 0;
+    for (int l = 0; l < ORBGPU_MAX_LEVELS; l++) {
+        P.sigma2[l] = l < kf2->nlevels ? level_sigma2_2[l] : 0.f;
+        P.scale[l] = l < kf2->nlevels ? kf2->scale_factors[l] : 0.f;
+    }
+    int *d_match = reinterpret_cast<int *>(base + off_out), *d_n = d_match + n1;
+#define TRI_F(off) reinterpret_cast<const float *>(base + (off))
+#define TRI_I(off) reinterpret_cast<const int *>(base + (off))
+    hipLaunchKernelGGL(k_tri_match, dim3((n1 + 3) / 4), dim3(256), 0, st, n1, TRI_F(o_x1), TRI_F(o_y1), TRI_F(o_u1),
+                       base + off_f1, TRI_I(o_n1), base + off_desc1, n2, TRI_F(o_x2), TRI_F(o_y2), TRI_I(o_o2),
+                       TRI_F(o_u2), base + off_f2, TRI_I(o_n2), base + off_desc2, P, d_match);
+    hipLaunchKernelGGL(k_tri_finish, dim3(1), dim3(1024), 0, st, n1, TRI_F(o_a1), TRI_F(o_a2), check_orientation ? 1 : 0,
+                       d_match, d_n);
+#undef TRI_F
+#undef TRI_I
+    ORBGPU_HIP_TRY(hipGetLastError());
+    ORBGPU_HIP_TRY(hipMemcpyAsync(match12, d_match, 4 * w1, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(nmatches, d_n, 4, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipStreamSynchronize(st));
+    return ORBGPU_OK;
 }
 
 } // extern "C"

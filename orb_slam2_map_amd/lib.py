@@ -114,6 +114,8 @@ ABI_SYMBOLS = [
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_vocabulary_create", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_size", "orbgpu_bow_transform",
     "orbgpu_bow_transform_batch_device", "orbgpu_search_by_bow", "orbgpu_search_by_bow_batch_device",
+    "orbgpu_search_by_bow_keyframes", "orbgpu_search_for_triangulation", "orbgpu_fuse", "orbgpu_fuse_sim3",
+    "orbgpu_search_by_sim3",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_insert_device",
     "orbgpu_cloud_last_path", "orbgpu_cloud_set_profiling", "orbgpu_cloud_last_insert_ms", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
@@ -556,6 +558,108 @@ def search_by_projection_sim3(kf_frame, Scw, fx, fy, cx, cy, log_sf, pts, th, kp
     check(lib().orbgpu_search_by_projection_sim3(C.byref(fv), _p(S), fx, fy, cx, cy, log_sf, C.byref(v), int(th), _p(out),
                                                  C.byref(n), device_id))
     return n.value, out
+
+
+# ---- M6: background-thread matchers ---------------------------------------------------------------------------
+_PTS_FIELDS = (("bad", np.uint8), ("world_pos", np.float32), ("normal", np.float32), ("min_dist", np.float32),
+               ("max_dist", np.float32), ("desc", np.uint8))
+
+
+def _points_view(cls, pts):
+    keep = {k: np.ascontiguousarray(pts[k], dt) for k, dt in _PTS_FIELDS}
+    v = cls()
+    v.m = len(keep["bad"])
+    for k in keep:
+        setattr(v, k, _p(keep[k]))
+    return v, keep
+
+
+def fuse(kf_frame, Tcw, fx, fy, cx, cy, bf, log_sf, pts, th, inv_level_sigma2, device_id=0):
+    """Candidate phase of ORBmatcher::Fuse(pKF, vpMapPoints, th) (ORBmatcher.cc:825-975): best_idx per point."""
+    v, keep = _points_view(PointsView, pts)
+    fv = kf_frame.view()
+    T = np.ascontiguousarray(Tcw, np.float32)
+    inv = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    out = np.full(max(v.m, 1), -1, np.int32)
+    n = C.c_int32()
+    L = lib()
+    L.orbgpu_fuse.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                                                            C.c_void_p, C.c_int32]
+    check(L.orbgpu_fuse(C.byref(fv), _p(T), fx, fy, cx, cy, bf, log_sf, C.byref(v), th, _p(inv), _p(out), C.byref(n),
+                        device_id))
+    return n.value, out[:v.m]
+
+
+def fuse_sim3(kf_frame, Scw, fx, fy, cx, cy, log_sf, pts, th, device_id=0):
+    """Candidate phase of ORBmatcher::Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.cc:977-1100)."""
+    v, keep = _points_view(PointsView, pts)
+    fv = kf_frame.view()
+    S = np.ascontiguousarray(Scw, np.float32)
+    out = np.full(max(v.m, 1), -1, np.int32)
+    n = C.c_int32()
+    L = lib()
+    L.orbgpu_fuse_sim3.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 5 + [C.c_void_p, C.c_float, C.c_void_p,
+                                                                                 C.c_void_p, C.c_int32]
+    check(L.orbgpu_fuse_sim3(C.byref(fv), _p(S), fx, fy, cx, cy, log_sf, C.byref(v), th, _p(out), C.byref(n), device_id))
+    return n.value, out[:v.m]
+
+
+def search_by_sim3(kf1, kf2, T1w, T2w, s12, R12, t12, fx, fy, cx, cy, log_sf1, log_sf2, pts1, already1, pts2, already2,
+                   th, device_id=0):
+    """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1102-1326): match12 per key point of key frame 1."""
+    v1, k1 = _points_view(PointsView, pts1)
+    v2, k2 = _points_view(PointsView, pts2)
+    f1, f2 = kf1.view(), kf2.view()
+    A = [np.ascontiguousarray(a, np.float32) for a in (T1w, T2w, R12, t12)]
+    a1 = None if already1 is None else np.ascontiguousarray(already1, np.uint8)
+    a2 = None if already2 is None else np.ascontiguousarray(already2, np.uint8)
+    out = np.full(max(v1.m, 1), -1, np.int32)
+    n = C.c_int32()
+    L = lib()
+    L.orbgpu_search_by_sim3.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p] + [C.c_float] * 6 + \
+        [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p, C.c_int32]
+    check(L.orbgpu_search_by_sim3(C.byref(f1), C.byref(f2), _p(A[0]), _p(A[1]), s12, _p(A[2]), _p(A[3]), fx, fy, cx, cy,
+                                  log_sf1, log_sf2, C.byref(v1), _p(a1), C.byref(v2), _p(a2), th, _p(out), C.byref(n),
+                                  device_id))
+    return n.value, out[:v1.m]
+
+
+def search_for_triangulation(kf1, has_mp1, node1, kf2, has_mp2, node2, F12, ex, ey, level_sigma2_2, only_stereo,
+                             check_ori, device_id=0):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:657-823): match12 per key point of key frame 1."""
+    f1, f2 = kf1.view(), kf2.view()
+    h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+    n1, n2 = np.ascontiguousarray(node1, np.int32), np.ascontiguousarray(node2, np.int32)
+    F = np.ascontiguousarray(F12, np.float32)
+    sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+    out = np.full(max(kf1.n, 1), -1, np.int32)
+    n = C.c_int32()
+    L = lib()
+    L.orbgpu_search_for_triangulation.argtypes = [C.c_void_p] * 7 + [C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
+                                                                     C.c_void_p, C.c_void_p, C.c_int32]
+    check(L.orbgpu_search_for_triangulation(C.byref(f1), _p(h1), _p(n1), C.byref(f2), _p(h2), _p(n2), _p(F), ex, ey,
+                                            _p(sg), int(only_stereo), int(check_ori), _p(out), C.byref(n), device_id))
+    return n.value, out[:kf1.n]
+
+
+def search_by_bow_keyframes(desc1, angle1, valid1, node1, desc2, angle2, valid2, node2, nnratio=0.75, check_ori=True,
+                            device_id=0):
+    """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:522-655): match12 per key point of pKF1."""
+    d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+    a1, a2 = np.ascontiguousarray(angle1, np.float32), np.ascontiguousarray(angle2, np.float32)
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    nd1, nd2 = np.ascontiguousarray(node1, np.int32), np.ascontiguousarray(node2, np.int32)
+    out = np.full(max(len(d1), 1), -1, np.int32)
+    n = C.c_int32()
+    L = lib()
+    L.orbgpu_search_by_bow_keyframes.argtypes = [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_float,
+                                                                                                   C.c_int32, C.c_void_p,
+                                                                                                   C.c_void_p, C.c_int32]
+    check(L.orbgpu_search_by_bow_keyframes(_p(d1), _p(a1), _p(v1), _p(nd1), len(d1), _p(d2), _p(a2), _p(v2), _p(nd2),
+                                           len(d2), nnratio, int(check_ori), _p(out), C.byref(n), device_id))
+    return n.value, out[:len(d1)]
 
 
 class BatchMatcher:
