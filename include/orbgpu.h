@@ -534,6 +534,13 @@ int orbgpu_cloud_insert_device(orbgpu_cloud *h, const float *d_depth, size_t dep
 int orbgpu_cloud_rebuild(orbgpu_cloud *h, int32_t n, const float *const *depth, size_t depth_stride,
                          const uint8_t *const *rgb, size_t rgb_stride, int32_t width, int32_t height, float fx,
                          float fy, float cx, float cy, const float *const *Tcw);
+/* The shutdown pass of PointCloudMapping::viewer (PointCloudMap.cc:270-282): clear the map, then for every key
+ * frame generatePointCloud + voxel.filter of THAT cloud alone + `globalMap += `.  After it the map is a
+ * concatenation of per-key-frame filtered clouds (what optimized_pointcloud.pcd holds before the outlier filter). */
+int orbgpu_cloud_clear(orbgpu_cloud *h);
+int orbgpu_cloud_append_filtered(orbgpu_cloud *h, const float *depth, size_t depth_stride, const uint8_t *rgb,
+                                 size_t rgb_stride, int32_t width, int32_t height, float fx, float fy, float cx,
+                                 float cy, const float *Tcw);
 int orbgpu_cloud_size(orbgpu_cloud *h, int64_t *n);
 /* Global map in ascending voxel-index order (pcl::VoxelGrid output order). */
 int orbgpu_cloud_download(orbgpu_cloud *h, orbgpu_point_xyzrgba *out, int64_t cap, int64_t *n);
@@ -557,6 +564,28 @@ int orbgpu_backproject(const float *depth, size_t depth_stride, const uint8_t *r
 /* pcl::VoxelGrid<PointXYZRGBA>::filter with leaf = (float)resolution (PointCloudMap.cc:41, 240-243). */
 int orbgpu_voxel_filter(const orbgpu_point_xyzrgba *in, int64_t n, double resolution, orbgpu_point_xyzrgba *out,
                         int64_t cap, int64_t *n_out, int32_t *overflow, int32_t device_id);
+
+/* ======================================================================================
+ * On-disk formats of the end-of-run artefacts: host serialisers, byte for byte.
+ * ====================================================================================== */
+/* Map::_WriteMapPoint (Map.cc:123-130): id (u64) + world position (3 x f32) = 20 bytes. */
+size_t orbgpu_mappoint_record_bytes(void);
+int orbgpu_write_mappoint_record(uint64_t id, const float *world_pos, uint8_t *out, size_t cap, size_t *written);
+/* Map::_WriteKeyFrame (Map.cc:133-183): id (u64), time stamp (f64), translation (3 x f32), rotation as the Eigen
+ * quaternion x y z w of Converter::toQuaternion (Converter.cc:137-149, 4 x f32), N (i32), then per key point
+ * x, y, size, angle, response (f32), octave (i32), the 32 descriptor bytes and the index of its map point in the
+ * file's map-point list (u64, ULONG_MAX = none): 64 bytes per key point.  keys = mvKeys (orbgpu_keypoint records
+ * as the extractor writes them). */
+size_t orbgpu_keyframe_record_bytes(int32_t n_features);
+int orbgpu_write_keyframe_record(uint64_t id, double timestamp, const float *Tcw, int32_t n,
+                                 const orbgpu_keypoint *keys, const uint8_t *desc, const uint64_t *mappoint_index,
+                                 uint8_t *out, size_t cap, size_t *written);
+/* pcl::io::savePCDFileBinary of a PointCloud<PointXYZRGBA> (PointCloudMap.cc:287; PCL 1.7 PCDWriter, header text
+ * as recalled -- unpinned): header, then n packed (x, y, z, rgba) records of 16 bytes. */
+int orbgpu_pcd_binary_header(int64_t n_points, char *buf, size_t cap, size_t *len);
+int orbgpu_write_pcd_binary(const char *path, const orbgpu_point_xyzrgba *points, int64_t n);
+/* optimized_pointcloud.pcd without the StatisticalOutlierRemoval pass (out of scope): the handle's map. */
+int orbgpu_cloud_save_pcd(orbgpu_cloud *h, const char *path);
 
 #ifdef __cplusplus
 }

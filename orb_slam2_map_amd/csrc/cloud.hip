@@ -1447,6 +1447,63 @@ int orbgpu_cloud_rebuild(orbgpu_cloud *c, int32_t n, const float *const *depth, 
     return cloud_filter(c, total);
 }
 
+int orbgpu_cloud_clear(orbgpu_cloud *c)
+{
+    ORBGPU_REQUIRE(c, "null argument");
+    c->size = 0;  // globalMap->clear()  (:270)
+    c->sorted_map = false;
+    c->last_overflow = 0;
+    return ORBGPU_OK;
+}
+
+// One iteration of the shutdown loop (PointCloudMap.cc:272-282): generatePointCloud(kf), voxel.filter of THAT cloud
+// alone, globalMap += the result.  The map is a concatenation afterwards (not sorted, not one point per voxel).
+static int cloud_append_filtered_device(orbgpu_cloud *c, const float *d_depth, size_t dstride, const uint8_t *d_rgb,
+                                        size_t cstride, int w, int h, float fx, float fy, float cx, float cy,
+                                        const float *Tcw)
+{
+    int rc;
+    const long long K = c->size;
+    const long long maxnew = (long long)((h + 2) / 3) * ((w + 2) / 3);
+    ORBGPU_REQUIRE(K + maxnew < (1ll << 30), "dense map too large (%lld points)", K + maxnew);
+    if ((rc = cloud_grow(c, c->cur, K + maxnew, K)) != ORBGPU_OK || (rc = cloud_grow(c, c->cur ^ 1, maxnew, 0)) != ORBGPU_OK)
+        return rc;
+    if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK || (rc = c->box.reserve(sizeof(unsigned) * 12)) != ORBGPU_OK)
+        return rc;
+    CloudState *S = c->ws.state.as<CloudState>();
+    Point *scratch = c->map[c->cur ^ 1].as<Point>();
+    if ((rc = backproject_launch(c->fs, d_depth, dstride, d_rgb, cstride, w, h, fx, fy, cx, cy, Tcw, scratch, &S->n_sort,
+                                 nullptr, nullptr, c->stream)) != ORBGPU_OK)
+        return rc;
+    CloudState hs;
+    if ((rc = read_state(c, hs)) != ORBGPU_OK)
+        return rc;
+    rc = voxel_filter_device(c->ws, scratch, hs.n_sort, c->leaf, c->map[c->cur].as<Point>() + K,
+                             c->box.as<unsigned>() + 6 * (c->cur ^ 1), c->stream);
+    if (rc != ORBGPU_OK || (rc = read_state(c, hs)) != ORBGPU_OK)
+        return rc;
+    c->size = K + hs.nout;
+    c->last_overflow = hs.overflow;
+    c->sorted_map = false;
+    c->last_path = 2;
+    return ORBGPU_OK;
+}
+
+int orbgpu_cloud_append_filtered(orbgpu_cloud *c, const float *depth, size_t dstride, const uint8_t *rgb, size_t cstride,
+                                 int32_t w, int32_t h, float fx, float fy, float cx, float cy, const float *Tcw)
+{
+    ORBGPU_REQUIRE(c && Tcw, "null argument");
+    int rc = check_frame_args(depth, dstride, rgb, cstride, w, h);
+    if (rc != ORBGPU_OK)
+        return rc;
+    if ((rc = select_device(c->device_id)) != ORBGPU_OK)
+        return rc;
+    if ((rc = upload_frame(c->fs, depth, dstride, rgb, cstride, w, h, c->stream)) != ORBGPU_OK)
+        return rc;
+    return cloud_append_filtered_device(c, c->fs.depth.as<float>(), (size_t)w, c->fs.rgb.as<uint8_t>(), (size_t)w * 3, w, h,
+                                        fx, fy, cx, cy, Tcw);
+}
+
 int orbgpu_cloud_size(orbgpu_cloud *c, int64_t *n)
 {
     ORBGPU_REQUIRE(c && n, "null argument");

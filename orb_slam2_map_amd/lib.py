@@ -116,8 +116,10 @@ ABI_SYMBOLS = [
     "orbgpu_bow_transform_batch_device", "orbgpu_search_by_bow", "orbgpu_search_by_bow_batch_device",
     "orbgpu_search_by_bow_keyframes", "orbgpu_search_for_triangulation", "orbgpu_fuse", "orbgpu_fuse_sim3",
     "orbgpu_search_by_sim3",
+    "orbgpu_mappoint_record_bytes", "orbgpu_write_mappoint_record", "orbgpu_keyframe_record_bytes",
+    "orbgpu_write_keyframe_record", "orbgpu_pcd_binary_header", "orbgpu_write_pcd_binary", "orbgpu_cloud_save_pcd",
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_insert_device",
-    "orbgpu_cloud_last_path", "orbgpu_cloud_set_profiling", "orbgpu_cloud_last_insert_ms", "orbgpu_cloud_rebuild",
+    "orbgpu_cloud_clear", "orbgpu_cloud_append_filtered", "orbgpu_cloud_last_path", "orbgpu_cloud_set_profiling", "orbgpu_cloud_last_insert_ms", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
     "orbgpu_voxel_filter",
 ]
@@ -691,6 +693,47 @@ class BatchMatcher:
 
 
 # --------------------------------------------------------------------------------------------
+# On-disk formats (Map::Save records, binary PCD)
+# --------------------------------------------------------------------------------------------
+def keyframe_record(kf_id, timestamp, Tcw, keys, desc, mappoint_index):
+    """Bytes of Map::_WriteKeyFrame (Map.cc:133-183). keys: KEYPOINT_DTYPE array, mappoint_index: uint64 (2**64-1 = none)."""
+    L = lib()
+    L.orbgpu_keyframe_record_bytes.restype = C.c_size_t
+    L.orbgpu_keyframe_record_bytes.argtypes = [C.c_int32]
+    L.orbgpu_write_keyframe_record.argtypes = [C.c_uint64, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    keys = np.ascontiguousarray(keys, KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    idx = np.ascontiguousarray(mappoint_index, np.uint64)
+    T = np.ascontiguousarray(Tcw, np.float32)
+    n = len(keys)
+    out = np.zeros(L.orbgpu_keyframe_record_bytes(n), np.uint8)
+    w = C.c_size_t()
+    check(L.orbgpu_write_keyframe_record(kf_id, timestamp, _p(T), n, _p(keys) if n else None, _p(desc) if n else None,
+                                         _p(idx) if n else None, _p(out), len(out), C.byref(w)))
+    return out[:w.value].tobytes()
+
+
+def mappoint_record(mp_id, world_pos):
+    L = lib()
+    L.orbgpu_write_mappoint_record.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    p = np.ascontiguousarray(world_pos, np.float32)
+    out = np.zeros(20, np.uint8)
+    w = C.c_size_t()
+    check(L.orbgpu_write_mappoint_record(mp_id, _p(p), _p(out), 20, C.byref(w)))
+    return out[:w.value].tobytes()
+
+
+def pcd_binary_header(n):
+    L = lib()
+    L.orbgpu_pcd_binary_header.argtypes = [C.c_int64, C.c_char_p, C.c_size_t, C.c_void_p]
+    buf = C.create_string_buffer(512)
+    w = C.c_size_t()
+    check(L.orbgpu_pcd_binary_header(n, buf, 512, C.byref(w)))
+    return buf.raw[:w.value]
+
+
+# --------------------------------------------------------------------------------------------
 # ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, reference include/ORBVocabulary.h)
 # --------------------------------------------------------------------------------------------
 TF_IDF, TF, IDF, BINARY = 0, 1, 2, 3
@@ -816,6 +859,25 @@ class PointCloudMapping:
         v = C.c_float()
         check(self.L.orbgpu_cloud_last_insert_ms(self.h, C.byref(v)))
         return v.value
+
+    def clear(self):
+        self.L.orbgpu_cloud_clear.argtypes = [C.c_void_p]
+        check(self.L.orbgpu_cloud_clear(self.h))
+
+    def appendFiltered(self, depth, rgb, fx, fy, cx, cy, Tcw):
+        """One iteration of the shutdown loop (PointCloudMap.cc:272-282)."""
+        depth = np.ascontiguousarray(depth, np.float32)
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        T = np.ascontiguousarray(Tcw, np.float32)
+        h, w = depth.shape
+        self.L.orbgpu_cloud_append_filtered.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32,
+                                                        C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        check(self.L.orbgpu_cloud_append_filtered(self.h, _p(depth), depth.strides[0] // 4, _p(rgb), rgb.strides[0], w, h,
+                                                  fx, fy, cx, cy, _p(T)))
+
+    def save_pcd(self, path):
+        self.L.orbgpu_cloud_save_pcd.argtypes = [C.c_void_p, C.c_char_p]
+        check(self.L.orbgpu_cloud_save_pcd(self.h, path.encode()))
 
     def last_path(self):
         v = C.c_int32()

@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -113,6 +114,64 @@ template <typename KeyPointT> class ORBextractorT {
     float scaleFactor_ = 0;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
 };
+
+// --------------------------------------------------------------------------------------------
+// ORBVocabulary (reference include/ORBVocabulary.h: DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>)
+// The file readers (loadFromTextFile / loadFromBinaryFile) stay the reference's; after loading, hand the node arrays
+// over once (node i > 0: parent, isLeaf, descriptor row, weight -- m_nodes in index order).
+// --------------------------------------------------------------------------------------------
+typedef std::map<unsigned int, double> BowVector;                      // DBoW2::BowVector
+typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;  // DBoW2::FeatureVector
+
+class ORBVocabularyT {
+  public:
+    ORBVocabularyT(int k, int L, const std::vector<int32_t> &parent, const std::vector<uint8_t> &is_leaf,
+                   const std::vector<uint8_t> &desc, const std::vector<double> &weight, int weighting = 0,
+                   int scoring = 0, int device_id = 0)
+    {
+        check(orbgpu_vocabulary_create(k, L, (int32_t)parent.size(), parent.data(), is_leaf.data(), desc.data(),
+                                       weight.data(), weighting, scoring, device_id, &h_),
+              "ORBVocabulary");
+    }
+    ~ORBVocabularyT() { orbgpu_vocabulary_destroy(h_); }
+    ORBVocabularyT(const ORBVocabularyT &) = delete;
+    ORBVocabularyT &operator=(const ORBVocabularyT &) = delete;
+
+    // void transform(const std::vector<TDescriptor>& features, BowVector &v, FeatureVector &fv, int levelsup) const
+    // (TemplatedVocabulary.h:145-146; Frame::ComputeBoW, Frame.cc:395-402).  descriptors: n rows of 32 bytes.
+    void transform(const uint8_t *descriptors, int n, BowVector &v, FeatureVector &fv, int levelsup) const
+    {
+        v.clear();
+        fv.clear();
+        const size_t m = (size_t)std::max(n, 1);
+        std::vector<int32_t> wid(m), nid(m), bid(m), fvn(m), fvs(m + 1), fvi(m);
+        std::vector<double> wgt(m), bval(m);
+        int32_t nb = 0, nf = 0;
+        check(orbgpu_bow_transform(h_, descriptors, n, levelsup, wid.data(), wgt.data(), nid.data(), bid.data(),
+                                   bval.data(), &nb, fvn.data(), fvs.data(), fvi.data(), &nf),
+              "ORBVocabulary::transform");
+        for (int i = 0; i < nb; i++)
+            v.emplace_hint(v.end(), (unsigned)bid[i], bval[i]);
+        for (int t = 0; t < nf; t++)
+            fv.emplace_hint(fv.end(), (unsigned)fvn[t],
+                            std::vector<unsigned int>(fvi.begin() + fvs[t], fvi.begin() + fvs[t + 1]));
+    }
+    orbgpu_vocabulary *handle() const { return h_; }
+
+  protected:
+    orbgpu_vocabulary *h_ = nullptr;
+};
+
+// per-feature node ids (-1 = not in the vector) from a FeatureVector: what orbgpu_search_by_bow consumes
+inline std::vector<int32_t> NodeIdsOf(const FeatureVector &fv, int n)
+{
+    std::vector<int32_t> node((size_t)std::max(n, 1), -1);
+    for (const auto &kv : fv)
+        for (unsigned int i : kv.second)
+            if ((int)i < n)
+                node[i] = (int32_t)kv.first;
+    return node;
+}
 
 // --------------------------------------------------------------------------------------------
 // ORBmatcher (reference include/ORBmatcher.h:41-106)
@@ -357,6 +416,39 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
         return nmatches;
     }
 
+    // int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint*> &vpMapPointMatches)
+    // (ORBmatcher.h:64, ORBmatcher.cc:159-288; Tracking::TrackReferenceKeyFrame, Tracking.cc:1051).
+    // KeyFrameT: N, mvKeysUn, mFeatVec, GetMapPointMatches(); FrameT: N, mvKeys, mFeatVec.
+    template <typename KeyFrameT, typename KfDescRow, typename DescRow>
+    int SearchByBoW(KeyFrameT *pKF, FrameT &F, std::vector<MapPointT *> &vpMapPointMatches, KfDescRow kf_desc_row,
+                    DescRow desc_row)
+    {
+        const std::vector<MapPointT *> vpMapPointsKF = pKF->GetMapPointMatches();
+        vpMapPointMatches.assign(F.N, nullptr);  // :163
+        const int nk = (int)vpMapPointsKF.size(), nf = F.N;
+        std::vector<uint8_t> dk((size_t)std::max(nk, 1) * 32), df((size_t)std::max(nf, 1) * 32), valid(std::max(nk, 1));
+        std::vector<float> ak(std::max(nk, 1)), af(std::max(nf, 1));
+        for (int i = 0; i < nk; i++) {
+            std::memcpy(&dk[(size_t)i * 32], kf_desc_row(*pKF, i), 32);
+            ak[i] = pKF->mvKeysUn[i].angle;
+            valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();  // :195-199
+        }
+        for (int j = 0; j < nf; j++) {
+            std::memcpy(&df[(size_t)j * 32], desc_row(F, j), 32);
+            af[j] = F.mvKeys[j].angle;  // :238
+        }
+        const std::vector<int32_t> nodek = NodeIdsOf(pKF->mFeatVec, nk), nodef = NodeIdsOf(F.mFeatVec, nf);
+        std::vector<int32_t> match(std::max(nf, 1), -1);
+        int32_t nmatches = 0;
+        check(orbgpu_search_by_bow(dk.data(), ak.data(), valid.data(), nodek.data(), nk, df.data(), af.data(), nodef.data(),
+                                   nf, TH_LOW, mfNNratio, mbCheckOrientation, match.data(), &nmatches, device_),
+              "SearchByBoW");
+        for (int j = 0; j < nf; j++)
+            if (match[j] >= 0)
+                vpMapPointMatches[j] = vpMapPointsKF[match[j]];  // :232
+        return nmatches;
+    }
+
     // void MapPoint::ComputeDistinctiveDescriptors()  (MapPoint.cc:242-307) for a batch of map points: groups[g] holds
     // the descriptor rows of the non-bad observing key frames of point g (in mObservations order); returns the index
     // of the chosen row per point (-1: no observation, mDescriptor stays).
@@ -386,8 +478,21 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
 // PointCloudMapping (reference include/PointCloudMap.h:41-88, src/PointCloudMap.cc)
 // Keeps the reference's thread / condition-variable protocol; the per-key-frame arithmetic runs on
 // the GPU.  KeyFrameT needs mImDep (float depth), mImRGB (8UC3), fx, fy, cx, cy and GetPose();
-// the accessors below adapt cv::Mat (or a stand-in).  Visualisation, StatisticalOutlierRemoval and
-// the PCD writer of the reference stay host-side and are not re-created here.
+// the Adapter adapts cv::Mat (or a stand-in): depth(kf), rgb(kf) -> ImageView, pose(kf, float[16]),
+// fx/fy/cx/cy(kf), and -- only for the loop-closure branch -- id(kf) (mnId) and isBad(kf).
+// Visualisation and StatisticalOutlierRemoval stay out; the PCD writer is
+// orbgpu_cloud_save_pcd.
+//
+// viewer() follows PointCloudMap.cc:182-289 branch by branch:
+//   * wait for key frames (:195-198) -- with a predicate: the reference's bare wait() can lose a wake-up and, woken
+//     by shutdown() with no new key frame, indexes keyframes[N] (:246);
+//   * loop closure (:217-243): when the hook reports LoopClosing::loop_detected (and clears it, :219), the map is
+//     rebuilt from all non-bad key frames of the Map sorted by id;
+//   * otherwise (:244-267) the new key frames are inserted.  The reference transforms only the LAST new cloud with
+//     the pose of the FIRST new key frame (:246-247) and, in the loop branch, does not advance lastKeyframeSize:
+//     setReferenceQuirks(true) reproduces both; by default every new key frame is inserted with its own pose;
+//   * after the loop (:270-288): clear, per key frame generatePointCloud + voxel.filter + `+=`, then (instead of
+//     sor.filter + savePCDFileBinary) the map is written with orbgpu_cloud_save_pcd if an output path is set.
 // --------------------------------------------------------------------------------------------
 struct ImageView {
     const void *data;
@@ -397,8 +502,15 @@ struct ImageView {
 
 template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
   public:
-    PointCloudMappingT(double resolution_, Adapter adapter = Adapter(), int device_id = 0)
-        : resolution(resolution_), adapt(adapter)
+    struct LoopHooks {
+        // returns true once per detected loop: `if (loopCloser->loop_detected) { loopCloser->loop_detected = false; ...`
+        std::function<bool()> take_loop_detected;
+        // loopCloser->getMap()->GetAllKeyFrames()
+        std::function<std::vector<KeyFrameT *>()> all_keyframes;
+    };
+
+    PointCloudMappingT(double resolution_, Adapter adapter = Adapter(), int device_id = 0, LoopHooks hooks_ = LoopHooks())
+        : resolution(resolution_), adapt(adapter), hooks(hooks_)
     {
         check(orbgpu_cloud_create(resolution, device_id, &cloud_), "PointCloudMapping");
         viewerThread = std::make_shared<std::thread>(&PointCloudMappingT::viewer, this);  // PointCloudMap.cc:53
@@ -410,10 +522,30 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
         orbgpu_cloud_destroy(cloud_);
     }
 
+    void setReferenceQuirks(bool on) { quirks = on; }
+    // "optimized_pointcloud.pcd" in the reference (:287); empty (default) = do not write a file
+    void setOutputPath(const std::string &path) { outputPath = path; }
+
     void insertKeyFrame(KeyFrameT *kf)  // PointCloudMap.cc:69-76
     {
         std::unique_lock<std::mutex> lck(keyframeMutex);
         keyframes.push_back(kf);
+        keyFrameUpdated.notify_one();
+    }
+
+    // blocks until the viewer has consumed every key frame / loop notification handed over so far (not in the
+    // reference: there the only way to know is the console output)
+    void waitProcessed()
+    {
+        std::unique_lock<std::mutex> lck(keyframeMutex);
+        processed.wait(lck, [&] { return finished || (!busy && !loopPending && keyframes.size() <= lastKeyframeSize); });
+    }
+
+    // a detected loop must wake the viewer too (the reference relies on the next key frame's notify)
+    void notifyLoop()
+    {
+        std::unique_lock<std::mutex> lck(keyframeMutex);
+        loopPending = true;
         keyFrameUpdated.notify_one();
     }
 
@@ -434,23 +566,72 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
             viewerThread->join();
     }
 
-    void viewer()  // PointCloudMap.cc:182-289, no-loop branch; see rebuild() for the loop-closure branch
+    void viewer()  // PointCloudMap.cc:182-289
     {
         while (true) {
-            {
-                std::unique_lock<std::mutex> lck(keyframeMutex);
-                keyFrameUpdated.wait(lck, [&] { return shutDownFlagLocked() || keyframes.size() > lastKeyframeSize; });
-            }
-            size_t N;
-            {
-                std::unique_lock<std::mutex> lck(keyframeMutex);
-                N = keyframes.size();
-            }
-            for (size_t i = lastKeyframeSize; i < N; i++)
-                insertOne(keyframes[i]);
-            lastKeyframeSize = N;
-            if (shutDownFlagLocked())
+            if (shutDownFlagLocked())  // :186-192
                 break;
+            size_t N, first;
+            {
+                std::unique_lock<std::mutex> lck(keyframeMutex);  // :195-198
+                keyFrameUpdated.wait(lck, [&] { return shutDownFlagLocked() || loopPending || keyframes.size() > lastKeyframeSize; });
+                loopPending = false;
+                busy = true;
+                N = keyframes.size();  // :202-205
+                first = lastKeyframeSize;
+            }
+            size_t done = first;
+            if (hooks.take_loop_detected && hooks.all_keyframes && hooks.take_loop_detected()) {  // :217-243
+                std::vector<KeyFrameT *> all = hooks.all_keyframes();
+                std::sort(all.begin(), all.end(), [&](KeyFrameT *a, KeyFrameT *b) { return adapt.id(a) < adapt.id(b); });
+                std::vector<KeyFrameT *> good;
+                for (KeyFrameT *kf : all)
+                    if (!adapt.isBad(kf))
+                        good.push_back(kf);
+                rebuild(good);
+                if (!quirks)
+                    done = N;  // the reference leaves it (the next pass re-inserts these key frames)
+            } else if (N > first) {  // :244-267
+                if (quirks)
+                    insertOne(keyframeAt(N - 1), keyframeAt(first));  // last cloud, first pose (:246-247)
+                else
+                    for (size_t i = first; i < N; i++)
+                        insertOne(keyframeAt(i), keyframeAt(i));
+                done = N;
+            }
+            {
+                std::unique_lock<std::mutex> lck(keyframeMutex);
+                lastKeyframeSize = done;
+                busy = false;
+                processed.notify_all();
+            }
+        }
+        {
+            std::unique_lock<std::mutex> lck(keyframeMutex);
+            busy = false;
+            finished = true;
+            processed.notify_all();
+        }
+        // :270-288: the down-sampled clouds of all key frames, one by one
+        std::vector<KeyFrameT *> kfs;
+        {
+            std::unique_lock<std::mutex> lck(keyframeMutex);
+            kfs = keyframes;
+        }
+        {
+            std::unique_lock<std::mutex> lck(cloudMutex);
+            check(orbgpu_cloud_clear(cloud_), "PointCloudMapping::shutdown");
+            for (KeyFrameT *kf : kfs) {
+                ImageView d = adapt.depth(kf), c = adapt.rgb(kf);
+                float Tcw[16];
+                adapt.pose(kf, Tcw);
+                check(orbgpu_cloud_append_filtered(cloud_, (const float *)d.data, d.step / sizeof(float),
+                                                   (const uint8_t *)c.data, c.step, d.cols, d.rows, adapt.fx(kf),
+                                                   adapt.fy(kf), adapt.cx(kf), adapt.cy(kf), Tcw),
+                      "PointCloudMapping::shutdown");
+            }
+            if (!outputPath.empty())
+                check(orbgpu_cloud_save_pcd(cloud_, outputPath.c_str()), "PointCloudMapping::save");
         }
     }
 
@@ -496,26 +677,34 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
         std::unique_lock<std::mutex> lck(shutDownMutex);
         return shutDownFlag;
     }
-    void insertOne(KeyFrameT *kf)
+    KeyFrameT *keyframeAt(size_t i)
     {
-        ImageView d = adapt.depth(kf), c = adapt.rgb(kf);
+        std::unique_lock<std::mutex> lck(keyframeMutex);
+        return keyframes[i];
+    }
+    void insertOne(KeyFrameT *image_kf, KeyFrameT *pose_kf)
+    {
+        ImageView d = adapt.depth(image_kf), c = adapt.rgb(image_kf);
         float Tcw[16];
-        adapt.pose(kf, Tcw);
+        adapt.pose(pose_kf, Tcw);
         std::unique_lock<std::mutex> lck(cloudMutex);
         check(orbgpu_cloud_insert(cloud_, (const float *)d.data, d.step / sizeof(float), (const uint8_t *)c.data, c.step,
-                                  d.cols, d.rows, adapt.fx(kf), adapt.fy(kf), adapt.cx(kf), adapt.cy(kf), Tcw),
+                                  d.cols, d.rows, adapt.fx(image_kf), adapt.fy(image_kf), adapt.cx(image_kf),
+                                  adapt.cy(image_kf), Tcw),
               "PointCloudMapping::insertKeyFrame");
     }
 
     orbgpu_cloud *cloud_ = nullptr;
     std::shared_ptr<std::thread> viewerThread;
-    bool shutDownFlag = false;
+    bool shutDownFlag = false, loopPending = false, quirks = false, busy = false, finished = false;
     std::mutex shutDownMutex, keyframeMutex, cloudMutex;
-    std::condition_variable keyFrameUpdated;
+    std::condition_variable keyFrameUpdated, processed;
     std::vector<KeyFrameT *> keyframes;
     size_t lastKeyframeSize = 0;
     double resolution = 0.01;
     Adapter adapt;
+    LoopHooks hooks;
+    std::string outputPath;
 };
 
 } // namespace orbgpu_shim

@@ -37,6 +37,8 @@ struct Frame {  // Frame.h:100-190
     std::vector<float> mvScaleFactors;
     float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0, mb = 0, mfLogScaleFactor = 0;
     float mTcw[16];
+    orbgpu_shim::FeatureVector mFeatVec;
+    orbgpu_shim::BowVector mBowVec;
 };
 
 struct KeyFrame {
@@ -45,6 +47,18 @@ struct KeyFrame {
     int rows = 0, cols = 0;
     float fx = 0, fy = 0, cx = 0, cy = 0;
     float pose[16];
+    long unsigned int mnId = 0;
+    bool bad = false;
+};
+
+struct BowKeyFrame {  // the KeyFrame members SearchByBoW reads (KeyFrame.h)
+    int N = 0;
+    std::vector<KeyPoint> mvKeysUn;
+    std::vector<uint8_t> mDescriptors;
+    std::vector<MapPoint *> mvpMapPoints;
+    orbgpu_shim::FeatureVector mFeatVec;
+    orbgpu_shim::BowVector mBowVec;
+    std::vector<MapPoint *> GetMapPointMatches() const { return mvpMapPoints; }
 };
 struct KFAdapter {
     orbgpu_shim::ImageView depth(KeyFrame *k) const { return {k->mImDep.data(), k->rows, k->cols, (size_t)k->cols * 4}; }
@@ -54,6 +68,8 @@ struct KFAdapter {
     float fy(KeyFrame *k) const { return k->fy; }
     float cx(KeyFrame *k) const { return k->cx; }
     float cy(KeyFrame *k) const { return k->cy; }
+    long unsigned int id(KeyFrame *k) const { return k->mnId; }
+    bool isBad(KeyFrame *k) const { return k->bad; }
 };
 
 template <typename T> static void rd(std::ifstream &f, T *p, size_t n) { f.read(reinterpret_cast<char *>(p), sizeof(T) * n); }
@@ -182,21 +198,91 @@ int main(int argc, char **argv)
             wr(out, best.data(), best.size());
         }
 
-        // ---- point cloud thread protocol
-        KeyFrame kf;
-        kf.mImDep = depth, kf.mImRGB = rgb, kf.rows = h, kf.cols = w;
-        kf.fx = cam[0], kf.fy = cam[1], kf.cx = cam[2], kf.cy = cam[3];
-        std::memcpy(kf.pose, Tcw, 64);
-        std::vector<orbgpu_point_xyzrgba> cloud;
+        // ---- vocabulary + SearchByBoW (TrackReferenceKeyFrame): the scenario's vocabulary, the first n_kf map points
+        //      play the key frame's features (every key point has its map point), the extracted frame is F
         {
-            orbgpu_shim::PointCloudMappingT<KeyFrame, KFAdapter> mapping(0.05);
-            mapping.insertKeyFrame(&kf);
-            mapping.shutdown();
-            cloud = mapping.globalMap();
+            int32_t vk = 0, vL = 0, vn = 0, n_kf = 0;
+            rd(in, &vk, 1), rd(in, &vL, 1), rd(in, &vn, 1), rd(in, &n_kf, 1);
+            std::vector<int32_t> parent(vn);
+            std::vector<uint8_t> leaf(vn), vdesc((size_t)vn * 32);
+            std::vector<double> weight(vn);
+            rd(in, parent.data(), vn), rd(in, leaf.data(), vn), rd(in, vdesc.data(), vdesc.size()), rd(in, weight.data(), vn);
+            orbgpu_shim::ORBVocabularyT voc(vk, vL, parent, leaf, vdesc, weight);
+            BowKeyFrame kfb;
+            kfb.N = n_kf;
+            kfb.mvKeysUn.resize(n_kf);
+            kfb.mDescriptors.resize((size_t)n_kf * 32);
+            kfb.mvpMapPoints.resize(n_kf);
+            for (int i = 0; i < n_kf; i++) {
+                kfb.mvKeysUn[i] = KeyPoint{{0, 0}, 31, 0, 0, 0, -1};
+                std::memcpy(&kfb.mDescriptors[(size_t)i * 32], mps[i].desc, 32);
+                kfb.mvpMapPoints[i] = &mps[i];
+            }
+            voc.transform(kfb.mDescriptors.data(), kfb.N, kfb.mBowVec, kfb.mFeatVec, 2);  // KeyFrame::ComputeBoW
+            voc.transform(F.mDescriptors.data(), F.N, F.mBowVec, F.mFeatVec, 2);          // Frame::ComputeBoW
+            orbgpu_shim::ORBmatcherT<Frame, MapPoint> bm(0.7f, false);
+            std::vector<MapPoint *> vpMatches;
+            const int nb = bm.SearchByBoW(
+                &kfb, F, vpMatches, [](const BowKeyFrame &k, int i) { return &k.mDescriptors[(size_t)i * 32]; }, desc_row);
+            int32_t nb32 = nb, nbow = (int32_t)F.mBowVec.size();
+            wr(out, &nb32, 1);
+            for (int j = 0; j < F.N; j++) {
+                int32_t id = vpMatches[j] ? vpMatches[j]->id : -1;
+                wr(out, &id, 1);
+            }
+            wr(out, &nbow, 1);
+            for (const auto &kv : F.mBowVec) {
+                int32_t w = (int32_t)kv.first;
+                wr(out, &w, 1);
+                wr(out, &kv.second, 1);
+            }
         }
-        int64_t nc = (int64_t)cloud.size();
-        wr(out, &nc, 1);
-        wr(out, cloud.data(), cloud.size());
+
+        // ---- point cloud thread protocol: three key frames (same images, shifted poses), then a loop closure that
+        //      moves every pose, then the shutdown pass
+        std::vector<KeyFrame> kfs(3);
+        for (int i = 0; i < 3; i++) {
+            KeyFrame &kf = kfs[i];
+            kf.mImDep = depth, kf.mImRGB = rgb, kf.rows = h, kf.cols = w;
+            kf.fx = cam[0], kf.fy = cam[1], kf.cx = cam[2], kf.cy = cam[3];
+            std::memcpy(kf.pose, Tcw, 64);
+            kf.pose[3] += 0.25f * (float)i;
+            kf.mnId = 10 - i;  // ids descending: the loop branch sorts by id
+        }
+        // shutdown() right after construction, repeatedly: the wake-up must never be lost (join would hang)
+        for (int rep = 0; rep < 40; rep++) {
+            orbgpu_shim::PointCloudMappingT<KeyFrame, KFAdapter> idle(0.05);
+            idle.shutdown();
+        }
+        bool loop_flag = false;
+        orbgpu_shim::PointCloudMappingT<KeyFrame, KFAdapter>::LoopHooks hooks;
+        hooks.take_loop_detected = [&] { const bool v = loop_flag; loop_flag = false; return v; };
+        hooks.all_keyframes = [&] { return std::vector<KeyFrame *>{&kfs[0], &kfs[1], &kfs[2]}; };
+        auto dump = [&](const std::vector<orbgpu_point_xyzrgba> &c) {
+            int64_t nc = (int64_t)c.size();
+            wr(out, &nc, 1);
+            wr(out, c.data(), c.size());
+        };
+        int64_t nc = 0;
+        {
+            orbgpu_shim::PointCloudMappingT<KeyFrame, KFAdapter> mapping(0.05, KFAdapter(), 0, hooks);
+            for (int i = 0; i < 3; i++) {
+                mapping.insertKeyFrame(&kfs[i]);
+                mapping.waitProcessed();  // one key frame per pass: the reference's common case
+            }
+            dump(mapping.globalMap());
+            for (int i = 0; i < 3; i++)
+                kfs[i].pose[7] -= 0.125f;  // the loop closure corrected the poses
+            kfs[1].bad = true;             // a culled key frame is skipped (:228-229)
+            loop_flag = true;
+            mapping.notifyLoop();
+            mapping.waitProcessed();
+            dump(mapping.globalMap());
+            mapping.shutdown();
+            const std::vector<orbgpu_point_xyzrgba> fin = mapping.globalMap();
+            nc = (int64_t)fin.size();
+            dump(fin);
+        }
         std::printf("shim ok: %d key points, %d projection matches, %lld map points\n", n, nm, (long long)nc);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "shim_test failed: %s\n", e.what());

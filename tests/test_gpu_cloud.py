@@ -292,3 +292,28 @@ def test_cloud_large_frame_and_tiny_frame(gpu, oracle, stream1280):
     want, _ = _oracle_step(oracle, np.zeros(0, oracle.POINT_DTYPE), depth, rgb, (5.0, 5.0, 3.0, 2.0), T, 0.01)
     assert cloud.last_path() == 1 and cloud.download().tobytes() == want.tobytes()
     cloud.close()
+
+
+def test_cloud_shutdown_pass(gpu, oracle, stream640):
+    """PointCloudMapping::viewer after the loop (PointCloudMap.cc:270-282): clear, then per key frame the voxel
+    filter of that key frame's cloud alone, concatenated; a later insert sees an unsorted map (general path)."""
+    camv = cam(stream640)
+    cloud = gpu.PointCloudMapping(0.03)
+    poses = [scenario.rigid(0.01 * i, 0.0, 0.0, (0.2 * i, 0.0, 0.0)) for i in range(3)]
+    frames = [stream640.frame(8 * i) for i in range(3)]
+    for (g, rgb, depth), T in zip(frames, poses):
+        cloud.insertKeyFrame(depth, rgb, *camv, T)
+    cloud.clear()
+    assert cloud.size() == 0
+    want = []
+    for (g, rgb, depth), T in zip(frames, poses):
+        cloud.appendFiltered(depth, rgb, *camv, T)
+        R, t = oracle.pose_inverse(T)
+        v, _ = oracle.voxel_filter(oracle.transform_points(oracle.backproject(depth, rgb, *camv), R, t), 0.03)
+        want.append(v)
+        assert cloud.download().tobytes() == np.concatenate(want).tobytes()
+    g, rgb, depth = stream640.frame(30)
+    cloud.insertKeyFrame(depth, rgb, *camv, poses[1])
+    omap, _ = _oracle_step(oracle, np.concatenate(want), depth, rgb, camv, poses[1], 0.03)
+    assert cloud.last_path() == 2 and cloud.download().tobytes() == omap.tobytes()
+    cloud.close()

@@ -54,6 +54,7 @@ def test_shim_end_to_end(gpu, oracle, stream640):
         px, py = st.offset(t)
         P, _ = scenario.world_points_from_prev(k, dp, (ox - px, oy - py), st, Tcw, rng)
         wp.append(P), dsc.append(d), octv.append(k["octave"])
+    n_first = len(wp[0])  # the map points made from frame t_cur - 1
     wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
     mp = scenario.local_map(oracle, st, Tcw, wp, dsc, octv, sf, rng, obs_zero_frac=0.1)
     # points outside the frustum (or whose predicted level leaves the pyramid: an error for the Sim3 matcher, which the
@@ -77,6 +78,12 @@ def test_shim_end_to_end(gpu, oracle, stream640):
                 f.write(mp["normal"][i].astype("<f4").tobytes())
                 f.write(struct.pack("<2f", float(mp["min_dist"][i]), float(mp["max_dist"][i])))
                 f.write(mp["desc"][i].tobytes())
+            # vocabulary for the SearchByBoW part + how many map points play the key frame's features
+            voc = scenario.synthetic_vocabulary(10, 3, 99)
+            n_kf = n_first
+            f.write(struct.pack("<4i", voc["k"], voc["L"], len(voc["parent"]), n_kf))
+            f.write(voc["parent"].astype("<i4").tobytes()), f.write(voc["is_leaf"].tobytes())
+            f.write(voc["desc"].tobytes()), f.write(voc["weight"].astype("<f8").tobytes())
         r = subprocess.run([exe, scen, outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout
         buf = open(outp, "rb").read()
@@ -113,12 +120,52 @@ def test_shim_end_to_end(gpu, oracle, stream640):
     best = np.frombuffer(buf, np.int32, 3, off)
     off += 12
     assert list(best) == [oracle.distinctive_descriptor(mp["desc"][0::2]), oracle.distinctive_descriptor(mp["desc"][1::2]), -1]
-    nc = struct.unpack_from("<q", buf, off)[0]
-    off += 8
-    cloud = np.frombuffer(buf, oracle.POINT_DTYPE, nc, off)
-    R, t = oracle.pose_inverse(Tcw)
-    ocloud, _ = oracle.voxel_filter(oracle.transform_points(
-        oracle.backproject(depth, rgb, float(st.fx), float(st.fy), float(st.cx), float(st.cy)), R, t), 0.05)
-    assert nc == len(ocloud)
-    for fld in "xyz":
-        assert np.max(np.abs(cloud[fld] - ocloud[fld])) <= 1e-4
+    # vocabulary transform + SearchByBoW through the shim (levelsup 2, ratio 0.7, no orientation check)
+    ov = oracle.Vocabulary(voc["k"], voc["L"], voc["parent"], voc["is_leaf"], voc["desc"], voc["weight"])
+    tk, tf = ov.transform(mp["desc"][:n_kf], 2), ov.transform(od, 2)
+    valid = (mp["bad"][:n_kf] == 0).astype(np.uint8)
+    nbo, mbo = oracle.search_by_bow(mp["desc"][:n_kf], np.zeros(n_kf, np.float32), valid, tk, od, ok["angle"], tf, 50, 0.7,
+                                    False)
+    nb = struct.unpack_from("<i", buf, off)[0]
+    off += 4
+    got = np.frombuffer(buf, np.int32, n, off)
+    off += 4 * n
+    assert nb == nbo and np.array_equal(got, mbo) and nbo > 20, (nb, nbo)
+    nbow = struct.unpack_from("<i", buf, off)[0]
+    off += 4
+    assert nbow == len(tf["bow_ids"])
+    for t in range(nbow):
+        wid, val = struct.unpack_from("<id", buf, off)
+        off += 12
+        assert wid == tf["bow_ids"][t] and val == tf["bow_vals"][t]
+
+    # point cloud thread: three key frames one per pass, a loop closure (poses moved, one key frame culled, key frames
+    # taken in id order = reversed), the shutdown pass
+    camv = (float(st.fx), float(st.fy), float(st.cx), float(st.cy))
+
+    def kf_cloud(T):
+        R, t = oracle.pose_inverse(T)
+        return oracle.transform_points(oracle.backproject(depth, rgb, *camv), R, t)
+
+    def read_cloud(off):
+        nc = struct.unpack_from("<q", buf, off)[0]
+        return np.frombuffer(buf, oracle.POINT_DTYPE, nc, off + 8), off + 8 + 16 * nc
+    poses = []
+    for i in range(3):
+        T = Tcw.astype(np.float32).copy()
+        T[0, 3] = np.float32(T[0, 3] + np.float32(0.25) * np.float32(i))
+        poses.append(T)
+    omap = np.zeros(0, oracle.POINT_DTYPE)
+    for T in poses:
+        omap, _ = oracle.voxel_filter(np.concatenate([omap, kf_cloud(T)]), 0.05)
+    cloud_a, off = read_cloud(off)
+    assert cloud_a.tobytes() == omap.tobytes(), "three inserts through the viewer thread"
+    for T in poses:
+        T[1, 3] = np.float32(T[1, 3] - np.float32(0.125))
+    oreb, _ = oracle.voxel_filter(np.concatenate([kf_cloud(poses[2]), kf_cloud(poses[0])]), 0.05)  # ids 8, (9 bad), 10
+    cloud_b, off = read_cloud(off)
+    assert cloud_b.tobytes() == oreb.tobytes(), "loop-closure rebuild: non-bad key frames in id order"
+    ofin = np.concatenate([oracle.voxel_filter(kf_cloud(T), 0.05)[0] for T in poses])
+    cloud_c, off = read_cloud(off)
+    assert cloud_c.tobytes() == ofin.tobytes(), "shutdown pass: per-key-frame filtered clouds, concatenated"
+    assert off == len(buf)
