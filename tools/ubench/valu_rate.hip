@@ -16,7 +16,9 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 enum Op { ADD_U32, ADD_F32, FMA_F32, PK_FMA_F32, MIN_I32, PK_MIN_I16, PK_SUB_I16, PERM, XOR_BCNT, DOT4, DOT2, PK_MAX3_F16,
-          ALIGNBIT, ALIGNBYTE, MUL_LO, MUL_U24, MAX3_I32 };
+          ALIGNBIT, ALIGNBYTE, MUL_LO, MUL_U24, MAX3_I32,
+          S_MIN_I32, S_MAX3_I32, S_PERM, S_PK_MIN_I16, S_PK_MAX3_F16, S_PK_MIN3_F16, S_BCNT, S_XOR, S_AND, S_ALIGNBIT, S_DOT4,
+          S_MAD_U32_U24, S_PK_SUB_I16 };
 
 template <int OP> __global__ void k(unsigned *out, int iters)
 {
@@ -49,6 +51,20 @@ template <int OP> __global__ void k(unsigned *out, int iters)
                 if (OP == PK_MAX3_F16) { pkh v = __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(pkh, x & 0x00FF00FFu), __builtin_bit_cast(pkh, y & 0x00FF00FFu)), __builtin_bit_cast(pkh, a[(i + 5) & 7] & 0x00FF00FFu)); a[i] = __builtin_bit_cast(unsigned, v) + 1; }
                 if (OP == ALIGNBIT) a[i] = __builtin_amdgcn_alignbit(x, y, 16) + 1;
                 if (OP == ALIGNBYTE) a[i] = __builtin_amdgcn_alignbyte(x, y, 3) + 1;
+                // single-instruction rows (inline asm, one instruction per step)
+                if (OP == S_MIN_I32) asm volatile("v_min_i32 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_MAX3_I32) asm volatile("v_max3_i32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_PERM) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(x), "v"(y), "v"(0x0c020c00u));
+                if (OP == S_PK_MIN_I16) asm volatile("v_pk_min_i16 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_PK_SUB_I16) asm volatile("v_pk_sub_i16 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_PK_MAX3_F16) asm volatile("v_pk_maximum3_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_PK_MIN3_F16) asm volatile("v_pk_minimum3_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_BCNT) asm volatile("v_bcnt_u32_b32 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_XOR) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_AND) asm volatile("v_and_b32 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_ALIGNBIT) asm volatile("v_alignbit_b32 %0, %1, %2, 16" : "=v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_DOT4) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                if (OP == S_MAD_U32_U24) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
                 if (OP == MUL_LO) asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
                 if (OP == MUL_U24) asm volatile("v_mul_u32_u24 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
                 if (OP == MAX3_I32) a[i] = (unsigned)max(max((int)x, (int)y), (int)a[(i + 5) & 7]) + 1;
@@ -94,6 +110,20 @@ int main()
     run<XOR_BCNT>("v_xor + v_bcnt (carries the add)", 2);
     run<DOT4>("v_dot4_u32_u8 (carries the add)", 1);
     run<DOT2>("v_dot2_u32_u16 (carries the add)", 1);
+    printf("-- the same instructions alone (inline asm, one per step)\n");
+    run<S_XOR>("v_xor_b32", 1);
+    run<S_AND>("v_and_b32", 1);
+    run<S_MIN_I32>("v_min_i32", 1);
+    run<S_MAX3_I32>("v_max3_i32", 1);
+    run<S_PK_MIN_I16>("v_pk_min_i16", 1);
+    run<S_PK_SUB_I16>("v_pk_sub_i16", 1);
+    run<S_PK_MAX3_F16>("v_pk_maximum3_f16", 1);
+    run<S_PK_MIN3_F16>("v_pk_minimum3_f16", 1);
+    run<S_PERM>("v_perm_b32", 1);
+    run<S_ALIGNBIT>("v_alignbit_b32", 1);
+    run<S_BCNT>("v_bcnt_u32_b32", 1);
+    run<S_DOT4>("v_dot4_u32_u8", 1);
+    run<S_MAD_U32_U24>("v_mad_u32_u24", 1);
     run<MUL_LO>("v_mul_lo_u32", 1);
     run<MUL_U24>("v_mul_u32_u24", 1);
     return 0;
