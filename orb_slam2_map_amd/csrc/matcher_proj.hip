@@ -371,7 +371,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
                                                        int row_angle_stride,
                                                        const float *__restrict__ kp_angle, int check_orientation,
                                                        int *__restrict__ kp_to_mp, int *__restrict__ nmatches,
-                                                       int *__restrict__ sweeps_out)
+                                                       int *__restrict__ sweeps_out, int novf)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int histo[ORBGPU_HISTO_LENGTH];
@@ -380,10 +380,23 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n = F.n_dev ? min(max(*F.n_dev, 0), F.n) : F.n;
     const int kp_angle_stride = F.kp_stride;
-    int *claimA = reinterpret_cast<int *>(smem);
-    int *claimB = claimA + n;
+    // LDS: [first four list words of the rows beyond the register budget (novf x 16 B)] [claimA n] [claimB n]
+    //      [their latest decision (novf x 4 B)] [their flags (novf B)]; the host sized novf to what fits
+    uint4 *ovf_w = reinterpret_cast<uint4 *>(smem);
+    int *claimA = reinterpret_cast<int *>(smem + (size_t)novf * 16);
+    int *claimB = claimA + F.n;
+    int *ovf_res = claimB + F.n;
+    uint8_t *ovf_flag = reinterpret_cast<uint8_t *>(ovf_res + novf);
     for (int j = tid; j < n; j += nt)
         claimA[j] = claim_init[j];
+    for (int o = tid; o < novf; o += nt) {
+        const int i = PJ_RC * nt + o;
+        const Query Q = q[i];
+        ovf_flag[o] = (uint8_t)((Q.active ? 1 : 0) | (Q.blocking ? 2 : 0));
+        ovf_w[o] = Q.active ? *reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST)
+                            : make_uint4(PJ_NONE, PJ_NONE, PJ_NONE, PJ_NONE);
+        ovf_res[o] = -2;
+    }
     for (int i = tid; i < m; i += nt)
         match[i] = -2;
     // register-resident rows: r-th row of this thread is i = r * nt + tid
@@ -441,7 +454,31 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
             if (result >= 0 && (cblk & (1u << r)))
                 atomicMin(&claimB[result], i);
         }
-        for (int i = PJ_RC * nt + tid; i < m; i += nt) {  // rows beyond the register budget
+        for (int o = tid; o < novf; o += nt) {  // rows beyond the register budget, cached in LDS
+            const int i = PJ_RC * nt + o;
+            int result = -1;
+            const uint8_t fl = ovf_flag[o];
+            if (fl & 1) {
+                const uint4 v = ovf_w[o];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                bool decided;
+                result = pj_decide<MODE>(w, lists, i, claimA, nnratio, th_dist, decided);
+                if (!decided) {
+                    slow[atomicAdd(&s_nslow, 1)] = i;
+                    ovf_res[o] = -3;  // decided by the wave-cooperative walk: re-read match[] next sweep
+                    continue;
+                }
+            }
+            const int before = ovf_res[o] == -3 ? match[i] : ovf_res[o];
+            if (before != result) {
+                changed = true;
+                match[i] = result;
+            }
+            ovf_res[o] = result;
+            if (result >= 0 && (fl & 2))
+                atomicMin(&claimB[result], i);
+        }
+        for (int i = PJ_RC * nt + novf + tid; i < m; i += nt) {  // ... and whatever LDS could not hold
             int result = -1;
             const Query Q = q[i];
             if (Q.active) {
@@ -559,6 +596,17 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
         sweeps_out[0] = sweeps;
         sweeps_out[1] = rewalked;
     }
+}
+
+// LDS of k_proj_resolve: two claim tables (8 B per key point slot) + 21 B per row cached beyond the register budget
+constexpr size_t PJ_RESOLVE_MAX_LDS = 150 * 1024;
+static inline size_t resolve_lds(int m, int ncap, int *novf)
+{
+    const size_t base = (size_t)8 * ncap;
+    const int over = std::max(m - PJ_RC * 1024, 0);
+    const int fit = base < PJ_RESOLVE_MAX_LDS ? (int)((PJ_RESOLVE_MAX_LDS - base) / 21) : 0;
+    *novf = std::min(over, fit);
+    return base + (size_t)*novf * 21 + 16;
 }
 
 // ---- host side -----------------------------------------------------------------------------
@@ -688,17 +736,19 @@ static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vecto
     static thread_local bool attr_set = false;
     if (!attr_set) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
         attr_set = true;
     }
     hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws.queries.as<Query>(),
                        ws.row_desc.as<uint8_t>(), F, ws.topk.as<uint32_t>());
-    hipLaunchKernelGGL(k_proj_resolve<MODE>, dim3(1), dim3(1024), (size_t)8 * n, st, m, ws.queries.as<Query>(),
+    int novf = 0;
+    const size_t lds = resolve_lds(m, n, &novf);
+    hipLaunchKernelGGL(k_proj_resolve<MODE>, dim3(1), dim3(1024), lds, st, m, ws.queries.as<Query>(),
                        ws.row_desc.as<uint8_t>(), F, nnratio, th_dist, ws.claim_init.as<int>(), ws.topk.as<uint32_t>(),
                        ws.match.as<int>(), ws.slow.as<int>(), ws.row_angle.as<float>(), 1, ws.kp_angle.as<float>(),
-                       check_orientation, ws.k2m.as<int>(), ws.out.as<int>(), ws.out.as<int>() + 1);
+                       check_orientation, ws.k2m.as<int>(), ws.out.as<int>(), ws.out.as<int>() + 1, novf);
     ORBGPU_HIP_TRY(hipGetLastError());
     ORBGPU_HIP_TRY(hipMemcpyAsync(kp_to_mp, ws.k2m.p, sizeof(int) * n, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipMemcpyAsync(nmatches, ws.out.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1186,7 +1236,7 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     static thread_local bool attr_set = false;
     if (!attr_set) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
         attr_set = true;
     }
     orbgpu_track_scratch none{};
@@ -1196,10 +1246,12 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
                        ws->claim_init.as<int>(), d_track ? *d_track : none, d_counts + 1);
     hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws->queries.as<Query>(), mp->desc, F,
                        ws->topk.as<uint32_t>());
-    hipLaunchKernelGGL(k_proj_resolve<0>, dim3(1), dim3(1024), (size_t)8 * cap, st, m, ws->queries.as<Query>(), mp->desc,
+    int novf = 0;
+    const size_t lds = resolve_lds(m, cap, &novf);
+    hipLaunchKernelGGL(k_proj_resolve<0>, dim3(1), dim3(1024), lds, st, m, ws->queries.as<Query>(), mp->desc,
                        F, nnratio, (int)ORBGPU_TH_HIGH, ws->claim_init.as<int>(), ws->topk.as<uint32_t>(),
                        ws->match.as<int>(), ws->slow.as<int>(), (const float *)nullptr, 1, (const float *)nullptr, 0,
-                       d_kp_to_mp, d_counts, ws->out.as<int>() + 1);
+                       d_kp_to_mp, d_counts, ws->out.as<int>() + 1, novf);
     ORBGPU_HIP_TRY(hipGetLastError());
     return ORBGPU_OK;
 }
@@ -1270,7 +1322,7 @@ int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur,
     static thread_local bool attr_set = false;
     if (!attr_set) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
         attr_set = true;
     }
     const int cover = std::max(m, cap);
@@ -1280,11 +1332,13 @@ int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur,
                        d_kp_to_mp, ws->claim_init.as<int>(), d_counts + 1);
     hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws->queries.as<Query>(), last->desc, F,
                        ws->topk.as<uint32_t>());
-    hipLaunchKernelGGL(k_proj_resolve<1>, dim3(1), dim3(1024), (size_t)8 * cap, st, m, ws->queries.as<Query>(),
+    int novf = 0;
+    const size_t lds = resolve_lds(m, cap, &novf);
+    hipLaunchKernelGGL(k_proj_resolve<1>, dim3(1), dim3(1024), lds, st, m, ws->queries.as<Query>(),
                        last->desc, F, 0.f, (int)ORBGPU_TH_HIGH, ws->claim_init.as<int>(), ws->topk.as<uint32_t>(),
                        ws->match.as<int>(), ws->slow.as<int>(), reinterpret_cast<const float *>(last->kps) + 3, kstride,
                        reinterpret_cast<const float *>(cur->kps) + 3, check_orientation ? 1 : 0, d_kp_to_mp, d_counts,
-                       ws->out.as<int>() + 1);
+                       ws->out.as<int>() + 1, novf);
     ORBGPU_HIP_TRY(hipGetLastError());
     return ORBGPU_OK;
 }
