@@ -375,7 +375,7 @@ def main():
             out["roofline"]["practical_peak"] = {"copy_kernel_GB/s": copy_gbs, "frac_of_practical": ach / copy_gbs,
                                                  "what": "16 B/lane device-to-device copy, 1 GiB, read + write bytes"}
             out["secondary"] = {}
-            for name, fn in (("c3", workloads.c3), ("c4", workloads.c4)):
+            for name, fn in (("c3", workloads.c3), ("c3_batch", workloads.c3_batch), ("c4", workloads.c4)):
                 try:
                     r = fn(device_id=local_rank)
                     r.pop("per_keyframe", None)

@@ -289,6 +289,21 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
                                       int32_t *d_kp_to_mp, int32_t *d_counts, const orbgpu_track_scratch *d_track,
                                       int32_t device_id, void *hip_stream);
 
+/* The same for n independent problems (one per sequence: frames shard by sequence) in four launches:
+ * the claim fixpoint of one frame is one workgroup by construction, so many sequences are what fills the device.
+ * Every problem has its own frame, map-point table, pose and outputs; cos_limit / th / nnratio are shared. */
+typedef struct orbgpu_local_points_problem {
+    const orbgpu_device_frame_view *frame;
+    const orbgpu_device_mappoint_table *table;
+    const float *Tcw;                     /* HOST 4x4 row-major float */
+    float fx, fy, cx, cy, mbf, log_scale_factor;
+    int32_t *d_kp_to_mp;                  /* device [frame->cap] in/out */
+    int32_t *d_counts;                    /* device [2] */
+    const orbgpu_track_scratch *d_track;  /* optional */
+} orbgpu_local_points_problem;
+int orbgpu_search_local_points_batch_device(int32_t n, const orbgpu_local_points_problem *problems, float cos_limit,
+                                            float th, float nnratio, int32_t device_id, void *hip_stream);
+
 /* Device-resident ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
  * (ORBmatcher.cc:1328-1470; Tracking::TrackWithMotionModel, Tracking.cc:1169/1175): the per-frame matcher of
  * RGB-D tracking.  cur = the frame that never left the device; last = the previous frame's key points (octave and

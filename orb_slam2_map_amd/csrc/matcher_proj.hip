@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstring>
 #include <cmath>
 #include <vector>
 
@@ -83,11 +84,11 @@ __device__ __forceinline__ void top4_insert64(uint64_t t[4], uint64_t k)
 // whose ascending order is exactly the order in which the sequential loop would prefer candidates.
 // `claim` == nullptr: no claim filtering (pass 1); otherwise key points with claim[idx] < i are hidden.
 // sink(key, octave) is called by the lane that found the candidate.
-template <class Sink>
+template <int LPR = 64, class Sink>
 __device__ __forceinline__ void proj_walk_each(const Query &Q, const uint64_t a[4], const FrameDev &F,
                                                const int *claim, int i, Sink &&sink)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & (LPR - 1);  // LPR lanes share a row (a whole wave, or 16 lanes in pass 1)
     const int c0 = (int)floorf((Q.x - F.min_x - Q.r) * F.inv_w);
     const int c1 = (int)ceilf((Q.x - F.min_x + Q.r) * F.inv_w);
     const int r0 = (int)floorf((Q.y - F.min_y - Q.r) * F.inv_h);
@@ -99,7 +100,7 @@ __device__ __forceinline__ void proj_walk_each(const Query &Q, const uint64_t a[
     const int ny = maxCy - minCy + 1;
     const int ncell = (maxCx - minCx + 1) * ny;
     const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
-    for (int seq = lane; seq < ncell; seq += 64) {
+    for (int seq = lane; seq < ncell; seq += LPR) {
         const int ix = minCx + seq / ny, iy = minCy + seq % ny;
         const int cell = ix * GR + iy;
         const int beg = F.cell_start[cell], end = F.cell_start[cell + 1];
@@ -189,15 +190,20 @@ __device__ __forceinline__ int pj_oct(uint32_t w) { return (int)((w >> 23) & 0xF
 
 // Pass 1: one wave per row walks the window once (no claim filter), drops every candidate into LDS, ranks them
 // by key and writes the PJ_LIST best as 32-bit words.
-__global__ __launch_bounds__(256) void k_proj_lists(int m, const Query *__restrict__ q,
-                                                    const uint8_t *__restrict__ row_desc, FrameDev F,
-                                                    uint32_t *__restrict__ lists)
+// A window holds a handful of grid cells with about one key point each, so 16 lanes per row (16 rows per
+// workgroup) keep the lanes busy; a whole wave per row left 55 of 64 lanes idle (C3: 14 -> see DESIGN.md).
+constexpr int PJ_LPR = 16;
+constexpr int PJ_ROWS_PER_BLOCK = 256 / PJ_LPR;
+
+__device__ __forceinline__ void proj_lists_body(int m, const Query *__restrict__ q,
+                                                const uint8_t *__restrict__ row_desc, const FrameDev &F,
+                                                uint32_t *__restrict__ lists)
 {
-    __shared__ uint64_t s_key[4][PJ_WBUF];
-    __shared__ uint32_t s_word[4][PJ_WBUF];
-    __shared__ int s_cnt[4];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + w;
+    __shared__ uint64_t s_key[PJ_ROWS_PER_BLOCK][PJ_WBUF];
+    __shared__ uint32_t s_word[PJ_ROWS_PER_BLOCK][PJ_WBUF];
+    __shared__ int s_cnt[PJ_ROWS_PER_BLOCK];
+    const int lane = threadIdx.x & (PJ_LPR - 1), w = threadIdx.x / PJ_LPR;
+    const int i = blockIdx.x * PJ_ROWS_PER_BLOCK + w;
     if (lane == 0)
         s_cnt[w] = 0;
     __syncthreads();
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void k_proj_lists(int m, const Query *__restri
         if (Q.active) {
             const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
             const uint64_t a[4] = {da[0], da[1], da[2], da[3]};
-            proj_walk_each(Q, a, F, nullptr, i, [&](uint64_t key, int oct) {
+            proj_walk_each<PJ_LPR>(Q, a, F, nullptr, i, [&](uint64_t key, int oct) {
                 const int slot = atomicAdd(&s_cnt[w], 1);
                 if (slot < PJ_WBUF) {
                     s_key[w][slot] = key;
@@ -222,20 +228,28 @@ __global__ __launch_bounds__(256) void k_proj_lists(int m, const Query *__restri
     uint32_t *out = lists + (size_t)i * PJ_LIST;
     const int total = s_cnt[w];
     if (total > PJ_WBUF) {
-        if (lane < PJ_LIST)
-            out[lane] = PJ_REWALK;
+        for (int c = lane; c < PJ_LIST; c += PJ_LPR)
+            out[c] = PJ_REWALK;
         return;
     }
-    if (lane < total) {
-        const uint64_t key = s_key[w][lane];
+    for (int c = lane; c < total; c += PJ_LPR) {
+        const uint64_t key = s_key[w][c];
         int rank = 0;
         for (int j = 0; j < total; j++)
             rank += s_key[w][j] < key ? 1 : 0;  // keys are unique (they carry the key point index)
         if (rank < PJ_LIST)
-            out[rank] = s_word[w][lane];
-    } else if (lane < PJ_LIST) {
-        out[lane] = PJ_NONE;
+            out[rank] = s_word[w][c];
     }
+    for (int c = lane; c < PJ_LIST; c += PJ_LPR)
+        if (c >= total)
+            out[c] = PJ_NONE;
+}
+
+__global__ __launch_bounds__(256) void k_proj_lists(int m, const Query *__restrict__ q,
+                                                    const uint8_t *__restrict__ row_desc, FrameDev F,
+                                                    uint32_t *__restrict__ lists)
+{
+    proj_lists_body(m, q, row_desc, F, lists);
 }
 
 // accept rule.  mode 0: ORBmatcher.cc:114-125 (TH_HIGH, ratio test only on equal levels);
@@ -362,8 +376,8 @@ __device__ __forceinline__ int pj_decide(const uint32_t w0[4], const uint32_t *_
 // match[] (global) always holds the latest decision of every row; the owner thread mirrors it in a register
 // for its cached rows and stores only when the decision changes.
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__restrict__ q,
-                                                       const uint8_t *__restrict__ row_desc, FrameDev F,
+__device__ __forceinline__ void proj_resolve_body(int m, const Query *__restrict__ q,
+                                                       const uint8_t *__restrict__ row_desc, const FrameDev &F,
                                                        float nnratio, int th_dist,
                                                        const int *__restrict__ claim_init,
                                                        const uint32_t *__restrict__ lists, int *__restrict__ match,
@@ -598,6 +612,22 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__restrict__ q,
+                                                       const uint8_t *__restrict__ row_desc, FrameDev F,
+                                                       float nnratio, int th_dist,
+                                                       const int *__restrict__ claim_init,
+                                                       const uint32_t *__restrict__ lists, int *__restrict__ match,
+                                                       int *__restrict__ slow, const float *__restrict__ row_angle,
+                                                       int row_angle_stride,
+                                                       const float *__restrict__ kp_angle, int check_orientation,
+                                                       int *__restrict__ kp_to_mp, int *__restrict__ nmatches,
+                                                       int *__restrict__ sweeps_out, int novf)
+{
+    proj_resolve_body<MODE>(m, q, row_desc, F, nnratio, th_dist, claim_init, lists, match, slow, row_angle,
+                            row_angle_stride, kp_angle, check_orientation, kp_to_mp, nmatches, sweeps_out, novf);
+}
+
 // LDS of k_proj_resolve: two claim tables (8 B per key point slot) + 21 B per row cached beyond the register budget
 constexpr size_t PJ_RESOLVE_MAX_LDS = 150 * 1024;
 static inline size_t resolve_lds(int m, int ncap, int *novf)
@@ -617,7 +647,7 @@ struct ProjWorkspace {
     int device = -1;
     hipStream_t stream = nullptr;
     DevBuf kp_x, kp_y, kp_octave, u_right, desc, cell_start, cell_items, kp_angle;
-    DevBuf queries, row_desc, row_angle, claim_init, topk, match, slow, k2m, out, inv_sigma2, tri;
+    DevBuf queries, row_desc, row_angle, claim_init, topk, match, slow, k2m, out, inv_sigma2, tri, problems, sweeps;
     ~ProjWorkspace()
     {
         // device memory is released with the process; the HIP runtime may already be gone here
@@ -741,7 +771,7 @@ static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vecto
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws.queries.as<Query>(),
+    hipLaunchKernelGGL(k_proj_lists, dim3((m + PJ_ROWS_PER_BLOCK - 1) / PJ_ROWS_PER_BLOCK), dim3(256), 0, st, m, ws.queries.as<Query>(),
                        ws.row_desc.as<uint8_t>(), F, ws.topk.as<uint32_t>());
     int novf = 0;
     const size_t lds = resolve_lds(m, n, &novf);
@@ -795,15 +825,15 @@ struct FrustumParams {
 // Thread i < m: Frame::isInFrustum (Frame.cc:269-325) + MapPoint::PredictScale (MapPoint.cc:385-394) for map
 // point i, then the query row of ORBmatcher::SearchByProjection (:45-137: radius by viewing cosine, levels
 // [l-1, l]).  Thread j < cap: the claim table entry of key point j from the incoming association.
-__global__ __launch_bounds__(256) void k_frustum_queries(int m, const float *__restrict__ world_pos,
+__device__ __forceinline__ void frustum_queries_body(int m, const float *__restrict__ world_pos,
                                                          const float *__restrict__ normal,
                                                          const float *__restrict__ min_dist,
                                                          const float *__restrict__ max_dist,
                                                          const uint8_t *__restrict__ skip,
-                                                         const uint8_t *__restrict__ obs_pos, FrustumParams P,
+                                                         const uint8_t *__restrict__ obs_pos, const FrustumParams &P,
                                                          Query *__restrict__ q, int cap,
                                                          const int *__restrict__ kp_to_mp, int *__restrict__ claim_init,
-                                                         orbgpu_track_scratch out, int *__restrict__ bad_levels)
+                                                         const orbgpu_track_scratch &out, int *__restrict__ bad_levels)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cap) {
@@ -884,6 +914,71 @@ __global__ __launch_bounds__(256) void k_frustum_queries(int m, const float *__r
         if (out.view_cos)
             out.view_cos[i] = view_cos;
     }
+}
+
+__global__ __launch_bounds__(256) void k_frustum_queries(int m, const float *__restrict__ world_pos,
+                                                         const float *__restrict__ normal,
+                                                         const float *__restrict__ min_dist,
+                                                         const float *__restrict__ max_dist,
+                                                         const uint8_t *__restrict__ skip,
+                                                         const uint8_t *__restrict__ obs_pos, FrustumParams P,
+                                                         Query *__restrict__ q, int cap,
+                                                         const int *__restrict__ kp_to_mp, int *__restrict__ claim_init,
+                                                         orbgpu_track_scratch out, int *__restrict__ bad_levels)
+{
+    frustum_queries_body(m, world_pos, normal, min_dist, max_dist, skip, obs_pos, P, q, cap, kp_to_mp, claim_init, out,
+                         bad_levels);
+}
+
+// ---- many independent SearchLocalPoints problems (one per sequence) in three launches ------------------------
+// The claim fixpoint of one frame is one workgroup by construction; independent sequences (the unit of
+// sharding) fill the device: blockIdx.y (queries, lists) / blockIdx.x (resolve) selects the problem.
+struct ProjProblem {
+    int m, cap, novf, pad;
+    const float *world_pos, *normal, *min_dist, *max_dist;
+    const uint8_t *desc, *skip, *obs_pos;
+    FrustumParams P;
+    FrameDev F;
+    Query *q;
+    int *kp_to_mp, *claim_init, *counts, *match, *slow, *sweeps;
+    uint32_t *lists;
+    float nnratio;
+    orbgpu_track_scratch track;
+};
+
+__global__ void k_batch_zero_counts(const ProjProblem *__restrict__ problems, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        problems[i].counts[0] = 0;
+        problems[i].counts[1] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_frustum_queries_batch(const ProjProblem *__restrict__ problems)
+{
+    const ProjProblem &p = problems[blockIdx.y];
+    if ((int)(blockIdx.x * blockDim.x) >= max(p.m, p.cap))
+        return;
+    frustum_queries_body(p.m, p.world_pos, p.normal, p.min_dist, p.max_dist, p.skip, p.obs_pos, p.P, p.q, p.cap,
+                         p.kp_to_mp, p.claim_init, p.track, p.counts + 1);
+}
+
+__global__ __launch_bounds__(256) void k_proj_lists_batch(const ProjProblem *__restrict__ problems)
+{
+    const ProjProblem &p = problems[blockIdx.y];
+    if ((int)(blockIdx.x * PJ_ROWS_PER_BLOCK) >= p.m)
+        return;
+    proj_lists_body(p.m, p.q, p.desc, p.F, p.lists);
+}
+
+__global__ __launch_bounds__(1024) void k_proj_resolve_batch(const ProjProblem *__restrict__ problems)
+{
+    const ProjProblem &p = problems[blockIdx.x];
+    if (p.m <= 0)
+        return;
+    proj_resolve_body<0>(p.m, p.q, p.desc, p.F, p.nnratio, (int)ORBGPU_TH_HIGH, p.claim_init, p.lists, p.match, p.slow,
+                         (const float *)nullptr, 1, (const float *)nullptr, 0, p.kp_to_mp, p.counts, p.sweeps, p.novf);
 }
 
 // ---- device-resident ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (:1328-1470) --------
@@ -1244,7 +1339,7 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     hipLaunchKernelGGL(k_frustum_queries, dim3((cover + 255) / 256), dim3(256), 0, st, m, mp->world_pos, mp->normal,
                        mp->min_dist, mp->max_dist, mp->skip, mp->obs_pos, P, ws->queries.as<Query>(), cap, d_kp_to_mp,
                        ws->claim_init.as<int>(), d_track ? *d_track : none, d_counts + 1);
-    hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws->queries.as<Query>(), mp->desc, F,
+    hipLaunchKernelGGL(k_proj_lists, dim3((m + PJ_ROWS_PER_BLOCK - 1) / PJ_ROWS_PER_BLOCK), dim3(256), 0, st, m, ws->queries.as<Query>(), mp->desc, F,
                        ws->topk.as<uint32_t>());
     int novf = 0;
     const size_t lds = resolve_lds(m, cap, &novf);
@@ -1330,7 +1425,7 @@ int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur,
     hipLaunchKernelGGL(k_project_last_queries, dim3((cover + 255) / 256), dim3(256), 0, st, m, last->n, last->kps,
                        last->has_mp, last->outlier, last->obs_pos, last->world_pos, P, ws->queries.as<Query>(), cap,
                        d_kp_to_mp, ws->claim_init.as<int>(), d_counts + 1);
-    hipLaunchKernelGGL(k_proj_lists, dim3((m + 3) / 4), dim3(256), 0, st, m, ws->queries.as<Query>(), last->desc, F,
+    hipLaunchKernelGGL(k_proj_lists, dim3((m + PJ_ROWS_PER_BLOCK - 1) / PJ_ROWS_PER_BLOCK), dim3(256), 0, st, m, ws->queries.as<Query>(), last->desc, F,
                        ws->topk.as<uint32_t>());
     int novf = 0;
     const size_t lds = resolve_lds(m, cap, &novf);
@@ -1339,6 +1434,113 @@ int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur,
                        ws->match.as<int>(), ws->slow.as<int>(), reinterpret_cast<const float *>(last->kps) + 3, kstride,
                        reinterpret_cast<const float *>(cur->kps) + 3, check_orientation ? 1 : 0, d_kp_to_mp, d_counts,
                        ws->out.as<int>() + 1, novf);
+    ORBGPU_HIP_TRY(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+int orbgpu_search_local_points_batch_device(int32_t n, const orbgpu_local_points_problem *problems, float cos_limit,
+                                            float th, float nnratio, int32_t device_id, void *hip_stream)
+{
+    ORBGPU_REQUIRE(n >= 0 && (n == 0 || problems), "bad arguments");
+    int rc = select_device(device_id);
+    if (rc != ORBGPU_OK || n == 0)
+        return rc;
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    size_t tot_m = 0, tot_cap = 0;
+    int max_m = 0, max_cover = 0;
+    size_t lds = 0;
+    std::vector<int> novfs((size_t)n);
+    for (int k = 0; k < n; k++) {
+        const orbgpu_local_points_problem &pr = problems[k];
+        const orbgpu_device_frame_view *f = pr.frame;
+        const orbgpu_device_mappoint_table *mp = pr.table;
+        ORBGPU_REQUIRE(f && mp && pr.Tcw && pr.d_kp_to_mp && pr.d_counts, "problem %d: null argument", k);
+        ORBGPU_REQUIRE(f->cap >= 1 && f->cap <= 16384, "problem %d: frame capacity out of range (max 16384)", k);
+        ORBGPU_REQUIRE(f->n && f->kps && f->desc && f->u_right && f->cell_start && f->cell_items, "problem %d: null frame arrays", k);
+        ORBGPU_REQUIRE(f->nlevels >= 1 && f->nlevels <= ORBGPU_MAX_LEVELS && f->scale_factors, "problem %d: bad scale factors", k);
+        ORBGPU_REQUIRE(f->max_x > f->min_x && f->max_y > f->min_y, "problem %d: empty image bounds", k);
+        ORBGPU_REQUIRE(mp->m >= 0 && mp->m < (1 << 20), "problem %d: bad map point count", k);
+        if (mp->m > 0)
+            ORBGPU_REQUIRE(mp->world_pos && mp->normal && mp->min_dist && mp->max_dist && mp->desc, "problem %d: null map point arrays", k);
+        tot_m += (size_t)std::max(mp->m, 1);
+        tot_cap += (size_t)f->cap;
+        max_m = std::max(max_m, mp->m);
+        max_cover = std::max(max_cover, std::max(mp->m, f->cap));
+        lds = std::max(lds, resolve_lds(mp->m, f->cap, &novfs[k]));
+    }
+    PJ_TRY(ws->queries.reserve(sizeof(Query) * tot_m));
+    PJ_TRY(ws->claim_init.reserve(sizeof(int) * tot_cap));
+    PJ_TRY(ws->topk.reserve(sizeof(uint32_t) * PJ_LIST * tot_m));
+    PJ_TRY(ws->match.reserve(sizeof(int) * tot_m));
+    PJ_TRY(ws->slow.reserve(sizeof(int) * tot_m));
+    PJ_TRY(ws->sweeps.reserve(sizeof(int) * 2 * (size_t)n));
+    PJ_TRY(ws->problems.reserve(sizeof(ProjProblem) * (size_t)n));
+    PJ_TRY(ws->out.reserve(4 * sizeof(int)));
+    std::vector<ProjProblem> hp((size_t)n);
+    size_t om = 0, oc = 0;
+    for (int k = 0; k < n; k++) {
+        const orbgpu_local_points_problem &pr = problems[k];
+        const orbgpu_device_frame_view *f = pr.frame;
+        const orbgpu_device_mappoint_table *mp = pr.table;
+        ProjProblem &P = hp[k];
+        memset(&P, 0, sizeof(P));
+        P.m = mp->m, P.cap = f->cap, P.novf = novfs[k];
+        P.world_pos = mp->world_pos, P.normal = mp->normal, P.min_dist = mp->min_dist, P.max_dist = mp->max_dist;
+        P.desc = mp->desc, P.skip = mp->skip, P.obs_pos = mp->obs_pos;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++)
+                P.P.T[4 * r + c] = pr.Tcw[4 * r + c];
+        minus_rt_t(pr.Tcw, P.P.Ow);
+        P.P.fx = pr.fx, P.P.fy = pr.fy, P.P.cx = pr.cx, P.P.cy = pr.cy, P.P.mbf = pr.mbf;
+        P.P.min_x = f->min_x, P.P.max_x = f->max_x, P.P.min_y = f->min_y, P.P.max_y = f->max_y;
+        P.P.log_sf = pr.log_scale_factor, P.P.cos_limit = cos_limit, P.P.th = th;
+        P.P.nlevels = f->nlevels;
+        for (int l = 0; l < ORBGPU_MAX_LEVELS; l++)
+            P.P.scale_factors[l] = l < f->nlevels ? f->scale_factors[l] : 0.f;
+        P.F.n = f->cap;
+        P.F.n_dev = f->n;
+        P.F.kp_stride = (int)(sizeof(orbgpu_keypoint) / sizeof(float));
+        P.F.kp_x = reinterpret_cast<const float *>(f->kps);
+        P.F.kp_y = P.F.kp_x + 1;
+        P.F.kp_octave = reinterpret_cast<const int *>(f->kps) + 5;
+        P.F.u_right = f->u_right;
+        P.F.desc = f->desc;
+        P.F.min_x = f->min_x, P.F.min_y = f->min_y;
+        P.F.inv_w = (float)GC / (f->max_x - f->min_x);
+        P.F.inv_h = (float)GR / (f->max_y - f->min_y);
+        P.F.cell_start = f->cell_start, P.F.cell_items = f->cell_items;
+        P.F.inv_sigma2 = nullptr;
+        P.q = ws->queries.as<Query>() + om;
+        P.lists = ws->topk.as<uint32_t>() + om * PJ_LIST;
+        P.match = ws->match.as<int>() + om;
+        P.slow = ws->slow.as<int>() + om;
+        P.claim_init = ws->claim_init.as<int>() + oc;
+        P.sweeps = ws->sweeps.as<int>() + 2 * (size_t)k;
+        P.kp_to_mp = pr.d_kp_to_mp;
+        P.counts = pr.d_counts;
+        P.nnratio = nnratio;
+        if (pr.d_track)
+            P.track = *pr.d_track;
+        om += (size_t)std::max(mp->m, 1);
+        oc += (size_t)f->cap;
+    }
+    ORBGPU_HIP_TRY(hipMemcpyAsync(ws->problems.p, hp.data(), sizeof(ProjProblem) * (size_t)n, hipMemcpyHostToDevice, st));
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve_batch),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
+        attr_set = true;
+    }
+    const ProjProblem *dp = ws->problems.as<ProjProblem>();
+    hipLaunchKernelGGL(k_batch_zero_counts, dim3((n + 255) / 256), dim3(256), 0, st, dp, n);
+    if (max_m > 0) {
+        hipLaunchKernelGGL(k_frustum_queries_batch, dim3((max_cover + 255) / 256, n), dim3(256), 0, st, dp);
+        hipLaunchKernelGGL(k_proj_lists_batch, dim3((max_m + PJ_ROWS_PER_BLOCK - 1) / PJ_ROWS_PER_BLOCK, n), dim3(256), 0, st, dp);
+        hipLaunchKernelGGL(k_proj_resolve_batch, dim3(n), dim3(1024), lds, st, dp);
+    }
     ORBGPU_HIP_TRY(hipGetLastError());
     return ORBGPU_OK;
 }

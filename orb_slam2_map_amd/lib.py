@@ -75,6 +75,12 @@ class DeviceMapPointTable(C.Structure):
                 ("max_dist", C.c_void_p), ("desc", C.c_void_p), ("skip", C.c_void_p), ("obs_pos", C.c_void_p)]
 
 
+class LocalPointsProblem(C.Structure):
+    _fields_ = [("frame", C.c_void_p), ("table", C.c_void_p), ("Tcw", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("mbf", C.c_float), ("log_scale_factor", C.c_float),
+                ("d_kp_to_mp", C.c_void_p), ("d_counts", C.c_void_p), ("d_track", C.c_void_p)]
+
+
 class DeviceLastFrameView(C.Structure):
     _fields_ = [("cap", C.c_int32), ("n", C.c_void_p), ("kps", C.c_void_p), ("has_mp", C.c_void_p),
                 ("outlier", C.c_void_p), ("obs_pos", C.c_void_p), ("world_pos", C.c_void_p), ("desc", C.c_void_p)]
@@ -110,7 +116,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
-    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_search_by_projection_last_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
+    "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_search_local_points_batch_device", "orbgpu_search_by_projection_last_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_vocabulary_create", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_size", "orbgpu_bow_transform",
     "orbgpu_bow_transform_batch_device", "orbgpu_search_by_bow", "orbgpu_search_by_bow_batch_device",
@@ -385,6 +391,28 @@ def search_local_points_device(frame_view, table, Tcw, fx, fy, cx, cy, mbf, log_
     check(lib().orbgpu_search_local_points_device(C.byref(frame_view), C.byref(table), _p(T), fx, fy, cx, cy, mbf, log_sf,
                                                   cos_limit, th, nnratio, d_kp_to_mp, d_counts,
                                                   C.byref(track) if track is not None else None, device_id, stream))
+
+
+def search_local_points_batch_device(problems, cos_limit, th, nnratio, stream=0, device_id=0):
+    """n independent Tracking::SearchLocalPoints problems in one call (orbgpu_search_local_points_batch_device).
+    problems: list of dicts with frame (DeviceFrameView), table (DeviceMapPointTable), Tcw (4x4), fx, fy, cx, cy, mbf,
+    log_sf, d_kp_to_mp, d_counts (device pointers)."""
+    n = len(problems)
+    arr = (LocalPointsProblem * max(n, 1))()
+    keep = []
+    for k, p in enumerate(problems):
+        T = np.ascontiguousarray(p["Tcw"], np.float32)
+        keep.append(T)
+        arr[k].frame = C.addressof(p["frame"])
+        arr[k].table = C.addressof(p["table"])
+        arr[k].Tcw = T.ctypes.data
+        arr[k].fx, arr[k].fy, arr[k].cx, arr[k].cy, arr[k].mbf = p["fx"], p["fy"], p["cx"], p["cy"], p["mbf"]
+        arr[k].log_scale_factor = p["log_sf"]
+        arr[k].d_kp_to_mp, arr[k].d_counts, arr[k].d_track = p["d_kp_to_mp"], p["d_counts"], None
+    L = lib()
+    L.orbgpu_search_local_points_batch_device.argtypes = [C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                                          C.c_void_p]
+    check(L.orbgpu_search_local_points_batch_device(n, arr, cos_limit, th, nnratio, device_id, stream))
 
 
 def search_by_projection_last_device(cur_view, cur_Tcw, last_view, last_Tcw, fx, fy, cx, cy, mbf, mb, th, mono, check_ori,

@@ -158,6 +158,121 @@ def c3(reps=30, device_id=0):
                                  "algorithmic_bytes": alg_ext, "note": "single frame: 16 dependent launches"}}
 
 
+def c3_batch(n_seq=128, reps=10, device_id=0):
+    """C3 in throughput mode: n_seq independent sequences (frames shard by sequence), one 1280x960 frame each per step:
+    batched extraction + frame glue + orbgpu_search_local_points_batch_device.  Every sequence has its own copy of the
+    frame, of the ~10 k-point map table and of all outputs (distinct addresses); the content is the C3 scenario."""
+    import torch
+    W, H, NF = 1280, 960, 2000
+    rng = np.random.default_rng(5678)
+    st = Stream(W, H, 1234)
+    nprev, t_cur = 5, 12
+    ts = [t_cur - 1 - i for i in range(nprev)] + [t_cur]
+    frames = [st.frame(t) for t in ts]
+    ext = G.ORBextractor(NF, max_batch=n_seq, device_id=device_id)
+    ks, ds = ext.extract_batch(np.stack([f[0] for f in frames]))
+    sf = ext.GetScaleFactors()
+    Tcw = rigid()
+    ox, oy = st.offset(t_cur)
+    wp, dsc, octv = [], [], []
+    for i, t in enumerate(ts[:-1]):
+        px, py = st.offset(t)
+        wp.append(_world_points(ks[i], frames[i][2], (ox - px, oy - py), st, Tcw, rng))
+        dsc.append(ds[i]), octv.append(ks[i]["octave"])
+    wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
+    tab = local_map_table(wp, dsc, octv, sf, Tcw, rng)
+    M = len(wp)
+    dev = "cuda:%d" % device_id
+    B = n_seq
+    img = torch.from_numpy(frames[-1][0]).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+    depth = torch.from_numpy(frames[-1][2]).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+    cap = ext.max_keypoints(W, H)
+    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    nout = torch.zeros(B, dtype=torch.int32, device=dev)
+    ur, dz = (torch.zeros((B, cap), dtype=torch.float32, device=dev) for _ in range(2))
+    cs = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device=dev)
+    items = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    dtab = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev).unsqueeze(0).repeat(*([B] + [1] * v.ndim)).contiguous()
+            for k, v in tab.items()}
+    k2m = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+    counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    sfa = np.asarray(sf, np.float32)
+    log_sf = float(np.log(np.float32(sfa[1])))
+    cam = G.make_camera(float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), W, H)
+    problems, keep = [], []
+    for b in range(B):
+        fv = G.DeviceFrameView()
+        fv.cap, fv.n, fv.kps, fv.desc = cap, nout[b:].data_ptr(), kps[b].data_ptr(), desc[b].data_ptr()
+        fv.u_right, fv.cell_start, fv.cell_items = ur[b].data_ptr(), cs[b].data_ptr(), items[b].data_ptr()
+        fv.nlevels, fv.scale_factors = len(sfa), sfa.ctypes.data
+        fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(W), 0.0, float(H)
+        tb = G.DeviceMapPointTable()
+        tb.m = M
+        for k in dtab:
+            setattr(tb, k, dtab[k][b].data_ptr())
+        keep.append((fv, tb))
+        problems.append({"frame": fv, "table": tb, "Tcw": Tcw, "fx": float(st.fx), "fy": float(st.fy), "cx": float(st.cx),
+                         "cy": float(st.cy), "mbf": float(st.bf), "log_sf": log_sf, "d_kp_to_mp": k2m[b].data_ptr(),
+                         "d_counts": counts[b].data_ptr()})
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+
+    def extract_glue():
+        ext.extract_batch_device(img.data_ptr(), B, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), s)
+        G.frame_glue_batch_device(B, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), W, W * H, cam, None,
+                                  ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s, device_id)
+
+    def search():
+        G.search_local_points_batch_device(problems, 0.5, 3.0, 0.8, stream=s, device_id=device_id)
+
+    def timed(fn, pre=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot = 0.0
+        for _ in range(reps):
+            if pre:
+                pre()
+            e0.record(stream)
+            fn()
+            e1.record(stream)
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / reps
+
+    extract_glue()
+    k2m.fill_(-1)
+    search()
+    torch.cuda.synchronize()
+    cnt = counts.cpu().numpy()
+    assert (cnt[:, 0] == cnt[0, 0]).all() and cnt[0, 0] > 0, "identical problems must give identical match counts"
+    N = int(nout[0])
+    ms_search = timed(search, pre=lambda: k2m.fill_(-1))
+    ext.set_profiling(True)
+    ms_extract = timed(extract_glue)
+    stages = ext.stage_times()
+    ext.set_profiling(False)
+    ms_chain = timed(lambda: (extract_glue(), search()), pre=lambda: k2m.fill_(-1))
+    alg_m2 = (M * 60 + N * 48 + 20292 + (M + N) * 4) * B
+    px = [1228800, 853600, 592963, 411996, 285671, 198404, 138138, 95676]
+    alg_ext = (sum(px[:-1]) + sum(px[1:]) + sum(px) + 2 * sum(px) + N * 1321) * B
+    ach_s = alg_m2 / (ms_search * 1e-3) / 1e9
+    ach_e = alg_ext / (ms_extract * 1e-3) / 1e9
+    return {"workload": "C3 throughput mode: %d independent sequences, one synthetic 1280x960 frame each per step, 2000 "
+                        "features, batched extract + glue + isInFrustum + SearchByProjection(th=3) of %d map points per "
+                        "sequence, device resident" % (B, M),
+            "sequences": B, "keypoints": N, "map_points": M, "matches_per_frame": int(cnt[0, 0]),
+            "search_ms": ms_search, "extract_glue_ms": ms_extract, "step_ms": ms_chain, "frames_per_s": B * 1e3 / ms_chain,
+            "extract_stage_ms": {k: round(v, 4) for k, v in stages.items()},
+            "roofline": {"bound": "hbm", "kernel": "extraction stages at 1280x960 (20.3 MB/frame)", "achieved": ach_e,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_e / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": alg_ext, "ms_per_launch": ms_extract},
+            "search_roofline": {"bound": "hbm", "kernel": "k_frustum_queries_batch + k_proj_lists_batch + k_proj_resolve_batch",
+                                "achieved": ach_s, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_s / HBM_PEAK_GBS,
+                                "algorithmic_bytes": alg_m2, "ms_per_launch": ms_search,
+                                "note": "one workgroup per sequence runs the claim fixpoint: latency bound per problem, "
+                                        "parallel across sequences"}}
+
+
 def c4(nkf=24, device_id=0, leaf=0.01):
     """C4: 640x480 key frames: extract + BF match against the previous key frame + dense-map insert (stride-3
     back-projection, transform, voxel filter of map + new points at 0.01 m), images resident in HBM."""

@@ -496,3 +496,78 @@ def test_search_by_projection_last_frame_device_resident(gpu, oracle, th, mono, 
     got = k2m.cpu().numpy()[:n1]
     assert c[1] == 0
     assert c[0] == no and np.array_equal(got, ko), "%d vs %d, %d differ" % (c[0], no, int((got != ko).sum()))
+
+
+def test_search_local_points_batch_of_sequences(gpu, oracle):
+    """orbgpu_search_local_points_batch_device: several independent (frame, local map, pose) problems in one call --
+    different sequences, different map sizes (incl. an empty map) -- each equal to the single-problem entry point and
+    to the oracle."""
+    torch = pytest.importorskip("torch")
+    from orb_slam2_map_amd.synth import Stream
+    w, h, nfeat = 640, 480, 1000
+    specs = [(1234, 12, 3, 0.0), (2234, 9, 1, 0.3), (3234, 15, 4, 0.1), (4234, 7, 0, 0.0)]  # seed, t_cur, prev frames, obs0
+    ge = gpu.ORBextractor(nfeat, max_batch=1)
+    cap = ge.max_keypoints(w, h)
+    sf = np.asarray(ge.GetScaleFactors(), np.float32)
+    log_sf = float(np.log(np.float32(sf[1])))
+    s = torch.cuda.current_stream().cuda_stream
+    problems, keep, expect = [], [], []
+    for seed, t_cur, nprev, obs0 in specs:
+        rng = np.random.default_rng(seed)
+        st = Stream(w, h, seed)
+        ts = [t_cur - 1 - i for i in range(nprev)] + [t_cur]
+        frames = [st.frame(t) for t in ts]
+        gb = gpu.ORBextractor(nfeat, max_batch=len(ts))
+        ks, ds = gb.extract_batch(np.stack([f[0] for f in frames]))
+        Tcw = scenario.rigid(0.01 + 0.001 * t_cur, -0.02, 0.015, (0.03, -0.02, 0.05))
+        ox, oy = st.offset(t_cur)
+        wp, dsc, octv = [np.zeros((0, 3), np.float32)], [np.zeros((0, 32), np.uint8)], [np.zeros(0, np.int32)]
+        for i, t in enumerate(ts[:-1]):
+            px, py = st.offset(t)
+            P, _ = scenario.world_points_from_prev(ks[i], frames[i][2], (ox - px, oy - py), st, Tcw, rng)
+            wp.append(P), dsc.append(ds[i]), octv.append(ks[i]["octave"])
+        wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
+        mp = scenario.local_map(oracle, st, Tcw, wp, dsc, octv, sf, rng, obs0, vary=True)
+        m = len(wp)
+        of = scenario.make_frame(oracle, ks[-1], ds[-1], frames[-1][2], st, sf)
+        k0 = np.full(of.n, -1, np.int32)
+        no, ko = oracle.search_by_projection(of, mp, 3.0, 0.8, k0) if m else (0, k0)
+        expect.append((no, ko, of.n))
+        img = torch.from_numpy(frames[-1][0][None]).cuda()
+        depth = torch.from_numpy(frames[-1][2][None]).cuda()
+        kps = torch.zeros((1, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda")
+        nout = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ge.extract_batch_device(img.data_ptr(), 1, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), s)
+        ur, dz = (torch.zeros((1, cap), dtype=torch.float32, device="cuda") for _ in range(2))
+        cs = torch.zeros((1, 64 * 48 + 1), dtype=torch.int32, device="cuda")
+        items = torch.zeros((1, cap), dtype=torch.int32, device="cuda")
+        cam = gpu.make_camera(float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), w, h)
+        gpu.frame_glue_batch_device(1, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), w, w * h, cam, None,
+                                    ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s)
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in
+               (("world_pos", wp if m else np.zeros((1, 3), np.float32)), ("normal", mp["normal"] if m else np.zeros((1, 3), np.float32)),
+                ("min_dist", mp["min_dist"] if m else np.zeros(1, np.float32)), ("max_dist", mp["max_dist"] if m else np.zeros(1, np.float32)),
+                ("desc", mp["desc"] if m else np.zeros((1, 32), np.uint8)), ("skip", mp["bad"] if m else np.zeros(1, np.uint8)),
+                ("obs_pos", mp["obs_pos"] if m else np.ones(1, np.uint8)))}
+        fv = gpu.DeviceFrameView()
+        fv.cap, fv.n, fv.kps, fv.desc, fv.u_right = cap, nout.data_ptr(), kps.data_ptr(), desc.data_ptr(), ur.data_ptr()
+        fv.cell_start, fv.cell_items, fv.nlevels, fv.scale_factors = cs.data_ptr(), items.data_ptr(), len(sf), sf.ctypes.data
+        fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(w), 0.0, float(h)
+        tb = gpu.DeviceMapPointTable()
+        tb.m = m
+        for k in dev:
+            setattr(tb, k, dev[k].data_ptr())
+        k2m = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+        counts = torch.full((2,), 77, dtype=torch.int32, device="cuda")
+        problems.append({"frame": fv, "table": tb, "Tcw": Tcw, "fx": float(st.fx), "fy": float(st.fy), "cx": float(st.cx),
+                         "cy": float(st.cy), "mbf": float(st.bf), "log_sf": log_sf, "d_kp_to_mp": k2m.data_ptr(),
+                         "d_counts": counts.data_ptr()})
+        keep.append((img, depth, kps, desc, nout, ur, dz, cs, items, dev, k2m, counts, fv, tb))
+    gpu.search_local_points_batch_device(problems, 0.5, 3.0, 0.8, stream=s)
+    torch.cuda.synchronize()
+    for (no, ko, n), kp in zip(expect, keep):
+        k2m, counts = kp[10], kp[11]
+        c = counts.cpu().numpy()
+        assert c[0] == no and np.array_equal(k2m.cpu().numpy()[:n], ko), (c, no)
+    assert expect[0][0] > 50 and expect[3][0] == 0
