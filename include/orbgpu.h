@@ -136,6 +136,9 @@ int orbgpu_extractor_debug_read(orbgpu_extractor *h, int32_t what, int32_t frame
  * boundaries of every call made while profiling is enabled (up to 256 calls per window; enabling and
  * disabling keeps the window, so a caller may profile a sample of its calls).
  * Names are returned by orbgpu_extractor_stage_name(i); count by orbgpu_extractor_stage_count(). */
+/* The host entry points (orbgpu_extract, orbgpu_extract_batch) replay their launch sequence as a hipGraph from the
+ * third call of a configuration on: *state = 1 graph in use, 0 not captured yet, -1 capture failed (plain launches). */
+int orbgpu_extractor_graph_state(const orbgpu_extractor *h, int32_t *state);
 int orbgpu_extractor_set_profiling(orbgpu_extractor *h, int32_t enable);
 int orbgpu_extractor_stage_count(void);
 const char *orbgpu_extractor_stage_name(int32_t i);

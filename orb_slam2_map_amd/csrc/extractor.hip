@@ -1458,6 +1458,11 @@ struct orbgpu_extractor {
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // PROF_SLOTS * 2 * ST_COUNT slots (ST_COUNT + 1 boundary events used per call), created lazily
     int prof_calls = 0;
+    // host entry points: the 17-launch sequence is captured once per (size, batch, buffers) and replayed as a hipGraph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_key = 0;
+    int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
 
 };
 
@@ -1923,6 +1928,10 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
     for (auto &x : e->ev)
         if (x)
             (void)hipEventDestroy(x);
+    if (e->graph_exec)
+        (void)hipGraphExecDestroy(e->graph_exec);
+    if (e->graph)
+        (void)hipGraphDestroy(e->graph);
     if (e->stream)
         (void)hipStreamDestroy(e->stream);
     delete e;
@@ -2018,11 +2027,70 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch
     for (int f = 0; f < batch; f++)
         ORBGPU_HIP_TRY(hipMemcpy2DAsync(e->d_in.as<uint8_t>() + img * f, (size_t)w, gray + frame_stride * f, stride,
                                         (size_t)w, (size_t)h, hipMemcpyHostToDevice, e->stream));
-    rc = orbgpu_extract_batch_device(e, e->d_in.as<uint8_t>(), batch, w, h, (size_t)w, img,
-                                     e->d_kps.as<orbgpu_keypoint>(), e->d_desc.as<uint8_t>(), cap,
-                                     e->d_nout.as<int32_t>(), e->stream);
-    if (rc != ORBGPU_OK)
+    // Single frames are launch bound (17 dependent launches for 0.3 MB): replay them as one hipGraph.  The graph bakes
+    // in the handle-owned buffers, so it is keyed on them and on the geometry; a first call of a configuration runs
+    // plain (it may allocate), the second captures.  Profiling (events between stages) and capture failures fall
+    // back to plain launches.
+    if ((rc = configure(e, w, h, std::max(batch, e->prm.max_batch))) != ORBGPU_OK)
         return rc;
+    if ((rc = e->d_aux.reserve(sizeof(KpAux) * (size_t)cap * batch)) != ORBGPU_OK)
+        return rc;
+    uint64_t key = 1469598103934665603ull;
+    for (uint64_t v : {(uint64_t)w, (uint64_t)h, (uint64_t)batch, (uint64_t)cap, (uint64_t)(uintptr_t)e->d_in.p,
+                       (uint64_t)(uintptr_t)e->d_kps.p, (uint64_t)(uintptr_t)e->d_desc.p, (uint64_t)(uintptr_t)e->d_nout.p,
+                       (uint64_t)(uintptr_t)e->d_pyr.p, (uint64_t)(uintptr_t)e->d_aux.p, (uint64_t)(uintptr_t)e->d_sel.p})
+        key = (key ^ v) * 1099511628211ull;
+    bool launched = false;
+    if (!e->profiling && e->graph_state >= 0) {
+        if (e->graph_exec && e->graph_key == key) {
+            if (hipGraphLaunch(e->graph_exec, e->stream) == hipSuccess)
+                launched = true;
+            else
+                e->graph_state = -1;
+        } else if (e->graph_key == key) {  // second call of this configuration: capture
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const int lrc = launch_pipeline(e, e->d_in.as<uint8_t>(), batch, w, h, (size_t)w, img,
+                                                e->d_kps.as<orbgpu_keypoint>(), e->d_desc.as<uint8_t>(), cap,
+                                                e->d_nout.as<int32_t>(), e->stream);
+                ok = hipStreamEndCapture(e->stream, &g) == hipSuccess && lrc == ORBGPU_OK && g;
+            }
+            if (ok)
+                ok = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+            if (ok) {
+                if (e->graph_exec)
+                    (void)hipGraphExecDestroy(e->graph_exec);
+                if (e->graph)
+                    (void)hipGraphDestroy(e->graph);
+                e->graph = g;
+                e->graph_exec = ge;
+                e->graph_state = 1;
+                ok = hipGraphLaunch(e->graph_exec, e->stream) == hipSuccess;
+                launched = ok;
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                if (g && g != e->graph)
+                    (void)hipGraphDestroy(g);
+                e->graph_state = -1;
+            }
+        } else {
+            e->graph_key = key;  // first call of a new configuration: plain launches, capture next time
+            if (e->graph_exec) {
+                (void)hipGraphExecDestroy(e->graph_exec);
+                e->graph_exec = nullptr;
+            }
+        }
+    }
+    if (!launched) {
+        rc = orbgpu_extract_batch_device(e, e->d_in.as<uint8_t>(), batch, w, h, (size_t)w, img,
+                                         e->d_kps.as<orbgpu_keypoint>(), e->d_desc.as<uint8_t>(), cap,
+                                         e->d_nout.as<int32_t>(), e->stream);
+        if (rc != ORBGPU_OK)
+            return rc;
+    }
     ORBGPU_HIP_TRY(hipMemcpyAsync(n_out, e->d_nout.p, sizeof(int) * batch, hipMemcpyDeviceToHost, e->stream));
     ORBGPU_HIP_TRY(hipStreamSynchronize(e->stream));
     for (int f = 0; f < batch; f++) {
@@ -2119,6 +2187,12 @@ int orbgpu_extractor_set_profiling(orbgpu_extractor *e, int32_t enable)
 {
     ORBGPU_REQUIRE(e, "null argument");
     e->profiling = enable != 0;  // the averaging window is kept: stage_times() reads and resets it
+    return ORBGPU_OK;
+}
+int orbgpu_extractor_graph_state(const orbgpu_extractor *e, int32_t *state)
+{
+    ORBGPU_REQUIRE(e && state, "null argument");
+    *state = e->graph_state;
     return ORBGPU_OK;
 }
 int orbgpu_extractor_stage_count(void) { return ST_COUNT; }

@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_get_inv_scale_factors", "orbgpu_extractor_get_sigma2", "orbgpu_extractor_get_inv_sigma2",
     "orbgpu_extractor_get_quotas", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
     "orbgpu_extract_batch_device", "orbgpu_extractor_get_pyramid_level", "orbgpu_extractor_debug_read",
-    "orbgpu_extractor_set_profiling", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
+    "orbgpu_extractor_graph_state", "orbgpu_extractor_set_profiling", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
@@ -328,6 +328,12 @@ class ORBextractor:
         if what in (DBG_PYRAMID_PADDED, DBG_BLURRED_PADDED):
             return buf[:n.value].copy(), aux.value
         return buf[:n.value * 12].view(np.int32).reshape(-1, 3).copy(), 0
+
+    def graph_state(self):
+        v = C.c_int32()
+        self.L.orbgpu_extractor_graph_state.argtypes = [C.c_void_p, C.c_void_p]
+        check(self.L.orbgpu_extractor_graph_state(self.h, C.byref(v)))
+        return v.value
 
     def set_profiling(self, on):
         check(self.L.orbgpu_extractor_set_profiling(self.h, int(on)))

@@ -263,3 +263,25 @@ def test_pyramid_getter(gpu, oracle, stream640):
                                                           C.byref(h_)))
         assert (w_.value, h_.value) == (ww, hh)
         assert np.array_equal(dst, op[19:19 + hh, 19:19 + ww])
+
+
+def test_host_entry_replays_a_graph(gpu, oracle, stream640):
+    """orbgpu_extract captures its launch sequence as a hipGraph on the second call of a configuration and replays
+    it afterwards; results stay bit-exact, and a change of image size re-captures."""
+    ge = gpu.ORBextractor(1000)
+    oe = oracle.Extractor(1000)
+    for t in range(4):
+        g = stream640.frame(20 + t)[0]
+        k, d = ge(g)
+        ok, od = oe.extract(g)
+        assert k.tobytes() == ok.tobytes() and np.array_equal(d, od)
+    assert ge.graph_state() == 1, "the graph path must be in use after the second call (state %d)" % ge.graph_state()
+    small = np.ascontiguousarray(stream640.frame(3)[0][:300, :400])
+    for _ in range(3):
+        k, d = ge(small)
+        ok, od = oe.extract(small)
+        assert k.tobytes() == ok.tobytes() and np.array_equal(d, od)
+    assert ge.graph_state() == 1
+    ge.set_profiling(True)  # stage events between the launches: plain launches, same results
+    k, d = ge(small)
+    assert k.tobytes() == ok.tobytes()
