@@ -339,9 +339,16 @@ __device__ __noinline__ int pj_decide_more(PjScan s, const uint32_t *__restrict_
     const uint4 *more = reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST);
     bool decided = false;
     int result = -1;
-    for (int g = 1; g < PJ_LIST / 4 && !decided; g++) {
-        const uint4 v = more[g];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    // the remaining 12 words in one round trip (three independent 16-byte loads), not one trip per group of four:
+    // with 10 k rows on 2 k key points most rows past the first few hundred find their leading candidates claimed
+    // and end up here in every sweep
+    static_assert(PJ_LIST == 16, "three more groups of four");
+    const uint4 vv[3] = {more[1], more[2], more[3]};
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        if (decided)
+            continue;
+        const uint32_t w[4] = {vv[g].x, vv[g].y, vv[g].z, vv[g].w};
         pj_scan4(w, i, claimA, s);
         result = pj_finish<MODE>(s, pj_dist(w[3]), nnratio, th_dist, decided);
     }
