@@ -481,6 +481,15 @@ int orbgpu_search_by_bow_keyframes(const uint8_t *desc1, const float *angle1, co
                                    const uint8_t *valid2, const int32_t *node2, int32_t n2, float nnratio,
                                    int32_t check_orientation, int32_t *match12, int32_t *nmatches, int32_t device_id);
 
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:405-520;
+ * Tracking::MonocularInitialization, Tracking.cc:877 -- monocular bootstrap only).  f1: kp_octave, kp_angle, desc of
+ * the initial frame (its grid is not read); f2: the current frame; prev_matched [f1->n][2] in/out.  The Hamming
+ * distances of every window candidate are computed on the device; the steal-if-strictly-closer bookkeeping between
+ * rows (:441-470) is sequential and runs on the host over those lists, statement by statement. */
+int orbgpu_search_for_initialization(const orbgpu_frame_view *f1, const orbgpu_frame_view *f2, float *prev_matched,
+                                     int32_t window_size, float nnratio, int32_t check_orientation,
+                                     int32_t *matches12, int32_t *nmatches, int32_t device_id);
+
 /* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:657-823, epipolar
  * test :140-157; LocalMapping::CreateNewMapPoints, LocalMapping.cc:268).  kf1 / kf2: the key frames as frame views
  * (kp_x / kp_y = mvKeysUn, u_right = mvuRight, kp_octave, kp_angle, desc; grids are not read); has_mp*: the key

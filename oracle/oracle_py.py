@@ -622,3 +622,13 @@ def search_by_bow_keyframes(desc1, angle1, valid1, fv1, desc2, angle2, valid2, f
     n = L.ora_search_by_bow_kf(_p(d1), _p(a1), _p(v1), len(d1), len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(d2), _p(a2),
                                _p(v2), len(d2), len(b[0]), _p(b[0]), _p(b[1]), _p(b[2]), nnratio, int(check_ori), _p(out))
     return n, out[:len(d1)]
+
+
+def search_for_initialization(f1, f2, prev_matched, window_size, nnratio=0.9, check_ori=True):
+    v1, v2 = f1.view(), f2.view()
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    out = np.full(max(f1.n, 1), -1, np.int32)
+    L = lib()
+    L.ora_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    n = L.ora_search_for_initialization(C.byref(v1), C.byref(v2), _p(pm), int(window_size), nnratio, int(check_ori), _p(out))
+    return n, out[:f1.n], pm

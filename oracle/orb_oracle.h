@@ -272,6 +272,9 @@ int ora_search_by_bow_kf(const uint8_t *desc1, const float *angle1, const uint8_
                          const int32_t *fv_nodes2, const int32_t *fv_start2, const int32_t *fv_items2, float nnratio,
                          int check_orientation, int32_t *match12);
 
+int ora_search_for_initialization(const ora_frame_view *f1, const ora_frame_view *f2, float *prev_matched,
+                                  int window_size, float nnratio, int check_orientation, int32_t *matches12);
+
 /* ---- BoW: vocabulary tree transform + node-wise matcher (orb_oracle_bow.c) ----
  * Nodes in the order TemplatedVocabulary::loadFromTextFile creates them (node 0 = root, a node after its parent);
  * children of a node in ascending id; leaves numbered in node order = word ids.  weighting: 0 TF_IDF, 1 TF, 2 IDF,

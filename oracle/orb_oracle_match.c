@@ -1102,3 +1102,97 @@ int ora_search_by_bow_kf(const uint8_t *desc1, const float *angle1, const uint8_
     free(matched2);
     return nmatches;
 }
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), ORBmatcher.cc:405-520
+ * (Tracking::MonocularInitialization, Tracking.cc:877).  f1: kp_octave / kp_angle / desc of the initial frame's
+ * mvKeysUn; f2: the current frame (grid, key points, descriptors).  prev_matched [n1][2] in/out (:514-517);
+ * matches12 [n1] out.  A later row steals a key point of F2 when its distance is strictly smaller (:441-442,
+ * 459-470).  Returns nmatches. */
+int ora_search_for_initialization(const ora_frame_view *f1, const ora_frame_view *f2, float *prev_matched,
+                                  int window_size, float nnratio, int check_orientation, int32_t *matches12)
+{
+    int nmatches = 0;
+    const int n1 = f1->n, n2 = f2->n;
+    int *vMatchedDistance = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    int *vnMatches21 = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    int32_t *vIndices2 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
+    int *hist_items = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1)); /* rotHist pushes: (bin, i1) in push order */
+    int *hist_bin = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1));
+    int npush = 0;
+    int histo[ORA_HISTO_LENGTH];
+    memset(histo, 0, sizeof(histo));
+    for (int i = 0; i < n1; i++)
+        matches12[i] = -1;
+    for (int j = 0; j < n2; j++) {
+        vMatchedDistance[j] = 2147483647;
+        vnMatches21[j] = -1;
+    }
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = f1->kp_octave[i1];
+        if (level1 > 0)
+            continue;
+        const int nc = ora_get_features_in_area(f2, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size,
+                                                level1, level1, vIndices2);
+        if (nc == 0)
+            continue;
+        const uint8_t *d1 = f1->desc + (size_t)i1 * 32;
+        int bestDist = 2147483647, bestDist2 = 2147483647, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = vIndices2[c];
+            const int dist = ora_descriptor_distance(d1, f2->desc + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist)
+                continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= ORA_TH_LOW) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    matches12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                matches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    const int bin = rot_bin(f1->kp_angle[i1], f2->kp_angle[bestIdx2]);
+                    hist_items[npush] = i1;
+                    hist_bin[npush] = bin;
+                    npush++;
+                    histo[bin]++;
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int i1m, i2m, i3m;
+        three_maxima(histo, ORA_HISTO_LENGTH, &i1m, &i2m, &i3m);
+        for (int p = 0; p < npush; p++) {
+            const int b = hist_bin[p];
+            if (b == i1m || b == i2m || b == i3m)
+                continue;
+            const int idx1 = hist_items[p];
+            if (matches12[idx1] >= 0) { /* :497-501: a stolen match is already gone */
+                matches12[idx1] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++) /* :514-517 */
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = f2->kp_x[matches12[i1]];
+            prev_matched[2 * i1 + 1] = f2->kp_y[matches12[i1]];
+        }
+    free(vMatchedDistance);
+    free(vnMatches21);
+    free(vIndices2);
+    free(hist_items);
+    free(hist_bin);
+    return nmatches;
+}

@@ -1186,6 +1186,38 @@ __global__ __launch_bounds__(1024) void k_tri_finish(int n1, const float *__rest
         *nmatches = s_count;
 }
 
+// ---- ORBmatcher::SearchForInitialization (ORBmatcher.cc:405-520): distances of every window candidate ---------
+// One wave per level-0 key point of F1: all key points of F2 inside its window (GetFeaturesInArea(x, y, windowSize,
+// 0, 0)) with their Hamming distance, as 64-bit keys distance << 44 | cell sequence << 32 | position in cell << 20
+// | index (the visiting order of the reference is the order of bits 43..20).  The steal-if-strictly-closer
+// bookkeeping (:441-470) is a sequential dependency between rows and runs on the host over these lists.
+__global__ __launch_bounds__(256) void k_window_candidates(int rows, const Query *__restrict__ q,
+                                                           const uint8_t *__restrict__ row_desc, FrameDev F, int cap,
+                                                           uint64_t *__restrict__ keys, int *__restrict__ counts)
+{
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + w;
+    if (lane == 0)
+        s_cnt[w] = 0;
+    __syncthreads();
+    if (i < rows) {
+        const Query Q = q[i];
+        if (Q.active) {
+            const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
+            const uint64_t a[4] = {da[0], da[1], da[2], da[3]};
+            proj_walk_each(Q, a, F, nullptr, i, [&](uint64_t key, int) {
+                const int slot = atomicAdd(&s_cnt[w], 1);
+                if (slot < cap)
+                    keys[(size_t)i * cap + slot] = key;
+            });
+        }
+    }
+    __syncthreads();
+    if (i < rows && lane == 0)
+        counts[i] = s_cnt[w];
+}
+
 } // namespace orbgpu
 
 using namespace orbgpu;
@@ -2174,6 +2206,156 @@ int orbgpu_search_for_triangulation(const orbgpu_frame_view *kf1, const uint8_t 
     ORBGPU_HIP_TRY(hipMemcpyAsync(match12, d_match, 4 * w1, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipMemcpyAsync(nmatches, d_n, 4, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipStreamSynchronize(st));
+    return ORBGPU_OK;
+}
+
+int orbgpu_search_for_initialization(const orbgpu_frame_view *f1, const orbgpu_frame_view *f2, float *prev_matched,
+                                     int32_t window_size, float nnratio, int32_t check_orientation,
+                                     int32_t *matches12, int32_t *nmatches, int32_t device_id)
+{
+    ORBGPU_REQUIRE(f1 && prev_matched && matches12 && nmatches && window_size > 0, "bad arguments");
+    ORBGPU_REQUIRE(f1->n >= 0 && (f1->n == 0 || (f1->kp_octave && f1->desc)), "null frame-1 arrays");
+    ORBGPU_REQUIRE(!check_orientation || f1->n == 0 || f1->kp_angle, "orientation check needs angles");
+    int rc = validate_frame(f2);
+    if (rc != ORBGPU_OK)
+        return rc;
+    ORBGPU_REQUIRE(!check_orientation || f2->n == 0 || f2->kp_angle, "orientation check needs angles");
+    if ((rc = select_device(device_id)) != ORBGPU_OK)
+        return rc;
+    const int n1 = f1->n, n2 = f2->n;
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++)
+        matches12[i] = -1;
+    if (n1 == 0 || n2 == 0)
+        return ORBGPU_OK;
+    // rows = the level-0 key points of F1 (:419-422)
+    std::vector<int> row_of;
+    std::vector<Query> q;
+    std::vector<uint8_t> rdesc;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (f1->kp_octave[i1] > 0)
+            continue;
+        Query Q{};
+        Q.x = prev_matched[2 * i1], Q.y = prev_matched[2 * i1 + 1];
+        Q.r = (float)window_size;
+        Q.min_level = f1->kp_octave[i1], Q.max_level = f1->kp_octave[i1];  // GetFeaturesInArea(.., level1, level1)
+        Q.active = 1;
+        row_of.push_back(i1);
+        q.push_back(Q);
+        rdesc.insert(rdesc.end(), f1->desc + (size_t)i1 * 32, f1->desc + (size_t)i1 * 32 + 32);
+    }
+    const int rows = (int)row_of.size();
+    if (rows == 0)
+        return ORBGPU_OK;
+    ProjWorkspace *ws = nullptr;
+    if ((rc = workspace(device_id, &ws)) != ORBGPU_OK)
+        return rc;
+    FrameDev F;
+    if ((rc = upload_frame(*ws, f2, F)) != ORBGPU_OK)
+        return rc;
+    hipStream_t st = ws->stream;
+    const int cap = n2;
+    PJ_TRY(put(ws->queries, q.data(), sizeof(Query) * rows, st));
+    PJ_TRY(put(ws->row_desc, rdesc.data(), (size_t)rows * 32, st));
+    PJ_TRY(ws->tri.reserve(sizeof(uint64_t) * (size_t)rows * cap + sizeof(int) * (size_t)rows + 64));
+    uint64_t *d_keys = ws->tri.as<uint64_t>();
+    int *d_counts = reinterpret_cast<int *>(d_keys + (size_t)rows * cap);
+    hipLaunchKernelGGL(k_window_candidates, dim3((rows + 3) / 4), dim3(256), 0, st, rows, ws->queries.as<Query>(),
+                       ws->row_desc.as<uint8_t>(), F, cap, d_keys, d_counts);
+    ORBGPU_HIP_TRY(hipGetLastError());
+    std::vector<int> counts((size_t)rows);
+    ORBGPU_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * (size_t)rows, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<size_t> off((size_t)rows + 1, 0);
+    for (int r = 0; r < rows; r++) {
+        ORBGPU_REQUIRE(counts[r] <= cap, "window candidate list overflow");  // cannot happen: cap = all key points
+        off[r + 1] = off[r] + (size_t)counts[r];
+    }
+    std::vector<uint64_t> keys(std::max<size_t>(off[rows], 1));
+    for (int r = 0; r < rows; r++)
+        if (counts[r])
+            ORBGPU_HIP_TRY(hipMemcpyAsync(&keys[off[r]], d_keys + (size_t)r * cap, sizeof(uint64_t) * (size_t)counts[r],
+                                          hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipStreamSynchronize(st));
+    // ---- the sequential part of the reference, verbatim, over the device-computed distances (:414-517)
+    std::vector<int> vMatchedDistance((size_t)n2, INT_MAX), vnMatches21((size_t)n2, -1);
+    std::vector<std::pair<int, int>> pushes;  // (bin, i1) in push order
+    int histo[ORBGPU_HISTO_LENGTH] = {0};
+    int nm = 0;
+    const float factor = 1.0f / ORBGPU_HISTO_LENGTH;
+    for (int r = 0; r < rows; r++) {
+        const int i1 = row_of[r];
+        uint64_t *b = &keys[off[r]], *e = b + counts[r];
+        if (b == e)
+            continue;  // :426-427
+        std::sort(b, e, [](uint64_t x, uint64_t y) { return ((x >> 20) & 0xFFFFFFull) < ((y >> 20) & 0xFFFFFFull); });
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (uint64_t *p = b; p != e; ++p) {
+            const int i2 = (int)(*p & 0xFFFFF), dist = (int)(*p >> 44);
+            if (vMatchedDistance[i2] <= dist)
+                continue;
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestIdx2 = i2;
+            } else if (dist < bestDist2) {
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= ORBGPU_TH_LOW && (float)bestDist < (float)bestDist2 * nnratio) {
+            if (vnMatches21[bestIdx2] >= 0) {
+                matches12[vnMatches21[bestIdx2]] = -1;
+                nm--;
+            }
+            matches12[i1] = bestIdx2;
+            vnMatches21[bestIdx2] = i1;
+            vMatchedDistance[bestIdx2] = bestDist;
+            nm++;
+            if (check_orientation) {
+                float rot = f1->kp_angle[i1] - f2->kp_angle[bestIdx2];
+                if (rot < 0.0)
+                    rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == ORBGPU_HISTO_LENGTH)
+                    bin = 0;
+                pushes.emplace_back(bin, i1);
+                histo[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;  // ComputeThreeMaxima, :1601-1642
+        for (int i = 0; i < ORBGPU_HISTO_LENGTH; i++) {
+            const int sz = histo[i];
+            if (sz > max1) {
+                max3 = max2, max2 = max1, max1 = sz;
+                ind3 = ind2, ind2 = ind1, ind1 = i;
+            } else if (sz > max2) {
+                max3 = max2, max2 = sz;
+                ind3 = ind2, ind2 = i;
+            } else if (sz > max3) {
+                max3 = sz, ind3 = i;
+            }
+        }
+        if ((float)max2 < 0.1f * (float)max1)
+            ind2 = ind3 = -1;
+        else if ((float)max3 < 0.1f * (float)max1)
+            ind3 = -1;
+        for (const auto &pr : pushes) {
+            if (pr.first == ind1 || pr.first == ind2 || pr.first == ind3)
+                continue;
+            if (matches12[pr.second] >= 0) {
+                matches12[pr.second] = -1;
+                nm--;
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)  // :514-517
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = f2->kp_x[matches12[i1]];
+            prev_matched[2 * i1 + 1] = f2->kp_y[matches12[i1]];
+        }
+    *nmatches = nm;
     return ORBGPU_OK;
 }
 

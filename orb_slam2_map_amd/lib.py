@@ -120,7 +120,7 @@ ABI_SYMBOLS = [
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_vocabulary_create", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_size", "orbgpu_bow_transform",
     "orbgpu_bow_transform_batch_device", "orbgpu_search_by_bow", "orbgpu_search_by_bow_batch_device",
-    "orbgpu_search_by_bow_keyframes", "orbgpu_search_for_triangulation", "orbgpu_fuse", "orbgpu_fuse_sim3",
+    "orbgpu_search_by_bow_keyframes", "orbgpu_search_for_triangulation", "orbgpu_search_for_initialization", "orbgpu_fuse", "orbgpu_fuse_sim3",
     "orbgpu_search_by_sim3",
     "orbgpu_mappoint_record_bytes", "orbgpu_write_mappoint_record", "orbgpu_keyframe_record_bytes",
     "orbgpu_write_keyframe_record", "orbgpu_pcd_binary_header", "orbgpu_write_pcd_binary", "orbgpu_cloud_save_pcd",
@@ -676,6 +676,20 @@ def search_for_triangulation(kf1, has_mp1, node1, kf2, has_mp2, node2, F12, ex, 
     check(L.orbgpu_search_for_triangulation(C.byref(f1), _p(h1), _p(n1), C.byref(f2), _p(h2), _p(n2), _p(F), ex, ey,
                                             _p(sg), int(only_stereo), int(check_ori), _p(out), C.byref(n), device_id))
     return n.value, out[:kf1.n]
+
+
+def search_for_initialization(f1, f2, prev_matched, window_size, nnratio=0.9, check_ori=True, device_id=0):
+    """ORBmatcher::SearchForInitialization (ORBmatcher.cc:405-520): (nmatches, matches12, updated prev_matched)."""
+    v1, v2 = f1.view(), f2.view()
+    pm = np.ascontiguousarray(prev_matched, np.float32).copy()
+    out = np.full(max(f1.n, 1), -1, np.int32)
+    n = C.c_int32()
+    L = lib()
+    L.orbgpu_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32,
+                                                   C.c_void_p, C.c_void_p, C.c_int32]
+    check(L.orbgpu_search_for_initialization(C.byref(v1), C.byref(v2), _p(pm), int(window_size), nnratio, int(check_ori),
+                                             _p(out), C.byref(n), device_id))
+    return n.value, out[:f1.n], pm
 
 
 def search_by_bow_keyframes(desc1, angle1, valid1, node1, desc2, angle2, valid2, node2, nnratio=0.75, check_ori=True,

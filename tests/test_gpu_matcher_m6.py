@@ -167,3 +167,29 @@ def test_search_by_bow_keyframes(gpu, oracle, ratio, check_ori, levelsup):
     assert ng == no and np.array_equal(mg, mo), "%d vs %d, %d differ" % (ng, no, int((mg != mo).sum()))
     assert np.all(v2[mo[mo >= 0]] == 1) and np.all(v1[np.nonzero(mo >= 0)[0]] == 1)
     gv.close()
+
+
+@pytest.mark.parametrize("window,ratio,check_ori,round2", [(100, 0.9, True, False), (40, 0.8, False, False),
+                                                           (100, 0.9, True, True)])
+def test_search_for_initialization(gpu, oracle, window, ratio, check_ori, round2):
+    """Tracking::MonocularInitialization (Tracking.cc:877): level-0 key points of the initial frame against the
+    current frame in a 100-px window around the previously matched position; later rows steal a key point when
+    strictly closer.  round2: a second call with the updated vbPrevMatched, as the tracker does frame after frame."""
+    from orb_slam2_map_amd.synth import Stream
+    st = Stream(640, 480, 1234)
+    ge = gpu.ORBextractor(2000, max_batch=3)  # the initialisation extractor uses 2 x nFeatures (Tracking.cc:211)
+    fr = [st.frame(70), st.frame(71), st.frame(72)]
+    ks, ds = ge.extract_batch(np.stack([f[0] for f in fr]))
+    sf = ge.GetScaleFactors()
+    g = [scenario.make_frame(gpu, ks[i], ds[i], fr[i][2], st, sf) for i in range(3)]
+    o = [scenario.make_frame(oracle, ks[i], ds[i], fr[i][2], st, sf) for i in range(3)]
+    pm0 = np.stack([ks[0]["x"], ks[0]["y"]], 1).astype(np.float32)  # mvbPrevMatched starts at the key points themselves
+    ng, mg, pg = gpu.search_for_initialization(g[0], g[1], pm0, window, ratio, check_ori)
+    no, mo, po = oracle.search_for_initialization(o[0], o[1], pm0, window, ratio, check_ori)
+    assert no > 100, no
+    assert ng == no and np.array_equal(mg, mo) and np.array_equal(pg, po), "%d vs %d" % (ng, no)
+    assert np.all(ks[0]["octave"][mo >= 0] == 0) and np.all(ks[1]["octave"][mo[mo >= 0]] == 0)
+    if round2:
+        ng2, mg2, pg2 = gpu.search_for_initialization(g[0], g[2], pg, window, ratio, check_ori)
+        no2, mo2, po2 = oracle.search_for_initialization(o[0], o[2], po, window, ratio, check_ori)
+        assert ng2 == no2 and np.array_equal(mg2, mo2) and np.array_equal(pg2, po2) and no2 > 100
