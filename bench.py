@@ -43,10 +43,8 @@ def algorithmic_bytes(stage, n_kp, n_cand):
     tot = sum(PYR_PX)
     if stage == "pyramid":
         return sum(PYR_PX[:-1]) + sum(PYR_PX[1:])  # R levels 0..6 + W levels 1..7 = 1 569 878 B
-    if stage == "fast_score":
-        return tot  # every level read once (the score map it writes is an intermediate, not counted)
-    if stage == "fast_nms":
-        return tot + 4 * n_cand  # score map read once (NMS + cell logic in one kernel) + surviving keys written
+    if stage == "fast":
+        return tot + 4 * n_cand  # every level read once (score + NMS + cell logic in one kernel) + surviving keys written
     if stage == "blur":
         return 2 * tot
     if stage == "orient":
@@ -58,8 +56,8 @@ def algorithmic_bytes(stage, n_kp, n_cand):
     raise KeyError(stage)
 
 
-STAGE_KERNELS = {"pyramid": ["k_border0"] + ["k_resize_fast"] * 7, "fast_score": ["k_fast_score"],
-                 "fast_nms": ["k_fast_cells"], "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
+STAGE_KERNELS = {"pyramid": ["k_border0"] + ["k_resize_fast"] * 7, "fast": ["k_fast_detect"],
+                 "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
                  "blur": ["k_blur"], "describe": ["k_describe"]}
 
 
@@ -330,7 +328,7 @@ def main():
                          "GB/s": round(algorithmic_bytes(k, n_kp, n_cand) * B / (max(v, 1e-6) * 1e-3) / 1e9, 1)}
                      for k, v in stage_ms.items()}
         traffic, traffic_src = pmc_traffic(dom, B)
-        ext_bytes = sum(algorithmic_bytes(k, n_kp, n_cand) for k in ("pyramid", "fast_score", "blur", "orient", "describe"))
+        ext_bytes = sum(algorithmic_bytes(k, n_kp, n_cand) for k in ("pyramid", "fast", "blur", "orient", "describe"))
         ext_ach = ext_bytes * B / (sum(stage_ms.values()) * 1e-3) / 1e9
         out = {
             "metric": "frames/sec ORB extract+match (640x480, 1000 feat)",

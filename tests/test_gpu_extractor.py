@@ -194,6 +194,23 @@ def test_full_value_range_extremes(gpu, oracle):
     assert_same_keypoints(gk, gd, ok, od, "extremes")
 
 
+@pytest.mark.parametrize("qcap", [0, 5, 64])
+def test_fast_key_queue_overflow(gpu, oracle, stream640, qcap, monkeypatch):
+    """k_fast_detect queues rows with corners in LDS and falls back to one atomic per key when a wave's queue is full.
+    The test hook shrinks the queue so that every wave takes the fallback (0), or mixes both paths (5, 64)."""
+    monkeypatch.setenv("ORBGPU_DEBUG_FAST_QUEUE", str(qcap))
+    ge = gpu.ORBextractor(1000)
+    monkeypatch.delenv("ORBGPU_DEBUG_FAST_QUEUE")
+    oe = oracle.Extractor(1000)
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (480, 640)).astype(np.uint8)
+    for what, img in (("stream", stream640.frame(0)[0]), ("noise", noise)):
+        gk, gd = ge(img)
+        ok, od = oe.extract(img)
+        check_stages(gpu, ge, oe, 0, 8, "queue %d %s" % (qcap, what))
+        assert_same_keypoints(gk, gd, ok, od, "queue %d %s" % (qcap, what))
+
+
 def test_too_small_image_is_rejected(gpu):
     ge = gpu.ORBextractor(1000)
     with pytest.raises(gpu.OrbGpuError) as ei:
