@@ -130,6 +130,77 @@ __global__ __launch_bounds__(256) void k_border0(const uint8_t *__restrict__ src
     }
 }
 
+// Fast path of K1a for 4-byte aligned rows whose width is a multiple of 4 (host-checked; k_border0 otherwise): every
+// aligned dword of the padded row -- interior, reflected border, or the fold between them -- is 4 bytes out of two
+// adjacent source dwords, picked by one v_perm_b32 with a selector that only depends on the column (BorderCol, built
+// on the host).  No per-byte path and no divergence: a thread owns 16 output bytes x BORDER_ROWS rows.
+constexpr int BORDER_ROWS = 4;
+
+struct BorderCol {
+    uint32_t d;    // first of the two adjacent source dwords
+    uint32_t sel;  // v_perm_b32 selector over {src[d+1], src[d]}
+};
+
+__global__ __launch_bounds__(256) void k_border0_fast(const uint8_t *__restrict__ src, size_t stride, size_t frame_stride,
+                                                      uint8_t *__restrict__ pyr, size_t frame_pyr,
+                                                      const LevelGeom *__restrict__ geom,
+                                                      const BorderCol *__restrict__ cols)
+{
+    const LevelGeom g = geom[0];
+    const int n16 = g.pitch >> 4;
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const int item = bx * 256 + threadIdx.x;
+    const int rg = item / n16;
+    const int c16 = item - rg * n16;
+    if (rg * BORDER_ROWS >= g.h + 2 * EDGE)
+        return;
+    const uint4 t01 = reinterpret_cast<const uint4 *>(cols)[c16 * 2], t23 = reinterpret_cast<const uint4 *>(cols)[c16 * 2 + 1];
+    const uint8_t *sf = src + (size_t)f * frame_stride;
+    uint8_t *dst = pyr + (size_t)f * frame_pyr + g.plane_off + c16 * 16;
+    // interior items (their 16 bytes are source bytes 16 c - 19 .. 16 c - 4): 5 consecutive dwords from 4 c - 5, every
+    // output dword = bytes 1..4 of a dword pair.  Only the two items at each end of a row go through the table.
+    const bool interior = c16 >= 2 && c16 * 16 - EDGE + 15 < g.w - 1 && c16 * 4 - 5 + 4 < (g.w >> 2);
+    struct __attribute__((packed, aligned(4))) Win {
+        uint32_t d[5];
+    };
+    if (interior) {
+        Win wn[BORDER_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < BORDER_ROWS; rr++) {
+            const int py = min(rg * BORDER_ROWS + rr, g.h + 2 * EDGE - 1);
+            wn[rr] = *reinterpret_cast<const Win *>(sf + __umul24((unsigned)reflect101(py - EDGE, g.h), (unsigned)stride) +
+                                                    (c16 * 16 - 20));
+        }
+#pragma unroll
+        for (int rr = 0; rr < BORDER_ROWS; rr++) {
+            const int py = rg * BORDER_ROWS + rr;
+            if (py >= g.h + 2 * EDGE)
+                break;
+            uint4 v;
+            v.x = __builtin_amdgcn_alignbyte(wn[rr].d[1], wn[rr].d[0], 1);
+            v.y = __builtin_amdgcn_alignbyte(wn[rr].d[2], wn[rr].d[1], 1);
+            v.z = __builtin_amdgcn_alignbyte(wn[rr].d[3], wn[rr].d[2], 1);
+            v.w = __builtin_amdgcn_alignbyte(wn[rr].d[4], wn[rr].d[3], 1);
+            *reinterpret_cast<uint4 *>(dst + rowoff(py, g.pitch)) = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int rr = 0; rr < BORDER_ROWS; rr++) {
+        const int py = rg * BORDER_ROWS + rr;
+        if (py >= g.h + 2 * EDGE)
+            break;
+        const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sf + __umul24((unsigned)reflect101(py - EDGE, g.h), (unsigned)stride));
+        uint4 v;
+        v.x = __builtin_amdgcn_perm(s32[t01.x + 1], s32[t01.x], t01.y);
+        v.y = __builtin_amdgcn_perm(s32[t01.z + 1], s32[t01.z], t01.w);
+        v.z = __builtin_amdgcn_perm(s32[t23.x + 1], s32[t23.x], t23.y);
+        v.w = __builtin_amdgcn_perm(s32[t23.z + 1], s32[t23.z], t23.w);
+        *reinterpret_cast<uint4 *>(dst + rowoff(py, g.pitch)) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1b: level l = resize(level l-1, INTER_LINEAR) + copyMakeBorder(REFLECT_101|ISOLATED)
 //      (ORBextractor.cc:1118-1124; OpenCV 2.4 8-bit fixed-point bilinear, A2).  Border pixels are
@@ -178,6 +249,7 @@ struct ResizeStrip {  // per padded output dword column of a level
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
+template <bool REUSE>  // keep a source row's horizontal interpolation for the next output row (pays on the large levels)
 __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                      const LevelGeom *__restrict__ geom, int level,
                                                      const ResizeStrip *__restrict__ strips,
@@ -207,28 +279,43 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
         const int py = min(rg * rows + rr, g.h + 2 * EDGE - 1);
         yts[rr] = ytab[g.ytab_off + reflect101(py - EDGE, g.h)];
     }
+    // consecutive output rows share a source row (row y's lower tap row is usually row y+1's upper one): its horizontal
+    // interpolation is kept instead of being loaded and computed again
+    int kept_row = -1, kept[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int rr = 0; rr < PYR_ROWS; rr++) {
         const int py = rg * rows + rr;
         if (rr >= rows || py >= g.h + 2 * EDGE)
             break;
         const YTab yt = yts[rr];
-        const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy0 + EDGE, gs.pitch));
         const uint32_t *S1 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy1 + EDGE, gs.pitch));
-        const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
         const uint32_t c0 = S1[0], c1 = S1[1], c2 = S1[2];
+        int t0[4];
+        if (!REUSE || (int)yt.sy0 != kept_row) {
+            const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy0 + EDGE, gs.pitch));
+            const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool q = (bq >> (16 + k)) & 1u;
+                const uint32_t p0 = __builtin_amdgcn_perm(q ? a2 : a1, q ? a1 : a0, selv[k]);
+                t0[k] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), __builtin_bit_cast(us2, wv[k]), 0u, false);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                t0[k] = kept[k];
+        }
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const bool q = (bq >> (16 + k)) & 1u;
-            const uint32_t p0 = __builtin_amdgcn_perm(q ? a2 : a1, q ? a1 : a0, selv[k]);
             const uint32_t p1 = __builtin_amdgcn_perm(q ? c2 : c1, q ? c1 : c0, selv[k]);
-            const us2 w = __builtin_bit_cast(us2, wv[k]);
-            const int t0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), w, 0u, false);
-            const int t1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), w, 0u, false);
-            const int o = ((__mul24((int)yt.b0, t0 >> 4) >> 16) + (__mul24((int)yt.b1, t1 >> 4) >> 16) + 2) >> 2;  // 12 x 15 bits
+            const int t1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), __builtin_bit_cast(us2, wv[k]), 0u, false);
+            const int o = ((__mul24((int)yt.b0, t0[k] >> 4) >> 16) + (__mul24((int)yt.b1, t1 >> 4) >> 16) + 2) >> 2;  // 12 x 15 bits
             v |= (uint32_t)(o & 0xFF) << (8 * k);
+            kept[k] = t1;
         }
+        kept_row = yt.sy1;
         *reinterpret_cast<uint32_t *>(dst + rowoff(py, g.pitch)) = v;
     }
 }
@@ -1406,7 +1493,7 @@ struct orbgpu_extractor {
     int sel_cap_total = 0, ncap = 0, max_kp = 0;
     size_t qt_lds = 0;
     // device state
-    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt, d_ctab;
+    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt, d_ctab, d_bcol;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
     DevBuf d_in, d_kps, d_desc, d_nout;  // staging for the host entry points
     DevBuf d_dbg;
@@ -1421,6 +1508,7 @@ struct orbgpu_extractor {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key = 0;
+    bool border_fast = false;  // level-0 column table present (width % 4 == 0)
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
 
@@ -1729,6 +1817,25 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
                            hi - lo + 1);
         }
     }
+    // k_border0_fast: per aligned dword of the padded level-0 row, the two adjacent source dwords and the byte selector
+    std::vector<BorderCol> bcol;
+    if (w % 4 == 0 && w >= 8) {
+        const LevelGeom &g0 = geom[0];
+        for (int c = 0; c < g0.pitch / 4; c++) {
+            int sx[4], lo = 1 << 30, hi = 0;
+            for (int k = 0; k < 4; k++) {
+                sx[k] = reflect101(std::min(c * 4 + k, g0.w + 2 * EDGE - 1) - EDGE, g0.w);
+                lo = std::min(lo, sx[k]);
+                hi = std::max(hi, sx[k]);
+            }
+            const int d = std::min(lo / 4, g0.w / 4 - 2);  // src[d + 1] stays inside the row
+            ORBGPU_REQUIRE(hi < d * 4 + 8 && lo >= d * 4, "level-0 border table: span of column %d", c);
+            BorderCol bc{(uint32_t)d, 0u};
+            for (int k = 0; k < 4; k++)
+                bc.sel |= (uint32_t)(sx[k] - d * 4) << (8 * k);  // bytes 0..3 = src[d], 4..7 = src[d+1]
+            bcol.push_back(bc);
+        }
+    }
     e->frame_pyr = plane_off;
     e->frame_slots = (size_t)slot_off;
     e->sel_cap_total = sel_off;
@@ -1744,6 +1851,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_geom, sizeof(LevelGeom) * nl);
     RSV(e->d_cells, sizeof(CellDesc) * cells.size());
     RSV(e->d_ctab, sizeof(ColumnInfo) * ctab.size());
+    RSV(e->d_bcol, sizeof(BorderCol) * std::max<size_t>(bcol.size(), 1));
     RSV(e->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1));
     RSV(e->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1));
     RSV(e->d_rstrip, sizeof(ResizeStrip) * std::max<size_t>(rstrip.size(), 1));
@@ -1764,6 +1872,9 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     ORBGPU_HIP_TRY(hipMemcpy(e->d_geom.p, geom.data(), sizeof(LevelGeom) * nl, hipMemcpyHostToDevice));
     ORBGPU_HIP_TRY(hipMemcpy(e->d_cells.p, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
     ORBGPU_HIP_TRY(hipMemcpy(e->d_ctab.p, ctab.data(), sizeof(ColumnInfo) * ctab.size(), hipMemcpyHostToDevice));
+    if (!bcol.empty())
+        ORBGPU_HIP_TRY(hipMemcpy(e->d_bcol.p, bcol.data(), sizeof(BorderCol) * bcol.size(), hipMemcpyHostToDevice));
+    e->border_fast = !bcol.empty();
     if (!xtab.empty()) {
         ORBGPU_HIP_TRY(hipMemcpy(e->d_xtab.p, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice));
         ORBGPU_HIP_TRY(hipMemcpy(e->d_ytab.p, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice));
@@ -1810,7 +1921,12 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     {
         const LevelGeom &g = e->geom[0];
         dim3 grid(((g.pitch / 4) * ((g.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS) + 255) / 256, batch);
-        hipLaunchKernelGGL(k_border0, grid, dim3(256), 0, st, d_gray, stride, frame_stride, pyr, e->frame_pyr, dg);
+        if (e->border_fast && stride % 4 == 0 && frame_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_gray) & 3) == 0) {
+            dim3 gridf(((g.pitch / 16) * ((g.h + 2 * EDGE + BORDER_ROWS - 1) / BORDER_ROWS) + 255) / 256, batch);
+            hipLaunchKernelGGL(k_border0_fast, gridf, dim3(256), 0, st, d_gray, stride, frame_stride, pyr, e->frame_pyr, dg,
+                               e->d_bcol.as<BorderCol>());
+        } else
+            hipLaunchKernelGGL(k_border0, grid, dim3(256), 0, st, d_gray, stride, frame_stride, pyr, e->frame_pyr, dg);
         for (int l = 1; l < nl; l++) {
             const LevelGeom &gl = e->geom[l];
             dim3 gr((gl.pitch / 4 + 255) / 256, gl.h + 2 * EDGE, batch);
@@ -1819,7 +1935,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
             const int rows = ndw_l >= 32768 ? PYR_ROWS : ndw_l >= 16384 ? PYR_ROWS / 2 : PYR_ROWS / 4;
             dim3 grf(((gl.pitch / 4) * ((gl.h + 2 * EDGE + rows - 1) / rows) + 255) / 256, batch);
             if (gl.rs_fast)
-                hipLaunchKernelGGL(k_resize_fast, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
+                hipLaunchKernelGGL(rows == PYR_ROWS ? k_resize_fast<true> : k_resize_fast<false>, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
                                    e->d_rstrip.as<ResizeStrip>(), e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(),
                                    e->d_ytab.as<YTab>(), gl.rs_off, rows);
             else
@@ -1922,7 +2038,7 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
     (void)hipSetDevice(e->prm.device_id);
     (void)hipDeviceSynchronize();
     DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_rstrip, &e->d_rsel,
-                      &e->d_rwt, &e->d_ctab, &e->d_pyr,
+                      &e->d_rwt, &e->d_ctab, &e->d_bcol, &e->d_pyr,
                       &e->d_blur, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
                       &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
     for (DevBuf *b : bufs)
