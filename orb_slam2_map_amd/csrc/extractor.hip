@@ -550,33 +550,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         dl.cellj = ci.cellj;
         s_lane[wave][lane] = dl;
     }
-    // keep-masks of the neighbour pairs (a set flag clears the half word): left / right neighbours of E = (px0, px2)
-    // and of O = (px1, px3)
-    auto keep = [&](int bit_lo, int bit_hi) {
-        return (((ci.flags >> bit_lo) & 1u) ? 0u : 0x0000FFFFu) | (((ci.flags >> bit_hi) & 1u) ? 0u : 0xFFFF0000u);
-    };
-    const uint32_t kLE = keep(4, 6), kRE = keep(8, 10), kLO = keep(5, 7), kRO = keep(9, 11);
-    // survivor flags (one byte per pixel) only count inside a cell interior and in the columns this wave owns
+    // neighbour pairs of E = (px0, px2) and O = (px1, px3).  A neighbour outside the pixel's cell counts as 0: for the
+    // pairs that come from the adjacent lanes the v_perm_b32 selector that assembles them zeroes the half word
+    // (selector byte 0x0c), the in-lane pairs are masked.
+    auto flag = [&](int bit) { return ((ci.flags >> bit) & 1u) != 0u; };
+    const uint32_t selLE = (flag(4) ? 0x0c0cu : 0x0302u) | (flag(6) ? 0x0c0c0000u : 0x05040000u);   // (px-1, px1) of {so, left so}
+    const uint32_t selRO = (flag(9) ? 0x0c0cu : 0x0302u) | (flag(11) ? 0x0c0c0000u : 0x05040000u);  // (px2, px4) of {right se, se}
+    const uint32_t kRE = (flag(8) ? 0u : 0x0000FFFFu) | (flag(10) ? 0u : 0xFFFF0000u);              // (px1, px3) right of E
+    const uint32_t kLO = (flag(5) ? 0u : 0x0000FFFFu) | (flag(7) ? 0u : 0xFFFF0000u);               // (px0, px2) left of O
+    // survivor sign bits only count inside a cell interior and in the columns this wave owns
     const bool own = lane >= 1 && lane <= FD_OWN;
-    const uint32_t vmask = own ? (((ci.flags & 1u) ? 0x01u : 0u) | ((ci.flags & 2u) ? 0x0100u : 0u) |
-                                  ((ci.flags & 4u) ? 0x010000u : 0u) | ((ci.flags & 8u) ? 0x01000000u : 0u))
-                               : 0u;
-    const int idxL = ((lane + 63) & 63) << 2, idxR = ((lane + 1) & 63) << 2;
+    const uint32_t vE = own ? ((flag(0) ? 0x8000u : 0u) | (flag(2) ? 0x80000000u : 0u)) : 0u;
+    const uint32_t vO = own ? ((flag(1) ? 0x8000u : 0u) | (flag(3) ? 0x80000000u : 0u)) : 0u;
     const uint32_t lane_tag = (uint32_t)lane << 9;
-    const short tl = (short)max(t_lo, 1);
-    const pk16 tpk = {tl, tl};
+    const uint32_t tl = (uint32_t)max(t_lo, 1);
+    const pkh tpk = __builtin_bit_cast(pkh, tl | (tl << 16));
 
-    // NMS state, one row behind the scores: T of rows k-2 and k-1, H and S of row k-1 (packed pairs)
+    // NMS state, one row behind the scores: T of rows k-2 and k-1; H of row k-1 with the threshold folded in
+    // (H = max(left, right, t)); S of row k-1 (packed pairs)
     uint32_t TpE = 0u, TpO = 0u, TcE = 0u, TcO = 0u, HcE = 0u, HcO = 0u, ScE = 0u, ScO = 0u;
     auto finish_row = [&](uint32_t TnE, uint32_t TnO, int row) {
         const pkh nbE = hmax3(__builtin_bit_cast(pkh, HcE), __builtin_bit_cast(pkh, TpE), __builtin_bit_cast(pkh, TnE));
         const pkh nbO = hmax3(__builtin_bit_cast(pkh, HcO), __builtin_bit_cast(pkh, TpO), __builtin_bit_cast(pkh, TnO));
-        const pk16 e16 = as_pk(ScE), o16 = as_pk(ScO);
-        // x > y  <=>  sign(y - x) for values in [0,255]: survivor <=> s > every neighbour and s > t
-        const uint32_t sE = as_u32(h_as_pk(nbE) - e16) & as_u32(tpk - e16);
-        const uint32_t sO = as_u32(h_as_pk(nbO) - o16) & as_u32(tpk - o16);
-        const uint32_t sg = (__builtin_amdgcn_perm(sO, sE, 0x07030501u) >> 7) & vmask;  // flag bytes in pixel order
-        if (sg) {
+        // x > y  <=>  sign(y - x) for values in [0,255]: survivor <=> s > max(every neighbour, t)
+        const uint32_t sE = as_u32(h_as_pk(nbE) - as_pk(ScE)) & vE;
+        const uint32_t sO = as_u32(h_as_pk(nbO) - as_pk(ScO)) & vO;
+        if (sE | sO) {
+            const uint32_t sg = (sE >> 15) | (sO >> 7);  // flag bytes in pixel order: px0 bit 0, px1 bit 8, px2 bit 16, px3 bit 24
             const uint32_t sc4 = __builtin_amdgcn_perm(ScO, ScE, 0x06020400u);
             const uint32_t rec = sg | ((uint32_t)row << 1) | lane_tag;
             const int slot = atomicAdd(&s_qn[wave], 1);
@@ -591,12 +591,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     };
     auto nms_row = [&](uint32_t se, uint32_t so, int k) {
-        const uint32_t oL = (uint32_t)__builtin_amdgcn_ds_bpermute(idxL, (int)so);  // left column's (px1, px3)
-        const uint32_t eR = (uint32_t)__builtin_amdgcn_ds_bpermute(idxR, (int)se);  // right column's (px0, px2)
-        const uint32_t le = __builtin_amdgcn_alignbit(so, oL, 16) & kLE;             // (px-1, px1)
+        // wave-wide lane shifts (DPP wave_shr:1 / wave_shl:1): an inactive or missing source lane yields 0
+        const uint32_t oL = __builtin_amdgcn_update_dpp(0u, so, 0x138, 0xf, 0xf, false);  // left column's (px1, px3)
+        const uint32_t eR = __builtin_amdgcn_update_dpp(0u, se, 0x130, 0xf, 0xf, false);  // right column's (px0, px2)
+        const uint32_t le = __builtin_amdgcn_perm(so, oL, selLE);                    // (px-1, px1)
         const uint32_t re = so & kRE;                                                 // (px1, px3)
         const uint32_t lo = se & kLO;                                                 // (px0, px2)
-        const uint32_t ro = __builtin_amdgcn_alignbit(eR, se, 16) & kRO;             // (px2, px4)
+        const uint32_t ro = __builtin_amdgcn_perm(eR, se, selRO);                    // (px2, px4)
         const uint32_t TnE = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(pkh, le), __builtin_bit_cast(pkh, se), __builtin_bit_cast(pkh, re)));
         const uint32_t TnO = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(pkh, lo), __builtin_bit_cast(pkh, so), __builtin_bit_cast(pkh, ro)));
         finish_row(TnE, TnO, k - 1);
@@ -604,8 +605,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         TpO = TcO;
         TcE = TnE;
         TcO = TnO;
-        HcE = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(pkh, le), __builtin_bit_cast(pkh, re)));
-        HcO = __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(pkh, lo), __builtin_bit_cast(pkh, ro)));
+        HcE = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(pkh, le), __builtin_bit_cast(pkh, re), tpk));
+        HcO = __builtin_bit_cast(uint32_t, hmax3(__builtin_bit_cast(pkh, lo), __builtin_bit_cast(pkh, ro), tpk));
         ScE = se;
         ScO = so;
     };
@@ -784,6 +785,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     const int N = g.quota;
 
     QtShared S;
+    uint32_t *dkey = dense_key + (size_t)f * frame_slots + g.slot_off;
+    uint16_t *dnode = dense_node + (size_t)f * frame_slots + g.slot_off;
     // list-ordered node arrays, ping-pong A (current) / B (next): bounds (ulx,uly,brx,bry), key
     // count, creation index inside the pass that created the node
     short4 *bndA, *bndB;
@@ -809,8 +812,6 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     }
 
     const uint32_t *fslots = slots + (size_t)f * frame_slots;
-    uint32_t *dkey = dense_key + (size_t)f * frame_slots + g.slot_off;
-    uint16_t *dnode = dense_node + (size_t)f * frame_slots + g.slot_off;
     int *ccounts = cell_cnt + (size_t)f * ncells_total + g.cell_first;
 
     // ---- step 0: this level's keys, compacted.  k_fast_detect leaves the NMS survivors above the lower threshold in
@@ -1718,7 +1719,8 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     ncap = std::max(ncap, (max_cells_level + 3) / 4);  // the cell scan reuses the [ncap*4] child-count array
     ncap = ((ncap + 7) / 8) * 8;
     const size_t qt_lds = (size_t)ncap * (2 * sizeof(short4) + 2 * sizeof(int) + 8 * sizeof(int) + 2 * sizeof(int) +
-                                          4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1) + 64 + (size_t)max_cells_level * sizeof(uint32_t);
+                                          4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1) + 64 +
+                          (size_t)max_cells_level * sizeof(uint32_t);
     ORBGPU_REQUIRE(qt_lds <= 160 * 1024 - 1024, "nfeatures too large for the quadtree kernel (needs %zu B of LDS)", qt_lds);
     ORBGPU_REQUIRE((size_t)slot_off < (1u << 23), "too many FAST key slots per frame");
 
