@@ -17,7 +17,8 @@ OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 # -ffp-contract=off: the float stages must round after every operation to match the reference's
 # scalar arithmetic.  HIP's correctly-rounded f32 divide/sqrt default stays on.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get(
+    "ORBGPU_EXTRA_FLAGS", "").split()  # e.g. -DORBGPU_QT_TIMING (tools/qt_sections.py)
 
 
 def sources():

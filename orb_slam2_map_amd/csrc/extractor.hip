@@ -716,9 +716,10 @@ struct QtShared {
 
 __device__ __forceinline__ int quadrant_of(uint32_t key, short4 b)
 {
-    // ExtractorNode::DivideNode, ORBextractor.cc:481-484, 513-526
-    const int halfx = (int)ceilf((float)(b.z - b.x) / 2);
-    const int halfy = (int)ceilf((float)(b.w - b.y) / 2);
+    // ExtractorNode::DivideNode, ORBextractor.cc:481-484, 513-526: halfX = ceil((float)(UR.x - UL.x) / 2), i.e.
+    // (d + 1) >> 1 for the non-negative integer d
+    const int halfx = (b.z - b.x + 1) >> 1;
+    const int halfy = (b.w - b.y + 1) >> 1;
     const int x = key_x(key), y = key_y(key);
     return (x < b.x + halfx) ? ((y < b.y + halfy) ? 0 : 2) : ((y < b.y + halfy) ? 1 : 3);
 }
@@ -764,6 +765,26 @@ __device__ int block_excl_scan(int *a, int n, int *s_tmp /*>= 16 ints*/)
     return total;
 }
 
+// counter[target] += 1 for every lane with `valid`; called by all 64 lanes of the wave (no lane masked off).  The keys
+// of a level are stored cell by cell, so neighbouring lanes mostly hold key points of the same node: a plain LDS atomic
+// takes one turn per lane on the same word (measured: 10 of the 18 us of a sweep over 18 k keys).  Here a run of equal
+// targets in consecutive lanes costs one atomic, issued by its first lane with the run length.
+__device__ __forceinline__ void count_runs(int *cnt, int target, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = valid ? target : -1;
+    const int prev = __builtin_amdgcn_update_dpp(-2, t, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);  // lane 0: -2
+    const bool head = t != prev;
+    const unsigned long long heads = __ballot(head);
+    if (head && t >= 0) {
+        const unsigned long long rest = lane == 63 ? 0ull : heads >> (lane + 1);
+        atomicAdd(&cnt[t], rest ? __ffsll((long long)rest) : 64 - lane);  // lanes up to the next run
+    }
+}
+
+constexpr int QT_ILP = 4;  // keys a thread carries through a sweep side by side (independent LDS / memory chains)
+
+template <bool LDS_KEYS>  // keep the level's first kcap keys and node ids in LDS (single frames: see the launch)
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__restrict__ geom,
                                                   const CellDesc *__restrict__ cells, int ncells_total,
                                                   const uint32_t *__restrict__ slots, size_t frame_slots,
@@ -772,10 +793,19 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
                                                   uint16_t *__restrict__ dense_node,
                                                   uint32_t *__restrict__ sel, int sel_cap_total,
                                                   int *__restrict__ nsel, int *__restrict__ ncand, int nlevels,
-                                                  int ncap, int t_ini)
+                                                  int ncap, int t_ini, int kcap_arg, int ncells_lds, long long *dbg_t)
 {
+    // section timestamps of workgroup (frame 0, level 0) for tools/qt_sections.py; compiled in with -DORBGPU_QT_TIMING
+#ifdef ORBGPU_QT_TIMING
+    int dbg_k = 0;
+#define QT_MARK(id) if (dbg_t && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == 0 && dbg_k < 500) { dbg_t[2 * dbg_k] = (id); dbg_t[2 * dbg_k + 1] = (long long)wall_clock64(); dbg_k++; }
+#else
+#define QT_MARK(id)
+#endif
+
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_tmp[16];
+    const int kcap = LDS_KEYS ? kcap_arg : 0;
     __shared__ int s_n, s_phase, s_done, s_nexp, s_cut;
 
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -785,6 +815,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     const int N = g.quota;
 
     QtShared S;
+    uint32_t *lkey;
+    uint16_t *lnode;
     uint32_t *dkey = dense_key + (size_t)f * frame_slots + g.slot_off;
     uint16_t *dnode = dense_node + (size_t)f * frame_slots + g.slot_off;
     // list-ordered node arrays, ping-pong A (current) / B (next): bounds (ulx,uly,brx,bry), key
@@ -808,64 +840,138 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         S.opos = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
         S.order = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
         S.inE = (uint8_t *)p; p += ((size_t)ncap + 3) / 4 * 4;
-        S.soff = (uint32_t *)p;
+        S.soff = (uint32_t *)p; p += sizeof(uint32_t) * ncells_lds;
+        lkey = (uint32_t *)p; p += sizeof(uint32_t) * kcap;
+        lnode = (uint16_t *)p;
     }
+    // LDS_KEYS: every pass sweeps the keys, and a sweep out of L2 is a chain of memory round trips -- the whole run
+    // time of a single frame's level-0 workgroup.  A batch is better served by eight workgroups per CU than by short
+    // sweeps (136 us against 198 us at B = 256 with 4096 keys per workgroup in LDS), so it runs with kcap = 0.
+    auto key_at = [&](int i) -> uint32_t { return i < kcap ? lkey[i] : dkey[i]; };
+    auto node_at = [&](int i) -> int { return i < kcap ? (int)lnode[i] : (int)dnode[i]; };
+    auto set_node = [&](int i, int nd) {
+        if (i < kcap)
+            lnode[i] = (uint16_t)nd;
+        else
+            dnode[i] = (uint16_t)nd;
+    };
 
     const uint32_t *fslots = slots + (size_t)f * frame_slots;
     int *ccounts = cell_cnt + (size_t)f * ncells_total + g.cell_first;
 
+    QT_MARK(0)
     // ---- step 0: this level's keys, compacted.  k_fast_detect leaves the NMS survivors above the lower threshold in
     //      every cell's slots, in no particular order, with the counter = survivors | (those above iniThFAST) << 16.
     //      cv::FAST(iniThFAST) of the cell is the subset above iniThFAST (a survivor of the 3x3 suppression at the lower
     //      threshold with s > t_hi also survives at t_hi: a neighbour with s_n <= t_hi cannot beat it), and only a cell
-    //      where that is empty keeps the rest (ORBextractor.cc:809-816).  One thread per stored key: the owning cell is
-    //      found by binary search in the scanned counts (LDS).  The order inside the dense array is arbitrary; the one
-    //      place where vToDistributeKeys order matters (step 3) derives it from the key.
+    //      where that is empty keeps the rest (ORBextractor.cc:809-816).  The order inside the dense array is arbitrary;
+    //      the one place where vToDistributeKeys order matters (step 3) derives it from the key.  On the way the keys
+    //      are counted per initial node (:542-585).
+    const int n_ini = g.n_ini;
+    const float hx = g.hx;
+    for (int b = tid; b < n_ini; b += nt)
+        S.sb[b] = 0;
     for (int c = tid; c < g.ncells; c += nt) {
         const int cnt = ccounts[c];
         ccounts[c] = 0;  // ready for the next extraction
         const int tot = cnt & 0xFFFF, ni = cnt >> 16;
         S.ccnt[c] = ni ? ni : tot;
         S.ccnt_next[c] = tot;
-        S.soff[c] = (uint32_t)cells[g.cell_first + c].slot_off | (ni ? 0x80000000u : 0u);
+        S.soff[c] = (uint32_t)cells[g.cell_first + c].slot_off | (ni ? 0x80000000u : 0u);  // bit 31: only keys above iniThFAST count
     }
     __syncthreads();
-    const int nkeys = block_excl_scan(S.ccnt, g.ncells, s_tmp);       // ccnt[c] = next dense index of cell c
-    const int nstored = block_excl_scan(S.ccnt_next, g.ncells, s_tmp);  // ccnt_next[c] = first stored key of cell c
-    for (int i = tid; i < nstored; i += nt) {
-        int lo = 0, hi = g.ncells - 1;  // last cell with start <= i
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (S.ccnt_next[mid] <= i)
-                lo = mid;
-            else
-                hi = mid - 1;
+    const int nkeys = block_excl_scan(S.ccnt, g.ncells, s_tmp);  // ccnt[c] = first dense index of cell c
+    if (LDS_KEYS) {
+        // single frames (one workgroup per CU, latency counts): one thread per cell walks the cell's slots, four
+        // loads in flight, and appends what the cell keeps at its place in the dense array -- no search, no atomics
+        for (int c = tid; c < g.ncells; c += nt) {
+            const int tot = S.ccnt_next[c];
+            const uint32_t so = S.soff[c];
+            const int thr = (so >> 31) ? t_ini : 0;  // cornerScore = s - 1:  s > t  <=>  response >= t
+            const uint32_t *src = fslots + (so & 0x7FFFFFFFu);
+            int pos = S.ccnt[c];
+            // a cell is narrower than an initial node: its keys fall into one bin or two neighbours
+            int b0 = -1, n0 = 0, n1 = 0;
+            for (int j = 0; j < tot; j += QT_ILP) {
+                uint32_t key[QT_ILP];
+    #pragma unroll
+                for (int u = 0; u < QT_ILP; u++)
+                    key[u] = src[min(j + u, tot - 1)];
+    #pragma unroll
+                for (int u = 0; u < QT_ILP; u++) {
+                    if (j + u < tot && key_resp(key[u]) >= thr) {
+                        dkey[pos] = key[u];  // also what the debug API reads
+                        if (pos < kcap)
+                            lkey[pos] = key[u];
+                        pos++;
+                        int bin = (int)((float)key_x(key[u]) / hx);
+                        bin = min(max(bin, 0), n_ini - 1);
+                        b0 = b0 < 0 ? bin : b0;
+                        if (bin == b0)
+                            n0++;
+                        else if (bin == b0 + 1)
+                            n1++;
+                        else
+                            atomicAdd(&S.sb[bin], 1);
+                    }
+                }
+            }
+            if (n0)
+                atomicAdd(&S.sb[b0], n0);
+            if (n1)
+                atomicAdd(&S.sb[b0 + 1], n1);
         }
-        const uint32_t so = S.soff[lo];
-        const uint32_t key = fslots[(so & 0x7FFFFFFFu) + (i - S.ccnt_next[lo])];
-        if (!(so >> 31) || key_resp(key) >= t_ini)  // cornerScore = s - 1:  s > t  <=>  response >= t
-            dkey[atomicAdd(&S.ccnt[lo], 1)] = key;
+    } else {
+        // batches (eight workgroups per CU, throughput counts): one thread per stored key, coalesced; the owning cell
+        // is found by binary search in the scanned stored counts
+        const int nstored = block_excl_scan(S.ccnt_next, g.ncells, s_tmp);  // ccnt_next[c] = first stored key of cell c
+        const int search_steps = 32 - __clz(max(g.ncells - 1, 1));          // halvings that pin one of ncells cells down
+        for (int i0 = tid; i0 - tid < nstored; i0 += QT_ILP * nt) {        // (all lanes iterate: count_runs works wave-wide)
+            int lo[QT_ILP], hi[QT_ILP], idx[QT_ILP];
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++) {
+                idx[u] = min(i0 + u * nt, nstored - 1);
+                lo[u] = 0;  // last cell with start <= idx
+                hi[u] = g.ncells - 1;
+            }
+            for (int it = 0; it < search_steps; it++) {
+#pragma unroll
+                for (int u = 0; u < QT_ILP; u++) {
+                    const int mid = (lo[u] + hi[u] + 1) >> 1;
+                    const bool open = lo[u] < hi[u];
+                    const bool right = S.ccnt_next[mid] <= idx[u];
+                    lo[u] = (open && right) ? mid : lo[u];
+                    hi[u] = (open && !right) ? mid - 1 : hi[u];
+                }
+            }
+            uint32_t so[QT_ILP], key[QT_ILP];
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++) {
+                so[u] = S.soff[lo[u]];
+                key[u] = fslots[(so[u] & 0x7FFFFFFFu) + (idx[u] - S.ccnt_next[lo[u]])];
+            }
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++) {
+                // cornerScore = s - 1:  s > t  <=>  response >= t
+                const bool keep = i0 + u * nt < nstored && (!(so[u] >> 31) || key_resp(key[u]) >= t_ini);
+                if (keep)
+                    dkey[atomicAdd(&S.ccnt[lo[u]], 1)] = key[u];
+                int bin = (int)((float)key_x(key[u]) / hx);
+                bin = min(max(bin, 0), n_ini - 1);
+                count_runs(S.sb, bin, keep);
+            }
+        }
     }
     __syncthreads();  // dkey written by this workgroup only; visible after the barrier (same CU)
     if (tid == 0)
         ncand[(size_t)f * nlevels + level] = nkeys;
 
-    // ---- step 1: initial nodes (:542-585)
-    const int n_ini = g.n_ini;
-    const float hx = g.hx;
-    for (int b = tid; b < n_ini; b += nt)
-        S.ccnt[b] = 0;
-    __syncthreads();
-    for (int i = tid; i < nkeys; i += nt) {
-        int b = (int)((float)key_x(dkey[i]) / hx);
-        b = min(max(b, 0), n_ini - 1);
-        atomicAdd(&S.ccnt[b], 1);
-    }
-    __syncthreads();
+    QT_MARK(1)
+    // ---- step 1: initial nodes (:542-585); S.sb[b] = keys of bin b, counted by step 0
     if (tid == 0) {
         int n = 0;
         for (int b = 0; b < n_ini; b++) {
-            int c = S.ccnt[b];
+            int c = S.sb[b];
             S.sa[b] = n;  // bin -> list position
             if (c > 0) {
                 bndA[n] = make_short4((short)(int)(hx * (float)b), 0, (short)(int)(hx * (float)(b + 1)),
@@ -883,14 +989,27 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     for (int i = tid; i < 4 * n_ini; i += nt)
         S.ccnt_next[i] = 0;
     __syncthreads();
-    for (int i = tid; i < nkeys; i += nt) {
-        const uint32_t key = dkey[i];
-        int b = (int)((float)key_x(key) / hx);
-        b = min(max(b, 0), n_ini - 1);
-        const int nd = S.sa[b];
-        dnode[i] = (uint16_t)nd;
-        if (cntA[nd] > 1)
-            atomicAdd(&S.ccnt_next[nd * 4 + quadrant_of(key, bndA[nd])], 1);
+    {
+        for (int i0 = tid; i0 - tid < nkeys; i0 += QT_ILP * nt) {
+            uint32_t key[QT_ILP];
+            int nd[QT_ILP];
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++)
+                key[u] = key_at(min(i0 + u * nt, nkeys - 1));
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++) {
+                int b = (int)((float)key_x(key[u]) / hx);
+                b = min(max(b, 0), n_ini - 1);
+                nd[u] = S.sa[b];
+            }
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++) {
+                const bool have = i0 + u * nt < nkeys;
+                if (have)
+                    set_node(i0 + u * nt, nd[u]);
+                count_runs(S.ccnt_next, nd[u] * 4 + quadrant_of(key[u], bndA[nd[u]]), have && cntA[nd[u]] > 1);
+            }
+        }
     }
     __syncthreads();
     {
@@ -899,6 +1018,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         S.ccnt_next = t;
     }
 
+    QT_MARK(2)
     // ---- passes
     for (int iter = 0; iter < 64; iter++) {
         const int n = s_n;
@@ -908,6 +1028,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         // (1) S.ccnt already holds the child key counts of every node with >1 keys: they are
         //     accumulated by the key loop of the previous pass (or of the initial assignment)
 
+        QT_MARK(10)
         // (2) processing order of the expandable nodes
         for (int p = tid; p < n; p += nt)
             S.sa[p] = cntA[p] > 1 ? 1 : 0;
@@ -937,6 +1058,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         }
         __syncthreads();
 
+        QT_MARK(11)
         // (3) children per expandable node in processing order; find the cut for phase 2
         for (int j = tid; j < nv; j += nt) {
             const int p = S.order[j];
@@ -959,6 +1081,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         const int nE = s_cut;
         const int C = (nE < nv) ? S.sb[nE] : call;  // children created in this pass
 
+        QT_MARK(12)
         // (4) untouched nodes keep their order behind the children
         for (int p = tid; p < n; p += nt)
             S.inE[p] = 0;
@@ -981,6 +1104,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             s_nexp = 0;
         __syncthreads();
 
+        QT_MARK(13)
         // (5) build the new list
         for (int p = tid; p < n; p += nt) {
             if (!S.inE[p]) {
@@ -1022,6 +1146,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             atomicAdd(&s_nexp, my_exp);
         __syncthreads();
 
+        QT_MARK(14)
         // (6) termination / phase switch (:669-673, :733-734), decided before the key loop so that a
         //     final pass does not count children
         if (tid == 0) {
@@ -1036,21 +1161,27 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         __syncthreads();
         const bool count_next = s_done == 0;
 
+        QT_MARK(15)
         // (7) re-label the keys and, in the same sweep, count the children of the NEW list's nodes
-        for (int i0 = tid; i0 < nkeys; i0 += 2 * nt) {
-            const int i1 = i0 + nt;
-            const bool has1 = i1 < nkeys;
-            const int nd0 = dnode[i0], nd1 = has1 ? dnode[i1] : 0;
-            const uint32_t k0 = dkey[i0], k1 = has1 ? dkey[i1] : 0u;
-            const int nn0 = S.inE[nd0] ? S.cpos[nd0 * 4 + quadrant_of(k0, bndA[nd0])] : S.opos[nd0];
-            dnode[i0] = (uint16_t)nn0;
-            if (count_next && cntB[nn0] > 1)
-                atomicAdd(&S.ccnt_next[nn0 * 4 + quadrant_of(k0, bndB[nn0])], 1);
-            if (has1) {
-                const int nn1 = S.inE[nd1] ? S.cpos[nd1 * 4 + quadrant_of(k1, bndA[nd1])] : S.opos[nd1];
-                dnode[i1] = (uint16_t)nn1;
-                if (count_next && cntB[nn1] > 1)
-                    atomicAdd(&S.ccnt_next[nn1 * 4 + quadrant_of(k1, bndB[nn1])], 1);
+        for (int i0 = tid; i0 - tid < nkeys; i0 += QT_ILP * nt) {
+            uint32_t key[QT_ILP];
+            int nd[QT_ILP], nn[QT_ILP];
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++) {
+                const int i = min(i0 + u * nt, nkeys - 1);
+                key[u] = key_at(i);
+                nd[u] = node_at(i);
+            }
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++)
+                nn[u] = S.inE[nd[u]] ? S.cpos[nd[u] * 4 + quadrant_of(key[u], bndA[nd[u]])] : S.opos[nd[u]];
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++) {
+                const bool have = i0 + u * nt < nkeys;
+                if (have)
+                    set_node(i0 + u * nt, nn[u]);
+                if (count_next)
+                    count_runs(S.ccnt_next, nn[u] * 4 + quadrant_of(key[u], bndB[nn[u]]), have && cntB[nn[u]] > 1);
             }
         }
         __syncthreads();
@@ -1067,6 +1198,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         __syncthreads();
     }
 
+    QT_MARK(3)
     // ---- step 3: best response per node, first maximum in vToDistributeKeys order (:741-760): cells row-major
     //      (:789-829), inside a cell cv::FAST's row-major output -- i.e. ascending (cell row, cell column, y, x), all of
     //      which the key holds.  One 64-bit maximum per node: response, then the inverted order, which is also enough to
@@ -1077,17 +1209,28 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         best[p] = 0ull;
     __syncthreads();
     const float inv_w = 1.0f / (float)g.wcell, inv_h = 1.0f / (float)g.hcell;
-    for (int i = tid; i < nkeys; i += nt) {
-        const uint32_t key = dkey[i];
-        const int x = key_x(key), y = key_y(key);  // relative to (minBorderX, minBorderY): cell interiors start at 3
-        // exact floor((v - 3) / cell) for v < 4096, cell >= 1: the float quotient is off by less than one ulp
-        int cj = (int)((float)(x - 3) * inv_w), ci = (int)((float)(y - 3) * inv_h);
-        cj += ((cj + 1) * g.wcell <= x - 3) ? 1 : 0;
-        cj -= (cj * g.wcell > x - 3) ? 1 : 0;
-        ci += ((ci + 1) * g.hcell <= y - 3) ? 1 : 0;
-        ci -= (ci * g.hcell > y - 3) ? 1 : 0;
-        const unsigned long long ord = ((unsigned long long)ci << 31) | ((unsigned long long)cj << 24) | (key >> 8);
-        atomicMax(&best[dnode[i]], ((unsigned long long)(key_resp(key) + 1) << 38) | (0x3FFFFFFFFFull - ord));
+    for (int i0 = tid; i0 < nkeys; i0 += QT_ILP * nt) {
+        uint32_t key[QT_ILP];
+        int nd[QT_ILP];
+#pragma unroll
+        for (int u = 0; u < QT_ILP; u++) {
+            const int i = min(i0 + u * nt, nkeys - 1);
+            key[u] = key_at(i);
+            nd[u] = node_at(i);
+        }
+#pragma unroll
+        for (int u = 0; u < QT_ILP; u++) {
+            const int x = key_x(key[u]), y = key_y(key[u]);  // relative to (minBorderX, minBorderY): cell interiors start at 3
+            // exact floor((v - 3) / cell) for v < 4096, cell >= 1: the float quotient is off by less than one ulp
+            int cj = (int)((float)(x - 3) * inv_w), ci = (int)((float)(y - 3) * inv_h);
+            cj += ((cj + 1) * g.wcell <= x - 3) ? 1 : 0;
+            cj -= (cj * g.wcell > x - 3) ? 1 : 0;
+            ci += ((ci + 1) * g.hcell <= y - 3) ? 1 : 0;
+            ci -= (ci * g.hcell > y - 3) ? 1 : 0;
+            const unsigned long long ord = ((unsigned long long)ci << 31) | ((unsigned long long)cj << 24) | (key[u] >> 8);
+            if (i0 + u * nt < nkeys)
+                atomicMax(&best[nd[u]], ((unsigned long long)(key_resp(key[u]) + 1) << 38) | (0x3FFFFFFFFFull - ord));
+        }
     }
     __syncthreads();
     uint32_t *osel = sel + (size_t)f * sel_cap_total + g.sel_off;
@@ -1097,6 +1240,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         const uint32_t yx = (uint32_t)((0x3FFFFFFFFFull - b) & 0xFFFFFFull);
         osel[p] = (yx << 8) | (uint32_t)((b >> 38) - 1ull);
     }
+    QT_MARK(4)
     if (tid == 0)
         nsel[(size_t)f * nlevels + level] = ok ? n : -1;
 }
@@ -1470,6 +1614,27 @@ static const int8_t k_pattern_host[1024] = {
 enum Stage { ST_PYRAMID = 0, ST_FAST, ST_QUADTREE, ST_ORIENT, ST_BLUR, ST_DESCRIBE, ST_COUNT };
 static const char *k_stage_names[ST_COUNT] = {"pyramid", "fast", "quadtree", "orient", "blur", "describe"};
 
+#ifdef ORBGPU_QT_TIMING
+static long long *g_qt_dbg = nullptr;
+static long long *qt_dbg()
+{
+    if (!g_qt_dbg) {
+        (void)hipMalloc(&g_qt_dbg, 8000);
+        (void)hipMemset(g_qt_dbg, 0, 8000);
+    }
+    return g_qt_dbg;
+}
+extern "C" void orbgpu_qt_dbg_dump()
+{
+    long long h[1000];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, g_qt_dbg, 8000, hipMemcpyDeviceToHost);
+    for (int i = 0; i < 500 && (i == 0 || h[2 * i + 1]); i++)
+        printf("mark %lld t %lld\n", h[2 * i], h[2 * i + 1]);
+}
+#else
+static long long *qt_dbg() { return nullptr; }
+#endif
 static inline int cv_round_host(double v) { return (int)lrint(v); }
 
 } // namespace orbgpu
@@ -1493,6 +1658,7 @@ struct orbgpu_extractor {
     size_t frame_pyr = 0, frame_slots = 0;
     int sel_cap_total = 0, ncap = 0, max_kp = 0;
     size_t qt_lds = 0;
+    int qt_kcap = 0, qt_cells = 0;  // keys of a level k_quadtree<true> keeps in LDS; cells of the largest level
     // device state
     DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt, d_ctab, d_bcol;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
@@ -1721,6 +1887,14 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     const size_t qt_lds = (size_t)ncap * (2 * sizeof(short4) + 2 * sizeof(int) + 8 * sizeof(int) + 2 * sizeof(int) +
                                           4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1) + 64 +
                           (size_t)max_cells_level * sizeof(uint32_t);
+    // single frames: keys (4 B) and node ids (2 B) of a level in LDS, as many as fit (never more than a level can hold)
+    int max_slots_level = 0;
+    for (int l = 0; l < nl; l++)
+        max_slots_level = std::max(max_slots_level, geom[l].slot_cnt);
+    int qt_kcap = max_slots_level;
+    if (const char *q = getenv("ORBGPU_DEBUG_QT_KEYS"))  // test hook: forces the mixed LDS / memory path
+        qt_kcap = std::max(atoi(q), 0);
+    qt_kcap = (int)std::min<size_t>((size_t)(qt_kcap + 7) / 8 * 8, qt_lds < 150 * 1024 ? (150 * 1024 - qt_lds) / 6 / 8 * 8 : 0);
     ORBGPU_REQUIRE(qt_lds <= 160 * 1024 - 1024, "nfeatures too large for the quadtree kernel (needs %zu B of LDS)", qt_lds);
     ORBGPU_REQUIRE((size_t)slot_off < (1u << 23), "too many FAST key slots per frame");
 
@@ -1843,6 +2017,8 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     e->sel_cap_total = sel_off;
     e->ncap = ncap;
     e->qt_lds = qt_lds;
+    e->qt_kcap = qt_kcap;
+    e->qt_cells = max_cells_level;
     int max_kp = 0;
     for (int l = 0; l < nl; l++)
         max_kp += geom[l].sel_cap - 1;
@@ -1889,8 +2065,10 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
     // cell counters start at zero; k_quadtree re-arms them after reading
     ORBGPU_HIP_TRY(hipMemset(e->d_cellcnt.p, 0, sizeof(int) * cells.size() * B));
-    ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree),
+    ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)qt_lds));
+    ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(qt_lds + (size_t)qt_kcap * 6)));
     e->cfg_w = w;
     e->cfg_h = h;
     e->cfg_batch = batch;
@@ -1957,11 +2135,18 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     }
     END(ST_FAST, st);
     BEGIN(ST_QUADTREE, st);
-    hipLaunchKernelGGL(k_quadtree, dim3(batch, nl), dim3(batch >= QT_BATCH_MIN ? QT_THREADS_BATCH : QT_THREADS), e->qt_lds, st, dg, e->d_cells.as<CellDesc>(),
-                       (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
-                       e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(), e->d_sel.as<uint32_t>(),
-                       e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl, e->ncap,
-                       std::max(e->prm.ini_th_fast, 1));
+    if (batch >= QT_BATCH_MIN)
+        hipLaunchKernelGGL(k_quadtree<false>, dim3(batch, nl), dim3(QT_THREADS_BATCH), e->qt_lds, st, dg,
+                           e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
+                           e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
+                           e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
+                           e->ncap, std::max(e->prm.ini_th_fast, 1), 0, e->qt_cells, qt_dbg());
+    else
+        hipLaunchKernelGGL(k_quadtree<true>, dim3(batch, nl), dim3(QT_THREADS), e->qt_lds + (size_t)e->qt_kcap * 6, st, dg,
+                           e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
+                           e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
+                           e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
+                           e->ncap, std::max(e->prm.ini_th_fast, 1), e->qt_kcap, e->qt_cells, qt_dbg());
     END(ST_QUADTREE, st);
     BEGIN(ST_ORIENT, st);
     const int or_iters = batch >= OR_BATCH_MIN ? OR_ITERS : 1;

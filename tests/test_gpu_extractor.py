@@ -243,20 +243,27 @@ def test_golden_fixture_on_gpu(gpu):
     assert np.array_equal(gd, g["desc"])
 
 
-def test_batch_equals_single_and_is_deterministic(gpu, stream640):
-    """Size-independent properties at the bench batch size: batched == per-frame, run twice == same."""
-    imgs = stream640.gray_batch(10, 16)
-    ge = gpu.ORBextractor(1000, max_batch=16)
+def test_batch_equals_single_and_is_deterministic(gpu, oracle, stream640):
+    """Size-independent properties at a bench-like batch size: batched == per-frame == oracle, run twice == same.
+    40 frames: batches of 32 and more take the many-workgroups variant of the quadtree kernel, single frames the one that
+    keeps a level's keys in LDS."""
+    imgs = stream640.gray_batch(10, 40)
+    ge = gpu.ORBextractor(1000, max_batch=40)
     k1, d1 = ge.extract_batch(imgs)
     k2, d2 = ge.extract_batch(imgs)
     single = gpu.ORBextractor(1000)
-    for f in range(16):
+    for f in range(40):
         assert np.array_equal(k1[f], k2[f]) and np.array_equal(d1[f], d2[f])
-    for f in (0, 7, 15):
+    for f in (0, 7, 39):
         ks, ds = single(imgs[f])
         assert np.array_equal(ks, k1[f]) and np.array_equal(ds, d1[f])
+    oe = oracle.Extractor(1000)
+    for f in (3, 33):
+        ok, od = oe.extract(imgs[f])
+        check_stages(gpu, ge, oe, f, 8, "batch frame %d" % f)
+        assert_same_keypoints(k1[f], d1[f], ok, od, "batch frame %d" % f)
     # structural invariants of the reference's output (E3', E4, E8)
-    for f in range(16):
+    for f in range(40):
         k = k1[f]
         assert 900 <= len(k) <= ge.max_keypoints(640, 480)
         assert np.all(np.diff(k["octave"]) >= 0), "levels are concatenated in order"
@@ -302,3 +309,18 @@ def test_host_entry_replays_a_graph(gpu, oracle, stream640):
     ge.set_profiling(True)  # stage events between the launches: plain launches, same results
     k, d = ge(small)
     assert k.tobytes() == ok.tobytes()
+
+
+@pytest.mark.parametrize("kcap", [0, 1000])
+def test_quadtree_keys_beyond_lds(gpu, oracle, stream640, kcap, monkeypatch):
+    """Single frames: k_quadtree keeps the first keys of a level in LDS and the rest in memory; the test hook shrinks
+    the LDS share so that both kinds of key take part in every sweep."""
+    monkeypatch.setenv("ORBGPU_DEBUG_QT_KEYS", str(kcap))
+    ge = gpu.ORBextractor(1000)
+    monkeypatch.delenv("ORBGPU_DEBUG_QT_KEYS")
+    oe = oracle.Extractor(1000)
+    img = stream640.frame(2)[0]
+    gk, gd = ge(img)
+    ok, od = oe.extract(img)
+    check_stages(gpu, ge, oe, 0, 8, "qt keys %d" % kcap)
+    assert_same_keypoints(gk, gd, ok, od, "qt keys %d" % kcap)
