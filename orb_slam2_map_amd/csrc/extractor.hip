@@ -726,7 +726,8 @@ __device__ __forceinline__ int quadrant_of(uint32_t key, short4 b)
 
 // workgroup size of k_quadtree: a single frame is bound by the latency of its level-0 workgroup (more threads per
 // key loop help), a full batch by barrier cost and workgroups per CU (fewer threads help): 155 -> 122 us at B = 256
-constexpr int QT_THREADS = 512, QT_THREADS_BATCH = 256, QT_BATCH_MIN = 32;
+constexpr int QT_THREADS = 1024, QT_THREADS_SMALL = 512, QT_THREADS_BATCH = 256, QT_BATCH_MIN = 32;
+constexpr int QT_LARGE_PIXELS = 700000;  // single frames from about 1024x768 use QT_THREADS (measured: 137 -> 128 us at 1280x960, 51 -> 54 us at 640x480)
 
 // In-place exclusive scan of an LDS int array by the whole workgroup; returns the total.
 __device__ int block_excl_scan(int *a, int n, int *s_tmp /*>= 16 ints*/)
@@ -782,6 +783,7 @@ __device__ __forceinline__ void count_runs(int *cnt, int target, bool valid)
     }
 }
 
+constexpr int QT_CELL_ILP = 8;  // ... of one cell in the single-frame compaction
 constexpr int QT_ILP = 4;  // keys a thread carries through a sweep side by side (independent LDS / memory chains)
 
 template <bool LDS_KEYS>  // keep the level's first kcap keys and node ids in LDS (single frames: see the launch)
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     __syncthreads();
     const int nkeys = block_excl_scan(S.ccnt, g.ncells, s_tmp);  // ccnt[c] = first dense index of cell c
     if (LDS_KEYS) {
-        // single frames (one workgroup per CU, latency counts): one thread per cell walks the cell's slots, four
+        // single frames (one workgroup per CU, latency counts): one thread per cell walks the cell's slots, eight
         // loads in flight, and appends what the cell keeps at its place in the dense array -- no search, no atomics
         for (int c = tid; c < g.ncells; c += nt) {
             const int tot = S.ccnt_next[c];
@@ -892,13 +894,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             int pos = S.ccnt[c];
             // a cell is narrower than an initial node: its keys fall into one bin or two neighbours
             int b0 = -1, n0 = 0, n1 = 0;
-            for (int j = 0; j < tot; j += QT_ILP) {
-                uint32_t key[QT_ILP];
+            for (int j = 0; j < tot; j += QT_CELL_ILP) {
+                uint32_t key[QT_CELL_ILP];
     #pragma unroll
-                for (int u = 0; u < QT_ILP; u++)
+                for (int u = 0; u < QT_CELL_ILP; u++)
                     key[u] = src[min(j + u, tot - 1)];
     #pragma unroll
-                for (int u = 0; u < QT_ILP; u++) {
+                for (int u = 0; u < QT_CELL_ILP; u++) {
                     if (j + u < tot && key_resp(key[u]) >= thr) {
                         dkey[pos] = key[u];  // also what the debug API reads
                         if (pos < kcap)
@@ -1039,21 +1041,28 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
                 if (cntA[p] > 1)
                     S.order[S.sa[p]] = (uint16_t)p;
         } else {
-            // sort by (cnt, creation) descending: rank by counting (keys are unique)
+            // sort by (cnt, creation) descending: rank by counting (keys are unique).  The sort keys of the expandable
+            // nodes are first laid out densely (S.sa is free between the scan above and section (4)) and padded with
+            // zeros to a multiple of 4, so that the counting loop reads them four at a time
+            uint32_t *skey = reinterpret_cast<uint32_t *>(S.sa);
             for (int p = tid; p < n; p += nt)
                 if (cntA[p] > 1)
                     S.opos[S.sa[p]] = (uint16_t)p;  // opos as temporary list of expandable nodes
+            __syncthreads();  // (also: every S.sa[p] has been read before the array is reused)
+            const int nv4 = (nv + 3) & ~3;
+            for (int a = tid; a < nv4; a += nt) {
+                const int p = S.opos[min(a, nv - 1)];
+                skey[a] = a < nv ? (((uint32_t)cntA[p] << 16) | creA[p]) : 0u;
+            }
             __syncthreads();
             for (int a = tid; a < nv; a += nt) {
-                const int p = S.opos[a];
-                const uint32_t ka = ((uint32_t)cntA[p] << 16) | creA[p];
+                const uint32_t ka = skey[a];
                 int rank = 0;
-                for (int b = 0; b < nv; b++) {
-                    const int q = S.opos[b];
-                    const uint32_t kb = ((uint32_t)cntA[q] << 16) | creA[q];
-                    rank += kb > ka;
+                for (int b = 0; b < nv4; b += 4) {
+                    const uint4 kb = *reinterpret_cast<const uint4 *>(&skey[b]);
+                    rank += (kb.x > ka) + (kb.y > ka) + (kb.z > ka) + (kb.w > ka);
                 }
-                S.order[rank] = (uint16_t)p;
+                S.order[rank] = S.opos[a];
             }
         }
         __syncthreads();
@@ -2142,7 +2151,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
                            e->ncap, std::max(e->prm.ini_th_fast, 1), 0, e->qt_cells, qt_dbg());
     else
-        hipLaunchKernelGGL(k_quadtree<true>, dim3(batch, nl), dim3(QT_THREADS), e->qt_lds + (size_t)e->qt_kcap * 6, st, dg,
+        hipLaunchKernelGGL(k_quadtree<true>, dim3(batch, nl), dim3(w * h >= QT_LARGE_PIXELS ? QT_THREADS : QT_THREADS_SMALL), e->qt_lds + (size_t)e->qt_kcap * 6, st, dg,
                            e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
