@@ -56,12 +56,12 @@ def algorithmic_bytes(stage, n_kp, n_cand):
     raise KeyError(stage)
 
 
-STAGE_KERNELS = {"pyramid": ["k_border0"] + ["k_resize_fast"] * 7, "fast": ["k_fast_detect"],
+STAGE_KERNELS = {"pyramid": ["k_border0_fast"] + ["k_resize_fast"] * 7, "fast": ["k_fast_detect"],
                  "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
                  "blur": ["k_blur"], "describe": ["k_describe"]}
 
 
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")  # newest first
+PMC_FILES = ("r02_pmc_traffic.json",)  # newest first (the round-1 file predates the fused FAST kernel)
 
 
 def pmc_traffic(stage, frames_per_launch):
@@ -356,7 +356,7 @@ def main():
             "extract_ms_per_step": round(sum(stage_ms.values()), 4),
             "extract_roofline": {"achieved": ext_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_ach / HBM_PEAK_GBS,
                                  "algorithmic_bytes": ext_bytes * B,
-                                 "note": "all seven extraction stages of one step against SURVEY.md 8d's 5.74 MB/frame"},
+                                 "note": "all six extraction stages of one step against SURVEY.md 8d's 5.74 MB/frame"},
             "fast_candidates_per_frame": n_cand,
             "match_ms_per_step": None if match_ms is None else round(match_ms, 4),
             "keypoints_per_frame": n_kp,

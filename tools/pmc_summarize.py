@@ -5,7 +5,7 @@
 
 Each pass wrote one *counter_collection.csv with a row per (dispatch, counter).  FETCH_SIZE / WRITE_SIZE are in KB.
 gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE under-reports coalesced streaming reads
-by 2x -- calibrated on k_border0, which reads each source byte once -- so HBM bytes = 2 * FETCH + WRITE.
+by 2x -- calibrated on the level-0 border kernel (k_border0 / k_border0_fast), which reads each source byte once -- so HBM bytes = 2 * FETCH + WRITE.
 Also copies the two CSVs (orbgpu kernels only) next to the JSON.
 """
 import csv
@@ -51,7 +51,7 @@ def main():
     out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/gpu_run.sh pmc), bench.py "
                    "--batch %d --pool %d; values are KB per launch (%d frames), averaged over launches. gfx950 "
                    "correction (MI355X_MICROARCH.md): FETCH_SIZE under-reports coalesced streaming reads by 2x; "
-                   "calibrated on k_border0, which reads each of the %d*307200 source bytes once. "
+                   "calibrated on the level-0 border kernel (k_border0 / k_border0_fast), which reads each of the %d*307200 source bytes once. "
                    "hbm_bytes_per_frame = (2*FETCH + WRITE)*1024/%d. Made by tools/pmc_summarize.py." % (
                        frames, pool, frames, frames, frames),
            "how": "separate --pmc passes at B=%d, pool %d" % (frames, pool),
