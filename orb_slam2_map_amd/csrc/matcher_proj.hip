@@ -332,56 +332,36 @@ __device__ __forceinline__ int pj_finish(const PjScan &s, int d_last, float nnra
 
 // The words beyond the first four, fetched only when those cannot decide (kept out of line: it is the rare path
 // and would otherwise be replicated for every register-resident row).
+// decision of a row from its 16 list words (registers) under a claim table: four words at a time until the scan
+// decides.  decided = false: more than the list holds is needed (or the list overflowed): whole-wave walk.
 template <int MODE>
-__device__ __noinline__ int pj_decide_more(PjScan s, const uint32_t *__restrict__ lists, int i, const int *claimA,
-                                           float nnratio, int th_dist, bool *decided_out)
+__device__ __forceinline__ int pj_decide16(const uint32_t w[PJ_LIST], int i, const int *claimA, float nnratio,
+                                           int th_dist, bool &decided)
 {
-    const uint4 *more = reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST);
-    bool decided = false;
+    static_assert(PJ_LIST == 16, "four groups of four");
+    decided = false;
+    if (w[0] == PJ_REWALK)
+        return -1;
+    PjScan s;
     int result = -1;
-    // the remaining 12 words in one round trip (three independent 16-byte loads), not one trip per group of four:
-    // with 10 k rows on 2 k key points most rows past the first few hundred find their leading candidates claimed
-    // and end up here in every sweep
-    static_assert(PJ_LIST == 16, "three more groups of four");
-    const uint4 vv[3] = {more[1], more[2], more[3]};
 #pragma unroll
-    for (int g = 0; g < 3; g++) {
+    for (int g = 0; g < 4; g++) {
         if (decided)
             continue;
-        const uint32_t w[4] = {vv[g].x, vv[g].y, vv[g].z, vv[g].w};
-        pj_scan4(w, i, claimA, s);
-        result = pj_finish<MODE>(s, pj_dist(w[3]), nnratio, th_dist, decided);
+        pj_scan4(w + 4 * g, i, claimA, s);
+        result = pj_finish<MODE>(s, pj_dist(w[4 * g + 3]), nnratio, th_dist, decided);
     }
-    *decided_out = decided;
     return decided ? result : -1;
 }
 
-// Row i: first four words given (registers).
-template <int MODE>
-__device__ __forceinline__ int pj_decide(const uint32_t w0[4], const uint32_t *__restrict__ lists, int i,
-                                         const int *claimA, float nnratio, int th_dist, bool &decided)
-{
-    if (w0[0] == PJ_REWALK) {
-        decided = false;
-        return -1;
-    }
-    PjScan s;
-    pj_scan4(w0, i, claimA, s);
-    const int result = pj_finish<MODE>(s, pj_dist(w0[3]), nnratio, th_dist, decided);
-    if (decided)
-        return result;
-    return pj_decide_more<MODE>(s, lists, i, claimA, nnratio, th_dist, &decided);
-}
-
-// Pass 2: the greedy claim order as a fixpoint, ONE workgroup.  Claim tables (two, ping-pong) live in
-// LDS.  A sweep re-decides every row from its cached candidate list, hiding key points that rows < i
-// with Observations()>0 claimed in the previous sweep; rows whose list cannot decide are re-walked by a
-// whole wave with the claim filter.  A sweep without changes is the sequential result; the loop is
-// bounded by m+1.  Then F.mvpMapPoints is written: the LAST claimant of a key point wins (a
-// non-blocking claimant can be overwritten, :123 / :1428) and, for mode 1, every accepted row whose
-// rotation bin is not among the three maxima clears its key point (:1448-1467).
-// match[] (global) always holds the latest decision of every row; the owner thread mirrors it in a register
-// for its cached rows and stores only when the decision changes.
+// The claim fixpoint as a blocked Gauss-Seidel.  Rows are visited in blocks of blockDim.x consecutive rows, one row
+// per thread with its whole candidate list in registers.  Every row of an earlier block is final, so `base` (claims
+// of the earlier blocks on top of claim_init) never changes while a block is worked on; inside the block the usual
+// sweeps run -- sweep s re-decides every row of the block, hiding what earlier rows claimed in sweep s-1 -- until a
+// sweep changes nothing, which makes the block's rows final (row p of the block after at most p+1 sweeps).  The
+// kernel is one workgroup on one CU and bound by that CU's instruction issue (tools/pj_sections.py: a 16-wave sweep
+// takes ~3 us whatever the barrier count), so what counts is row decisions: 10 blocks x ~3 sweeps x 1024 rows = 31 k
+// against 6 sweeps x 10 k rows = 60 k for the all-rows sweeps this replaces, and no list word is read twice.
 template <int MODE>
 __device__ __forceinline__ void proj_resolve_body(int m, const Query *__restrict__ q,
                                                        const uint8_t *__restrict__ row_desc, const FrameDev &F,
@@ -392,7 +372,7 @@ __device__ __forceinline__ void proj_resolve_body(int m, const Query *__restrict
                                                        int row_angle_stride,
                                                        const float *__restrict__ kp_angle, int check_orientation,
                                                        int *__restrict__ kp_to_mp, int *__restrict__ nmatches,
-                                                       int *__restrict__ sweeps_out, int novf)
+                                                       int *__restrict__ sweeps_out, int /*unused*/)
 {
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int histo[ORBGPU_HISTO_LENGTH];
@@ -401,168 +381,127 @@ __device__ __forceinline__ void proj_resolve_body(int m, const Query *__restrict
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n = F.n_dev ? min(max(*F.n_dev, 0), F.n) : F.n;
     const int kp_angle_stride = F.kp_stride;
-    // LDS: [first four list words of the rows beyond the register budget (novf x 16 B)] [claimA n] [claimB n]
-    //      [their latest decision (novf x 4 B)] [their flags (novf B)]; the host sized novf to what fits
-    uint4 *ovf_w = reinterpret_cast<uint4 *>(smem);
-    int *claimA = reinterpret_cast<int *>(smem + (size_t)novf * 16);
-    int *claimB = claimA + F.n;
-    int *ovf_res = claimB + F.n;
-    uint8_t *ovf_flag = reinterpret_cast<uint8_t *>(ovf_res + novf);
+    // LDS: three claim tables of F.n entries that rotate: base / previous sweep / the sweep being built
+    int *T0 = reinterpret_cast<int *>(smem), *T1 = T0 + F.n, *T2 = T1 + F.n;
+    int *base = T0;
     for (int j = tid; j < n; j += nt)
-        claimA[j] = claim_init[j];
-    for (int o = tid; o < novf; o += nt) {
-        const int i = PJ_RC * nt + o;
-        const Query Q = q[i];
-        ovf_flag[o] = (uint8_t)((Q.active ? 1 : 0) | (Q.blocking ? 2 : 0));
-        ovf_w[o] = Q.active ? *reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST)
-                            : make_uint4(PJ_NONE, PJ_NONE, PJ_NONE, PJ_NONE);
-        ovf_res[o] = -2;
-    }
-    for (int i = tid; i < m; i += nt)
-        match[i] = -2;
-    // register-resident rows: r-th row of this thread is i = r * nt + tid
-    uint32_t cw[PJ_RC][4];
-    int cres[PJ_RC];
-    uint32_t cact = 0, cblk = 0;  // bit r: row active / row blocking
-    uint32_t cslow = 0;           // bit r: row was queued in the current sweep
-#pragma unroll
-    for (int r = 0; r < PJ_RC; r++) {
-        const int i = r * nt + tid;
-        cres[r] = -2;
-        cw[r][0] = cw[r][1] = cw[r][2] = cw[r][3] = PJ_NONE;
-        if (i < m) {
-            if (q[i].active) {
-                cact |= 1u << r;
-                const uint4 v = *reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST);
-                cw[r][0] = v.x, cw[r][1] = v.y, cw[r][2] = v.z, cw[r][3] = v.w;
-            }
-            if (q[i].blocking)
-                cblk |= 1u << r;
-        }
-    }
+        base[j] = claim_init[j];
     __syncthreads();
     int sweeps = 0, rewalked = 0;
-    for (int iter = 0; iter <= m + 1; iter++) {
-        for (int j = tid; j < n; j += nt)
-            claimB[j] = claim_init[j];
-        if (tid == 0) {
-            s_changed = 0;
-            s_nslow = 0;
-        }
-        __syncthreads();
-        bool changed = false;
-        cslow = 0;
+    const int nblocks = (m + nt - 1) / nt;
+    // the next block's row is fetched while the current block is being decided
+    auto load_row = [&](int i, uint32_t w[PJ_LIST], bool &active, bool &blocking) {
+        active = blocking = false;
 #pragma unroll
-        for (int r = 0; r < PJ_RC; r++) {
-            const int i = r * nt + tid;
-            if (i >= m)
-                continue;
-            int result = -1;
-            if (cact & (1u << r)) {
-                bool decided;
-                result = pj_decide<MODE>(cw[r], lists, i, claimA, nnratio, th_dist, decided);
-                if (!decided) {
-                    slow[atomicAdd(&s_nslow, 1)] = i;
-                    cslow |= 1u << r;
-                    continue;
+        for (int k = 0; k < PJ_LIST; k++)
+            w[k] = PJ_NONE;
+        if (i < m) {
+            active = q[i].active;
+            blocking = q[i].blocking;
+            if (active) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint4 v = src[g];
+                    w[4 * g] = v.x, w[4 * g + 1] = v.y, w[4 * g + 2] = v.z, w[4 * g + 3] = v.w;
                 }
             }
-            if (cres[r] != result) {
-                changed = true;
-                cres[r] = result;
-                match[i] = result;
-            }
-            if (result >= 0 && (cblk & (1u << r)))
-                atomicMin(&claimB[result], i);
         }
-        for (int o = tid; o < novf; o += nt) {  // rows beyond the register budget, cached in LDS
-            const int i = PJ_RC * nt + o;
-            int result = -1;
-            const uint8_t fl = ovf_flag[o];
-            if (fl & 1) {
-                const uint4 v = ovf_w[o];
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                bool decided;
-                result = pj_decide<MODE>(w, lists, i, claimA, nnratio, th_dist, decided);
+    };
+    uint32_t wn[PJ_LIST];
+    bool act_n, blk_n;
+    load_row(tid, wn, act_n, blk_n);
+    for (int b = 0; b < nblocks; b++) {
+        const int i = b * nt + tid;
+        uint32_t w[PJ_LIST];
+#pragma unroll
+        for (int k = 0; k < PJ_LIST; k++)
+            w[k] = wn[k];
+        const bool active = act_n, blocking = blk_n;
+        if (b + 1 < nblocks)
+            load_row(i + nt, wn, act_n, blk_n);
+        int *claimA = base;                       // sweep 0 of the block sees the earlier blocks only
+        int *claimB = base == T0 ? T1 : T0;       // the two tables that are not `base`
+        int *spare = base == T2 ? T1 : T2;
+        int res = -2;
+        const int rows_here = min(nt, m - b * nt);
+        for (int iter = 0; iter <= rows_here + 1; iter++) {
+            for (int j = tid; j < n; j += nt)
+                claimB[j] = base[j];
+            if (tid == 0) {
+                s_changed = 0;
+                s_nslow = 0;
+            }
+            __syncthreads();
+            bool changed = false, queued = false;
+            if (i < m) {
+                int result = -1;
+                bool decided = true;
+                if (active)
+                    result = pj_decide16<MODE>(w, i, claimA, nnratio, th_dist, decided);
                 if (!decided) {
                     slow[atomicAdd(&s_nslow, 1)] = i;
-                    ovf_res[o] = -3;  // decided by the wave-cooperative walk: re-read match[] next sweep
-                    continue;
-                }
-            }
-            const int before = ovf_res[o] == -3 ? match[i] : ovf_res[o];
-            if (before != result) {
-                changed = true;
-                match[i] = result;
-            }
-            ovf_res[o] = result;
-            if (result >= 0 && (fl & 2))
-                atomicMin(&claimB[result], i);
-        }
-        for (int i = PJ_RC * nt + novf + tid; i < m; i += nt) {  // ... and whatever LDS could not hold
-            int result = -1;
-            const Query Q = q[i];
-            if (Q.active) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(lists + (size_t)i * PJ_LIST);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-                bool decided;
-                result = pj_decide<MODE>(w, lists, i, claimA, nnratio, th_dist, decided);
-                if (!decided) {
-                    slow[atomicAdd(&s_nslow, 1)] = i;
-                    continue;
-                }
-            }
-            if (match[i] != result) {
-                changed = true;
-                match[i] = result;
-            }
-            if (result >= 0 && Q.blocking)
-                atomicMin(&claimB[result], i);
-        }
-        __syncthreads();
-        {
-            const int nslow = s_nslow;
-            rewalked += nslow;
-            const int wave = tid >> 6, nw = nt >> 6;
-            for (int r = wave; r < nslow; r += nw) {
-                const int i = slow[r];
-                const Query Q = q[i];
-                const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)i * 4;
-                const uint64_t a[4] = {da[0], da[1], da[2], da[3]};
-                uint64_t t[4];
-                proj_walk(Q, a, F, claimA, i, t);
-                top4_wave_merge64(t);
-                if ((tid & 63) == 0) {
-                    int result = -1;
-                    if (t[0] != KEY_NONE)
-                        result = proj_accept<MODE>(t[0], t[1], F, nnratio, th_dist);
-                    if (match[i] != result) {
+                    queued = true;
+                } else {
+                    if (res != result) {
                         changed = true;
-                        match[i] = result;
+                        res = result;
                     }
-                    if (result >= 0 && Q.blocking)
+                    if (result >= 0 && blocking)
                         atomicMin(&claimB[result], i);
                 }
             }
+            __syncthreads();
+            const int nslow = s_nslow;
+            if (nslow) {  // rows whose list cannot decide: exact re-walk of the window by a whole wave
+                rewalked += nslow;
+                const int wave = tid >> 6, nw = nt >> 6;
+                for (int r = wave; r < nslow; r += nw) {
+                    const int ir = slow[r];
+                    const Query Q = q[ir];
+                    const uint64_t *da = reinterpret_cast<const uint64_t *>(row_desc) + (size_t)ir * 4;
+                    const uint64_t a[4] = {da[0], da[1], da[2], da[3]};
+                    uint64_t t[4];
+                    proj_walk(Q, a, F, claimA, ir, t);
+                    top4_wave_merge64(t);
+                    if ((tid & 63) == 0) {
+                        int result = -1;
+                        if (t[0] != KEY_NONE)
+                            result = proj_accept<MODE>(t[0], t[1], F, nnratio, th_dist);
+                        match[ir] = result;  // handed back to the row's thread below
+                        if (result >= 0 && Q.blocking)
+                            atomicMin(&claimB[result], ir);
+                    }
+                }
+                __syncthreads();
+                if (queued) {
+                    const int result = match[i];
+                    if (res != result) {
+                        changed = true;
+                        res = result;
+                    }
+                }
+            }
+            if (changed)
+                s_changed = 1;
+            __syncthreads();
+            sweeps++;
+            const bool again = s_changed != 0;
+            __syncthreads();
+            if (!again) {
+                base = claimB;  // nothing changed: the table just built is the block's final one
+                break;
+            }
+            // rotate: the table just built becomes the previous sweep's, the old previous one (never `base`) is rebuilt
+            int *prev = claimA;
+            claimA = claimB;
+            claimB = prev == base ? spare : prev;
         }
-        if (changed)
-            s_changed = 1;
-        __syncthreads();
-        if (cslow) {  // pick up what the wave-cooperative walk decided for this thread's queued rows
-#pragma unroll
-            for (int r = 0; r < PJ_RC; r++)
-                if (cslow & (1u << r))
-                    cres[r] = match[r * nt + tid];
-        }
-        sweeps++;
-        const bool again = s_changed != 0;
-        __syncthreads();
-        if (!again)
-            break;
-        int *tmp = claimA;
-        claimA = claimB;
-        claimB = tmp;
+        if (i < m)
+            match[i] = res;
     }
+    __syncthreads();
+    int *claimA = base == T0 ? T1 : T0;  // scratch for the finish
 
     // ---- finish
     int *last_claim = claimA;  // reuse
@@ -635,15 +574,12 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(int m, const Query *__res
                             row_angle_stride, kp_angle, check_orientation, kp_to_mp, nmatches, sweeps_out, novf);
 }
 
-// LDS of k_proj_resolve: two claim tables (8 B per key point slot) + 21 B per row cached beyond the register budget
+// LDS of k_proj_resolve: three claim tables of one int per key point slot
 constexpr size_t PJ_RESOLVE_MAX_LDS = 150 * 1024;
-static inline size_t resolve_lds(int m, int ncap, int *novf)
+static inline size_t resolve_lds(int /*m*/, int ncap, int *novf)
 {
-    const size_t base = (size_t)8 * ncap;
-    const int over = std::max(m - PJ_RC * 1024, 0);
-    const int fit = base < PJ_RESOLVE_MAX_LDS ? (int)((PJ_RESOLVE_MAX_LDS - base) / 21) : 0;
-    *novf = std::min(over, fit);
-    return base + (size_t)*novf * 21 + 16;
+    *novf = 0;
+    return (size_t)12 * ncap + 16;
 }
 
 // ---- host side -----------------------------------------------------------------------------
