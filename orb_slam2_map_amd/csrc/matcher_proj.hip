@@ -354,6 +354,26 @@ __device__ __forceinline__ int pj_decide16(const uint32_t w[PJ_LIST], int i, con
     return decided ? result : -1;
 }
 
+// section timestamps of the first workgroup for tools/pj_sections.py; compiled in with -DORBGPU_PJ_TIMING
+#ifdef ORBGPU_PJ_TIMING
+__device__ long long g_pj_dbg[2048];
+__device__ int g_pj_k;
+#define PJ_MARK(id) if (threadIdx.x == 0 && blockIdx.x == 0 && g_pj_k < 1000) { g_pj_dbg[2 * g_pj_k] = (id); g_pj_dbg[2 * g_pj_k + 1] = (long long)wall_clock64(); g_pj_k++; }
+extern "C" void orbgpu_pj_dbg_dump()
+{
+    static long long h[2048];
+    int k = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pj_dbg), sizeof(h));
+    (void)hipMemcpyFromSymbol(&k, HIP_SYMBOL(g_pj_k), sizeof(int));
+    for (int i = 0; i < k; i++)
+        printf("mark %lld t %lld\n", h[2 * i], h[2 * i + 1]);
+    k = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pj_k), &k, sizeof(int));
+}
+#else
+#define PJ_MARK(id)
+#endif
 // The claim fixpoint as a blocked Gauss-Seidel.  Rows are visited in blocks of blockDim.x consecutive rows, one row
 // per thread with its whole candidate list in registers.  Every row of an earlier block is final, so `base` (claims
 // of the earlier blocks on top of claim_init) never changes while a block is worked on; inside the block the usual
@@ -412,6 +432,7 @@ __device__ __forceinline__ void proj_resolve_body(int m, const Query *__restrict
     bool act_n, blk_n;
     load_row(tid, wn, act_n, blk_n);
     for (int b = 0; b < nblocks; b++) {
+        PJ_MARK(1)  // block start
         const int i = b * nt + tid;
         uint32_t w[PJ_LIST];
 #pragma unroll
@@ -485,6 +506,7 @@ __device__ __forceinline__ void proj_resolve_body(int m, const Query *__restrict
             if (changed)
                 s_changed = 1;
             __syncthreads();
+            PJ_MARK(6)  // sweep end
             sweeps++;
             const bool again = s_changed != 0;
             __syncthreads();
@@ -501,6 +523,7 @@ __device__ __forceinline__ void proj_resolve_body(int m, const Query *__restrict
             match[i] = res;
     }
     __syncthreads();
+    PJ_MARK(7)  // finish
     int *claimA = base == T0 ? T1 : T0;  // scratch for the finish
 
     // ---- finish
@@ -551,6 +574,7 @@ __device__ __forceinline__ void proj_resolve_body(int m, const Query *__restrict
     if ((tid & 63) == 0)
         atomicAdd(&s_count, cnt);
     __syncthreads();
+    PJ_MARK(8)  // end
     if (tid == 0) {
         *nmatches = s_count;
         sweeps_out[0] = sweeps;
