@@ -568,6 +568,14 @@ int orbgpu_cloud_clear(orbgpu_cloud *h);
 int orbgpu_cloud_append_filtered(orbgpu_cloud *h, const float *depth, size_t depth_stride, const uint8_t *rgb,
                                  size_t rgb_stride, int32_t width, int32_t height, float fx, float fy, float cx,
                                  float cy, const float *Tcw);
+/* The outlier filter of the shutdown pass (PointCloudMap.cc:46-47: sor.setMeanK(50), sor.setStddevMulThresh(1.0);
+ * :283-285: sor.setInputCloud(globalMap); sor.filter(*tmp); globalMap->swap(*tmp)), applied to the handle's map in
+ * place; the points that stay keep their order.  pcl::StatisticalOutlierRemoval is restated from PCL 1.7
+ * (filters/impl/statistical_outlier_removal.hpp -- PCL is not vendored by the reference: unpinned): mean distance of
+ * every point to its mean_k nearest neighbours (exact search, float squared distances as FLANN's L2_Simple, summed
+ * in double), a point goes when that exceeds mean + stddev_mul * stddev of all of them.  mean_k <= 63; needs more
+ * than mean_k points (PCL reads past the neighbour list otherwise).  removed may be NULL. */
+int orbgpu_cloud_remove_outliers(orbgpu_cloud *h, int32_t mean_k, double stddev_mul, int64_t *removed);
 int orbgpu_cloud_size(orbgpu_cloud *h, int64_t *n);
 /* Global map in ascending voxel-index order (pcl::VoxelGrid output order). */
 int orbgpu_cloud_download(orbgpu_cloud *h, orbgpu_point_xyzrgba *out, int64_t cap, int64_t *n);
@@ -592,6 +600,12 @@ int orbgpu_backproject(const float *depth, size_t depth_stride, const uint8_t *r
 int orbgpu_voxel_filter(const orbgpu_point_xyzrgba *in, int64_t n, double resolution, orbgpu_point_xyzrgba *out,
                         int64_t cap, int64_t *n_out, int32_t *overflow, int32_t device_id);
 
+/* pcl::StatisticalOutlierRemoval<PointXYZRGBA>::filter on host points (see orbgpu_cloud_remove_outliers).  cap >= n;
+ * mean_dist ([n], may be NULL) receives every point's mean neighbour distance (0 for non-finite points, which stay). */
+int orbgpu_statistical_outlier_removal(const orbgpu_point_xyzrgba *in, int64_t n, int32_t mean_k, double stddev_mul,
+                                       orbgpu_point_xyzrgba *out, int64_t cap, int64_t *n_out, float *mean_dist,
+                                       int32_t device_id);
+
 /* ======================================================================================
  * On-disk formats of the end-of-run artefacts: host serialisers, byte for byte.
  * ====================================================================================== */
@@ -611,7 +625,8 @@ int orbgpu_write_keyframe_record(uint64_t id, double timestamp, const float *Tcw
  * as recalled -- unpinned): header, then n packed (x, y, z, rgba) records of 16 bytes. */
 int orbgpu_pcd_binary_header(int64_t n_points, char *buf, size_t cap, size_t *len);
 int orbgpu_write_pcd_binary(const char *path, const orbgpu_point_xyzrgba *points, int64_t n);
-/* optimized_pointcloud.pcd without the StatisticalOutlierRemoval pass (out of scope): the handle's map. */
+/* pcl::io::savePCDFileBinary("optimized_pointcloud.pcd", *globalMap) (PointCloudMap.cc:287): the handle's map as it
+ * is (call orbgpu_cloud_remove_outliers first for the reference's shutdown sequence). */
 int orbgpu_cloud_save_pcd(orbgpu_cloud *h, const char *path);
 
 #ifdef __cplusplus

@@ -112,6 +112,8 @@ def lib(path=None):
     L.ora_pose_inverse.argtypes = [vp, vp, vp]
     L.ora_transform_points.argtypes = [vp, ci, vp, vp, vp]
     L.ora_voxel_filter.argtypes = [vp, ci, cf, vp, vp]
+    L.ora_statistical_outlier_removal.argtypes = [vp, ci, ci, C.c_double, vp, vp]
+    L.ora_statistical_outlier_removal.restype = ci
     L.ora_vocabulary_create.restype = vp
     L.ora_vocabulary_create.argtypes = [ci, ci, ci, vp, vp, vp, vp, ci, ci]
     L.ora_vocabulary_destroy.argtypes = [vp]
@@ -478,6 +480,17 @@ def voxel_filter(pts, leaf):
     ov = C.c_int(0)
     n = lib().ora_voxel_filter(_p(pts), len(pts), leaf, _p(out), C.byref(ov))
     return out[:n].copy(), bool(ov.value)
+
+
+def statistical_outlier_removal(pts, mean_k=50, stddev_mul=1.0):
+    """pcl::StatisticalOutlierRemoval (brute-force neighbours): (kept points, mean neighbour distance of every point)."""
+    pts = np.ascontiguousarray(pts, POINT_DTYPE)
+    out = np.zeros(max(1, len(pts)), POINT_DTYPE)
+    md = np.zeros(max(1, len(pts)), np.float32)
+    n = lib().ora_statistical_outlier_removal(_p(pts), len(pts), mean_k, stddev_mul, _p(out), _p(md))
+    if n < 0:
+        raise ValueError("statistical_outlier_removal: needs more than mean_k finite points")
+    return out[:n].copy(), md[:len(pts)].copy()
 
 
 class Vocabulary:

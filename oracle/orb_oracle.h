@@ -249,6 +249,11 @@ void ora_transform_points(const ora_point *in, int n, const double R[9], const d
  * Output ascending voxel index. Returns output count; if the index space would overflow
  * int32 the input is returned unfiltered (PCL behaviour) and *overflow is set. */
 int ora_voxel_filter(const ora_point *in, int n, float leaf, ora_point *out, int *overflow);
+/* pcl::StatisticalOutlierRemoval::filter (PointCloudMap.cc:46-47, 283-285; PCL 1.7 applyFilterIndices, brute-force
+ * neighbours).  Returns the number of points kept (-1: bad arguments or fewer than mean_k + 1 finite points);
+ * mean_dist[n] (may be NULL) receives every point's mean neighbour distance. */
+int ora_statistical_outlier_removal(const ora_point *in, int n, int mean_k, double stddev_mul, ora_point *out,
+                                    float *mean_dist);
 
 /* ---- M6: background-thread matchers (orb_oracle_match.c); see the function comments there ---- */
 int ora_fuse(const ora_frame_view *kf, const float *Tcw, float fx, float fy, float cx, float cy, float bf,

@@ -218,3 +218,83 @@ int ora_voxel_filter(const ora_point *in, int n, float leaf, ora_point *out, int
     free(iv);
     return nout;
 }
+
+/* ---- pcl::StatisticalOutlierRemoval<PointXYZRGBA>::filter as PointCloudMapping::viewer uses it at shutdown
+ * (PointCloudMap.cc:46-47: setMeanK(50), setStddevMulThresh(1.0); :283-285: sor.filter of the concatenated key-frame
+ * clouds).  Restated from PCL 1.7 filters/impl/statistical_outlier_removal.hpp (applyFilterIndices) -- PCL is not
+ * vendored in the reference: third-party boundary, unpinned:
+ *   - per finite point: nearestKSearch(point, mean_k + 1) on a kd-tree of the finite points, squared distances in
+ *     float (FLANN L2_Simple<float>: ((dx*dx) + dy*dy) + dz*dz), ascending; entry 0 is the query point itself;
+ *     dist_sum (double) += sqrt(nn_dists[k]) for k = 1 .. mean_k -- ::sqrt(double) of the promoted float, the
+ *     overload a gnu++98 libstdc++ of PCL 1.7's time resolves the unqualified call to;
+ *     distances[i] = (float)(dist_sum / mean_k);  non-finite points get 0 and do not count;
+ *   - sum += distances[i], sq_sum += distances[i] * distances[i] (a float product) over all points, in index order;
+ *     mean = sum / valid, variance = (sq_sum - sum * sum / valid) / (valid - 1), threshold = mean + mul * sqrt(variance);
+ *   - a point is removed iff distances[i] > threshold; the others keep their order.
+ * The exact kd-tree search is replaced by brute force (same multiset of the mean_k + 1 smallest distances).
+ * Needs n_finite > mean_k (PCL reads past the neighbour list otherwise).  mean_dist (n floats) may be NULL.
+ * Returns the number of points kept, -1 on bad arguments. */
+static int sor_cmp_float(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+int ora_statistical_outlier_removal(const ora_point *in, int n, int mean_k, double stddev_mul, ora_point *out,
+                                    float *mean_dist)
+{
+    if (n <= 0 || mean_k < 1)
+        return -1;
+    int nfinite = 0;
+    for (int i = 0; i < n; i++)
+        nfinite += isfinite(in[i].x) && isfinite(in[i].y) && isfinite(in[i].z);
+    if (nfinite <= mean_k)
+        return -1;
+    float *dist = (float *)malloc(sizeof(float) * (size_t)n);
+    float *d2 = (float *)malloc(sizeof(float) * (size_t)nfinite);
+    int valid = 0;
+    for (int i = 0; i < n; i++) {
+        const ora_point *p = &in[i];
+        if (!(isfinite(p->x) && isfinite(p->y) && isfinite(p->z))) {
+            dist[i] = 0.0f;
+            continue;
+        }
+        int m = 0;
+        for (int j = 0; j < n; j++) {
+            const ora_point *q = &in[j];
+            if (!(isfinite(q->x) && isfinite(q->y) && isfinite(q->z)))
+                continue;
+            const float dx = p->x - q->x, dy = p->y - q->y, dz = p->z - q->z;
+            float r = 0.0f;
+            r += dx * dx;
+            r += dy * dy;
+            r += dz * dz;
+            d2[m++] = r;
+        }
+        qsort(d2, (size_t)m, sizeof(float), sor_cmp_float);
+        double dist_sum = 0.0;
+        for (int k = 1; k < mean_k + 1; k++)
+            dist_sum += sqrt((double)d2[k]);
+        dist[i] = (float)(dist_sum / mean_k);
+        valid++;
+    }
+    double sum = 0, sq_sum = 0;
+    for (int i = 0; i < n; i++) {
+        sum += dist[i];
+        sq_sum += dist[i] * dist[i];
+    }
+    const double mean = sum / (double)valid;
+    const double variance = (sq_sum - sum * sum / (double)valid) / ((double)valid - 1);
+    const double stddev = sqrt(variance);
+    const double distance_threshold = mean + stddev_mul * stddev;
+    int kept = 0;
+    for (int i = 0; i < n; i++) {
+        if (mean_dist)
+            mean_dist[i] = dist[i];
+        if (dist[i] > distance_threshold)
+            continue;
+        out[kept++] = in[i];
+    }
+    free(dist);
+    free(d2);
+    return kept;
+}

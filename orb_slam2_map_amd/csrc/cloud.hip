@@ -23,6 +23,8 @@
 // paths, so the per-voxel float sums are reproducible.  HBM-bound integer/float streaming; no MFMA.
 #include "common.h"
 
+#include <cstring>
+
 #include <algorithm>
 #include <cmath>
 #include <new>
@@ -1017,6 +1019,226 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
 }
 
 // ------------------------------------------------------------------------------------------
+// StatisticalOutlierRemoval: the mean distance of every point to its mean_k nearest neighbours
+// (PointCloudMap.cc:46-47, 283-285; PCL 1.7 filters/impl/statistical_outlier_removal.hpp).
+//
+// The exact kd-tree search becomes an exact search on a uniform grid: points sorted by cell index (the radix sort
+// above), so the points of a run of cells along x are one contiguous range found with two binary searches.  One wave
+// per query point scans the (2S+1)^3 block of cells around its own cell, S = 1, 2, ..., keeping the mean_k + 1
+// smallest squared distances (only the distances matter); once the block holds mean_k + 1 points whose farthest is
+// nearer than S cells, nothing outside can be nearer and the search ends.  Squared distances are FLANN's
+// L2_Simple<float> ((dx*dx + dy*dy) + dz*dz, no contraction), the mean is summed in double in ascending order like
+// PCL's loop over the sorted neighbour list.
+// ------------------------------------------------------------------------------------------
+struct SorGrid {
+    float mn[3];
+    float h, inv_h;
+    int dim[3];
+};
+
+constexpr int SOR_MAX_K = 63;  // mean_k + 1 distances fit one wave
+constexpr int SOR_BUF = 128;   // candidate distances a wave holds between selections
+
+__global__ __launch_bounds__(256) void k_sor_box(const Point *__restrict__ pts, int n, unsigned *__restrict__ box6,
+                                                 int *__restrict__ nfinite)
+{
+    __shared__ Box s_box[4];
+    Box bx;
+    box_init(bx);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        box_add(bx, pts[i]);
+    box_block_reduce(bx, s_box);
+    if (threadIdx.x == 0) {
+        box_atomic(box6, bx);
+        if (bx.nfinite)
+            atomicAdd(nfinite, bx.nfinite);
+    }
+}
+
+__device__ __forceinline__ uint32_t sor_key(const Point &p, const SorGrid &g)
+{
+    if (!isfinite(p.x) || !isfinite(p.y) || !isfinite(p.z))
+        return 0xFFFFFFFFu;
+    const int cx = min(max((int)floorf((p.x - g.mn[0]) * g.inv_h), 0), g.dim[0] - 1);
+    const int cy = min(max((int)floorf((p.y - g.mn[1]) * g.inv_h), 0), g.dim[1] - 1);
+    const int cz = min(max((int)floorf((p.z - g.mn[2]) * g.inv_h), 0), g.dim[2] - 1);
+    return (uint32_t)((cz * g.dim[1] + cy) * g.dim[0] + cx);
+}
+
+__global__ __launch_bounds__(256) void k_sor_keys(const Point *__restrict__ pts, int n, SorGrid g,
+                                                  uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                  unsigned *__restrict__ ghist, CloudState *__restrict__ st)
+{
+    __shared__ unsigned s_h[4 * 256];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->n_sort = n;
+        st->overflow = 0;
+    }
+    for (int i = threadIdx.x; i < 4 * 256; i += 256)
+        s_h[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long i = (long long)blockIdx.x * TILE + k * 256 + threadIdx.x;
+        if (i < n) {
+            const uint32_t key = sor_key(pts[i], g);
+            keys[i] = key;
+            vals[i] = (uint32_t)i;
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++)
+                atomicAdd(&s_h[ps * 256 + ((key >> (8 * ps)) & 255u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * 256; i += 256)
+        if (s_h[i])
+            atomicAdd(&ghist[i], s_h[i]);
+}
+
+// occupied cells (distinct keys among the first nfinite sorted keys), for the choice of the cell size
+__global__ __launch_bounds__(256) void k_sor_count_cells(const uint32_t *__restrict__ keys, int nfinite,
+                                                         int *__restrict__ cells)
+{
+    int c = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nfinite; i += (long long)gridDim.x * 256)
+        c += (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    c = wave_reduce_add(c);
+    if ((threadIdx.x & 63) == 0 && c)
+        atomicAdd(cells, c);
+}
+
+__global__ __launch_bounds__(256) void k_sor_gather(const Point *__restrict__ pts, const uint32_t *__restrict__ vals,
+                                                    int n, float4 *__restrict__ sorted)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r < n) {
+        const Point p = pts[vals[r]];
+        sorted[r] = make_float4(p.x, p.y, p.z, 0.f);
+    }
+}
+
+// ascending bitonic sort of the SOR_BUF floats of one wave's LDS buffer (two elements per lane and step)
+__device__ __forceinline__ void sor_sort(float *buf, int lane)
+{
+    for (int k = 2; k <= SOR_BUF; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int t = lane + 64 * half;
+                const int o = t ^ j;
+                if (o > t) {
+                    const float a = buf[t], b = buf[o];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) {
+                        buf[t] = b;
+                        buf[o] = a;
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256) void k_sor_knn(const float4 *__restrict__ sorted, const uint32_t *__restrict__ keys,
+                                                 const uint32_t *__restrict__ vals, int n, int nfinite, SorGrid g,
+                                                 int mean_k, float *__restrict__ mean_dist)
+{
+    __shared__ float s_buf[4][SOR_BUF];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * 4 + wave;  // query = r-th point in cell order
+    if (r >= n)
+        return;
+    if (r >= nfinite) {  // non-finite points sort to the end: distance 0, no neighbours (PCL: `continue`)
+        if (lane == 0)
+            mean_dist[vals[r]] = 0.0f;
+        return;
+    }
+    float *buf = s_buf[wave];
+    const float4 q = sorted[r];
+    const uint32_t key = keys[r];
+    const int cx = (int)(key % (uint32_t)g.dim[0]), cy = (int)((key / (uint32_t)g.dim[0]) % (uint32_t)g.dim[1]),
+              cz = (int)(key / ((uint32_t)g.dim[0] * (uint32_t)g.dim[1]));
+    const int need = mean_k + 1;
+    for (int S = 1;; S++) {
+        const int x0 = max(cx - S, 0), x1 = min(cx + S, g.dim[0] - 1);
+        const int y0 = max(cy - S, 0), y1 = min(cy + S, g.dim[1] - 1);
+        const int z0 = max(cz - S, 0), z1 = min(cz + S, g.dim[2] - 1);
+        const int ny = y1 - y0 + 1, nruns = ny * (z1 - z0 + 1);
+        int cnt = 0;              // distances in buf (wave-uniform)
+        float tau = INFINITY;     // nothing above it can be among the `need` smallest
+        for (int run0 = 0; run0 < nruns; run0 += 32) {
+            // lanes 2i / 2i+1: first / one-past-last sorted position of run run0 + i (the cells x0..x1 of one (y, z))
+            const int ri = run0 + (lane >> 1);
+            int pos = 0;
+            if (ri < nruns) {
+                const int yy = y0 + ri % ny, zz = z0 + ri / ny;
+                const uint32_t base = (uint32_t)((zz * g.dim[1] + yy) * g.dim[0]);
+                const uint32_t target = (lane & 1) ? base + (uint32_t)x1 : base + (uint32_t)x0;
+                int lo = 0, hi = nfinite;  // lower_bound (even lanes) / upper_bound (odd lanes)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const uint32_t km = keys[mid];
+                    if ((lane & 1) ? km <= target : km < target)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                pos = lo;
+            }
+            const int nr = min(32, nruns - run0);
+            for (int i = 0; i < nr; i++) {
+                const int beg = __shfl(pos, 2 * i, 64), end = __shfl(pos, 2 * i + 1, 64);
+                for (int j0 = beg; j0 < end; j0 += 64) {
+                    const int j = j0 + lane;
+                    float d2 = INFINITY;
+                    if (j < end) {
+                        const float4 p = sorted[j];
+                        const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+                        d2 = dx * dx;
+                        d2 += dy * dy;
+                        d2 += dz * dz;
+                    }
+                    const bool keep = j < end && d2 <= tau;
+                    const unsigned long long m = __ballot(keep);
+                    if (keep)
+                        buf[cnt + __popcll(m & ((1ull << lane) - 1ull))] = d2;
+                    cnt += __popcll(m);
+                    if (cnt > SOR_BUF - 64) {  // make room for the next 64: keep the `need` smallest
+                        for (int t = cnt + lane; t < SOR_BUF; t += 64)
+                            buf[t] = INFINITY;
+                        sor_sort(buf, lane);
+                        cnt = min(cnt, need);
+                        if (cnt == need)
+                            tau = buf[need - 1];
+                    }
+                }
+            }
+        }
+        for (int t = cnt + lane; t < SOR_BUF; t += 64)
+            buf[t] = INFINITY;
+        sor_sort(buf, lane);
+        const bool covered = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1;
+        // a point outside the block is at least S cells away along one axis (0.1 % slack for the rounding of the cell
+        // coordinates)
+        const float reach = (float)S * g.h * 0.999f;
+        if (covered || (cnt >= need && buf[need - 1] <= reach * reach))
+            break;
+    }
+    if (lane == 0) {
+        double dist_sum = 0.0;
+        for (int k = 1; k < need; k++)  // entry 0 is the query point itself (distance 0)
+            dist_sum += sqrt((double)buf[k]);
+        mean_dist[vals[r]] = (float)(dist_sum / (double)mean_k);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct VoxelWorkspace {
@@ -1254,6 +1476,153 @@ static int upload_frame(FrameStage &fs, const float *depth, size_t dstride, cons
                                     hipMemcpyHostToDevice, st));
     ORBGPU_HIP_TRY(hipMemcpy2DAsync(fs.rgb.p, (size_t)w * 3, rgb, cstride, (size_t)w * 3, h, hipMemcpyHostToDevice, st));
     return ORBGPU_OK;
+}
+
+// ---- StatisticalOutlierRemoval on device points: mean neighbour distance of every point -> d_mean_dist[n] ----------
+// Cell size: a pilot pass at a coarse cell size counts the occupied cells; the clouds this runs on are surfaces, where
+// the points per cell grow with h^2, so h is rescaled to about SOR_CELL_POINTS points per cell (any h is exact, the
+// choice only decides how many candidates a query scans and how often it needs a second shell).
+constexpr double SOR_CELL_POINTS = 8.0;
+
+static int sor_grid_for(const float mn[3], const float mx[3], double h, SorGrid &g)
+{
+    for (;;) {
+        double cells = 1.0;
+        for (int a = 0; a < 3; a++) {
+            g.mn[a] = mn[a];
+            const double d = std::floor(((double)mx[a] - (double)mn[a]) / h) + 1.0;
+            g.dim[a] = (int)std::min(d, 2.0e9);
+            cells *= d;
+        }
+        if (cells < 4.0e9)
+            break;
+        h *= 1.5;  // the cell index must fit 32 bits
+    }
+    g.h = (float)h;
+    g.inv_h = 1.0f / g.h;
+    return ORBGPU_OK;
+}
+
+static int sor_sort_cells(VoxelWorkspace &ws, const Point *d_pts, long long n, const SorGrid &g, hipStream_t st)
+{
+    const int nt = tiles_of(n);
+    ORBGPU_HIP_TRY(hipMemsetAsync(ws.ghist.p, 0, sizeof(unsigned) * 4 * 256, st));
+    hipLaunchKernelGGL(k_sor_keys, dim3(nt), dim3(256), 0, st, d_pts, (int)n, g, ws.keys[0].as<uint32_t>(),
+                       ws.vals[0].as<uint32_t>(), ws.ghist.as<unsigned>(), ws.state.as<CloudState>());
+    radix_sort_device(ws, nt, st);
+    ORBGPU_HIP_TRY(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+static int sor_mean_distances(VoxelWorkspace &ws, const Point *d_pts, long long n, int mean_k, float *d_mean_dist,
+                              long long *nfinite_out, hipStream_t st)
+{
+    ORBGPU_REQUIRE(n >= 1 && n < (1ll << 30), "statistical outlier removal: bad point count %lld", n);
+    ORBGPU_REQUIRE(mean_k >= 1 && mean_k <= SOR_MAX_K, "mean_k must be in [1, %d]", SOR_MAX_K);
+    int rc = ws.reserve(n, 1);
+    if (rc != ORBGPU_OK)
+        return rc;
+    DevBuf scratch, sorted;
+    auto done = [&](int code) {
+        scratch.release();
+        sorted.release();
+        return code;
+    };
+    if ((rc = scratch.reserve(sizeof(unsigned) * 8)) != ORBGPU_OK || (rc = sorted.reserve(sizeof(float4) * (size_t)n)) != ORBGPU_OK)
+        return done(rc);
+    // bounding box and count of the finite points
+    unsigned hbox[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};  // mn[3], mx[3], nfinite, cells
+    hipError_t e = hipMemcpyAsync(scratch.p, hbox, sizeof(hbox), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const int nb = (int)std::min<long long>((n + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_sor_box, dim3(nb), dim3(256), 0, st, d_pts, (int)n, scratch.as<unsigned>(),
+                           reinterpret_cast<int *>(scratch.as<unsigned>() + 6));
+        e = hipMemcpyAsync(hbox, scratch.p, sizeof(hbox), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        set_error("statistical outlier removal: %s", hipGetErrorString(e));
+        return done(ORBGPU_EHIP);
+    }
+    const long long nfinite = (long long)hbox[6];
+    *nfinite_out = nfinite;
+    if (nfinite <= mean_k) {
+        set_error("statistical outlier removal needs more than mean_k = %d finite points (%lld given): PCL reads past "
+                  "the neighbour list", mean_k, nfinite);
+        return done(ORBGPU_EINVAL);
+    }
+    auto ord2f_host = [](unsigned o) {
+        const unsigned b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+        float f;
+        memcpy(&f, &b, 4);
+        return f;
+    };
+    float mn[3], mx[3];
+    double ext = 0;
+    for (int a = 0; a < 3; a++) {
+        mn[a] = ord2f_host(hbox[a]);
+        mx[a] = ord2f_host(hbox[3 + a]);
+        ext = std::max(ext, (double)mx[a] - (double)mn[a]);
+    }
+    SorGrid g;
+    double h = std::max(ext / 256.0, 1e-6);
+    if (ext > 0) {
+        // pilot: occupied cells at a coarse size
+        sor_grid_for(mn, mx, h, g);
+        if ((rc = sor_sort_cells(ws, d_pts, n, g, st)) != ORBGPU_OK)
+            return done(rc);
+        const int nbc = (int)std::min<long long>((nfinite + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_sor_count_cells, dim3(nbc), dim3(256), 0, st, ws.keys[0].as<uint32_t>(), (int)nfinite,
+                           reinterpret_cast<int *>(scratch.as<unsigned>() + 7));
+        e = hipMemcpyAsync(hbox, scratch.p, sizeof(hbox), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            set_error("statistical outlier removal: %s", hipGetErrorString(e));
+            return done(ORBGPU_EHIP);
+        }
+        const double per_cell = (double)nfinite / (double)std::max(hbox[7], 1u);
+        h = g.h * std::sqrt(SOR_CELL_POINTS / per_cell);
+        h = std::min(std::max(h, ext / 4096.0), ext);
+    }
+    sor_grid_for(mn, mx, h, g);
+    if ((rc = sor_sort_cells(ws, d_pts, n, g, st)) != ORBGPU_OK)
+        return done(rc);
+    hipLaunchKernelGGL(k_sor_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_pts, ws.vals[0].as<uint32_t>(),
+                       (int)n, sorted.as<float4>());
+    hipLaunchKernelGGL(k_sor_knn, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, sorted.as<float4>(),
+                       ws.keys[0].as<uint32_t>(), ws.vals[0].as<uint32_t>(), (int)n, (int)nfinite, g, mean_k, d_mean_dist);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        set_error("statistical outlier removal: %s", hipGetErrorString(e));
+        return done(ORBGPU_EHIP);
+    }
+    return done(ORBGPU_OK);
+}
+
+// PCL's statistics and selection (applyFilterIndices): sequential double sums over the float distances in index order
+// -- host work, like the std::vector loops they restate.  keep[i] = 1 for the points that stay.
+static long long sor_select(const float *dist, long long n, long long nfinite, double stddev_mul, uint8_t *keep)
+{
+    double sum = 0, sq_sum = 0;
+    for (long long i = 0; i < n; i++) {
+        sum += dist[i];
+        sq_sum += dist[i] * dist[i];  // a float product, as in PCL
+    }
+    const double valid = (double)nfinite;
+    const double mean = sum / valid;
+    const double variance = (sq_sum - sum * sum / valid) / (valid - 1);
+    const double stddev = sqrt(variance);
+    const double distance_threshold = mean + stddev_mul * stddev;
+    long long kept = 0;
+    for (long long i = 0; i < n; i++) {
+        keep[i] = !(dist[i] > distance_threshold);
+        kept += keep[i];
+    }
+    return kept;
 }
 
 } // namespace orbgpu
@@ -1588,6 +1957,107 @@ int orbgpu_cloud_append_filtered(orbgpu_cloud *c, const float *depth, size_t dst
         return rc;
     return cloud_append_filtered_device(c, c->fs.depth.as<float>(), (size_t)w, c->fs.rgb.as<uint8_t>(), (size_t)w * 3, w, h,
                                         fx, fy, cx, cy, Tcw);
+}
+
+// sor.setInputCloud(globalMap); sor.filter(*tmp); globalMap->swap(*tmp)  (PointCloudMap.cc:283-285)
+int orbgpu_cloud_remove_outliers(orbgpu_cloud *c, int32_t mean_k, double stddev_mul, int64_t *removed)
+{
+    ORBGPU_REQUIRE(c, "null argument");
+    int rc = select_device(c->device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    if (removed)
+        *removed = 0;
+    const long long n = c->size;
+    ORBGPU_REQUIRE(n > mean_k, "statistical outlier removal needs more than mean_k = %d points (the map holds %lld)", mean_k, n);
+    DevBuf ddist;
+    if ((rc = ddist.reserve(sizeof(float) * (size_t)n)) != ORBGPU_OK)
+        return rc;
+    long long nfinite = 0;
+    rc = sor_mean_distances(c->ws, c->map[c->cur].as<Point>(), n, mean_k, ddist.as<float>(), &nfinite, c->stream);
+    std::vector<float> dist;
+    std::vector<Point> pts;
+    std::vector<uint8_t> keep;
+    if (rc == ORBGPU_OK) {
+        dist.resize((size_t)n);
+        pts.resize((size_t)n);
+        keep.resize((size_t)n);
+        hipError_t e = hipMemcpy(dist.data(), ddist.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(pts.data(), c->map[c->cur].p, sizeof(Point) * (size_t)n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            const long long kept = sor_select(dist.data(), n, nfinite, stddev_mul, keep.data());
+            long long o = 0;
+            for (long long i = 0; i < n; i++)
+                if (keep[(size_t)i])
+                    pts[(size_t)o++] = pts[(size_t)i];
+            if (kept > 0)
+                e = hipMemcpy(c->map[c->cur].p, pts.data(), sizeof(Point) * (size_t)kept, hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                c->size = kept;
+                c->sorted_map = false;  // the next insert re-derives order and bounding box from the points
+                if (removed)
+                    *removed = n - kept;
+            }
+        }
+        if (e != hipSuccess) {
+            set_error("cloud_remove_outliers: %s", hipGetErrorString(e));
+            rc = ORBGPU_EHIP;
+        }
+    }
+    ddist.release();
+    return rc;
+}
+
+// pcl::StatisticalOutlierRemoval<PointXYZRGBA>::filter on host points (stateless, for parity tests and other callers)
+int orbgpu_statistical_outlier_removal(const orbgpu_point_xyzrgba *in, int64_t n, int32_t mean_k, double stddev_mul,
+                                       orbgpu_point_xyzrgba *out, int64_t cap, int64_t *n_out, float *mean_dist,
+                                       int32_t device_id)
+{
+    ORBGPU_REQUIRE(in && out && n_out && n >= 1 && n < (1ll << 30), "bad arguments");
+    ORBGPU_REQUIRE(cap >= n, "cap must be >= n");
+    int rc = select_device(device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    *n_out = 0;
+    VoxelWorkspace ws;
+    DevBuf din, ddist;
+    auto cleanup = [&]() {
+        ws.release();
+        din.release();
+        ddist.release();
+    };
+    if ((rc = din.reserve(sizeof(Point) * (size_t)n)) != ORBGPU_OK || (rc = ddist.reserve(sizeof(float) * (size_t)n)) != ORBGPU_OK) {
+        cleanup();
+        return rc;
+    }
+    hipError_t e = hipMemcpy(din.p, in, sizeof(Point) * (size_t)n, hipMemcpyHostToDevice);
+    long long nfinite = 0;
+    if (e == hipSuccess) {
+        rc = sor_mean_distances(ws, din.as<Point>(), n, mean_k, ddist.as<float>(), &nfinite, nullptr);
+        if (rc == ORBGPU_OK) {
+            std::vector<float> dist((size_t)n);
+            std::vector<uint8_t> keep((size_t)n);
+            e = hipMemcpy(dist.data(), ddist.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) {
+                sor_select(dist.data(), n, nfinite, stddev_mul, keep.data());
+                int64_t o = 0;
+                for (int64_t i = 0; i < n; i++) {
+                    if (mean_dist)
+                        mean_dist[i] = dist[(size_t)i];
+                    if (keep[(size_t)i])
+                        out[o++] = in[i];
+                }
+                *n_out = o;
+            }
+        }
+    }
+    if (e != hipSuccess) {
+        set_error("statistical_outlier_removal: %s", hipGetErrorString(e));
+        rc = ORBGPU_EHIP;
+    }
+    cleanup();
+    return rc;
 }
 
 int orbgpu_cloud_size(orbgpu_cloud *c, int64_t *n)

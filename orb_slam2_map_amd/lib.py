@@ -127,7 +127,7 @@ ABI_SYMBOLS = [
     "orbgpu_cloud_create", "orbgpu_cloud_destroy", "orbgpu_cloud_insert", "orbgpu_cloud_insert_device",
     "orbgpu_cloud_clear", "orbgpu_cloud_append_filtered", "orbgpu_cloud_last_path", "orbgpu_cloud_set_profiling", "orbgpu_cloud_last_insert_ms", "orbgpu_cloud_rebuild",
     "orbgpu_cloud_size", "orbgpu_cloud_download", "orbgpu_cloud_last_overflow", "orbgpu_backproject",
-    "orbgpu_voxel_filter",
+    "orbgpu_voxel_filter", "orbgpu_cloud_remove_outliers", "orbgpu_statistical_outlier_removal",
 ]
 
 
@@ -199,6 +199,8 @@ def lib():
         "orbgpu_cloud_last_overflow": [vp, vp],
         "orbgpu_backproject": [vp, sz, vp, sz, i32, i32, f32, f32, f32, f32, vp, vp, C.c_int64, vp, i32],
         "orbgpu_voxel_filter": [vp, C.c_int64, C.c_double, vp, C.c_int64, vp, vp, i32],
+        "orbgpu_cloud_remove_outliers": [vp, i32, C.c_double, vp],
+        "orbgpu_statistical_outlier_removal": [vp, C.c_int64, i32, C.c_double, vp, C.c_int64, vp, vp, i32],
     }
     for name, args in sigs.items():
         fn = getattr(L, name, None)
@@ -923,6 +925,12 @@ class PointCloudMapping:
         check(self.L.orbgpu_cloud_append_filtered(self.h, _p(depth), depth.strides[0] // 4, _p(rgb), rgb.strides[0], w, h,
                                                   fx, fy, cx, cy, _p(T)))
 
+    def remove_outliers(self, mean_k=50, stddev_mul=1.0):
+        """sor.filter of the global map (PointCloudMap.cc:283-285); returns the number of points removed."""
+        r = C.c_int64()
+        check(self.L.orbgpu_cloud_remove_outliers(self.h, mean_k, float(stddev_mul), C.byref(r)))
+        return r.value
+
     def save_pcd(self, path):
         self.L.orbgpu_cloud_save_pcd.argtypes = [C.c_void_p, C.c_char_p]
         check(self.L.orbgpu_cloud_save_pcd(self.h, path.encode()))
@@ -973,6 +981,17 @@ def backproject(depth, rgb, fx, fy, cx, cy, Tcw=None, device_id=0):
     check(lib().orbgpu_backproject(_p(depth), depth.strides[0] // 4, _p(rgb), rgb.strides[0], w, h, fx, fy, cx, cy,
                                    _p(T), _p(out), max(1, cap), C.byref(n), device_id))
     return out[:n.value].copy()
+
+
+def statistical_outlier_removal(points, mean_k=50, stddev_mul=1.0, device_id=0):
+    """pcl::StatisticalOutlierRemoval::filter: (kept points, mean neighbour distance of every input point)."""
+    points = np.ascontiguousarray(points, POINT_DTYPE)
+    out = np.zeros(max(1, len(points)), POINT_DTYPE)
+    md = np.zeros(max(1, len(points)), np.float32)
+    n = C.c_int64()
+    check(lib().orbgpu_statistical_outlier_removal(_p(points), len(points), mean_k, float(stddev_mul), _p(out),
+                                                   max(1, len(points)), C.byref(n), _p(md), device_id))
+    return out[:n.value].copy(), md[:len(points)].copy()
 
 
 def voxel_filter(points, resolution, device_id=0):

@@ -480,7 +480,7 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
 // the GPU.  KeyFrameT needs mImDep (float depth), mImRGB (8UC3), fx, fy, cx, cy and GetPose();
 // the Adapter adapts cv::Mat (or a stand-in): depth(kf), rgb(kf) -> ImageView, pose(kf, float[16]),
 // fx/fy/cx/cy(kf), and -- only for the loop-closure branch -- id(kf) (mnId) and isBad(kf).
-// Visualisation and StatisticalOutlierRemoval stay out; the PCD writer is
+// Visualisation stays out; the outlier filter of the shutdown pass is orbgpu_cloud_remove_outliers, the PCD writer
 // orbgpu_cloud_save_pcd.
 //
 // viewer() follows PointCloudMap.cc:182-289 branch by branch:
@@ -491,8 +491,9 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
 //   * otherwise (:244-267) the new key frames are inserted.  The reference transforms only the LAST new cloud with
 //     the pose of the FIRST new key frame (:246-247) and, in the loop branch, does not advance lastKeyframeSize:
 //     setReferenceQuirks(true) reproduces both; by default every new key frame is inserted with its own pose;
-//   * after the loop (:270-288): clear, per key frame generatePointCloud + voxel.filter + `+=`, then (instead of
-//     sor.filter + savePCDFileBinary) the map is written with orbgpu_cloud_save_pcd if an output path is set.
+//   * after the loop (:270-288): clear, per key frame generatePointCloud + voxel.filter + `+=`, then sor.filter
+//     (meanK 50, stddev factor 1.0: the constructor's settings, :46-47) and, if an output path is set,
+//     savePCDFileBinary.  A map of meanK points or fewer is left unfiltered (PCL reads past its neighbour list there).
 // --------------------------------------------------------------------------------------------
 struct ImageView {
     const void *data;
@@ -525,6 +526,8 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
     void setReferenceQuirks(bool on) { quirks = on; }
     // "optimized_pointcloud.pcd" in the reference (:287); empty (default) = do not write a file
     void setOutputPath(const std::string &path) { outputPath = path; }
+    // the reference fixes these in its constructor (:46-47); meanK <= 0 skips the filter
+    void setOutlierFilter(int meanK, double stddevMul) { sorMeanK = meanK, sorStddevMul = stddevMul; }
 
     void insertKeyFrame(KeyFrameT *kf)  // PointCloudMap.cc:69-76
     {
@@ -630,6 +633,10 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
                                                    adapt.fy(kf), adapt.cx(kf), adapt.cy(kf), Tcw),
                       "PointCloudMapping::shutdown");
             }
+            int64_t npts = 0;
+            check(orbgpu_cloud_size(cloud_, &npts), "PointCloudMapping::shutdown");
+            if (sorMeanK > 0 && npts > sorMeanK)  // :283-285
+                check(orbgpu_cloud_remove_outliers(cloud_, sorMeanK, sorStddevMul, nullptr), "PointCloudMapping::shutdown");
             if (!outputPath.empty())
                 check(orbgpu_cloud_save_pcd(cloud_, outputPath.c_str()), "PointCloudMapping::save");
         }
@@ -702,6 +709,8 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
     std::vector<KeyFrameT *> keyframes;
     size_t lastKeyframeSize = 0;
     double resolution = 0.01;
+    int sorMeanK = 50;          // sor.setMeanK(50), PointCloudMap.cc:46
+    double sorStddevMul = 1.0;  // sor.setStddevMulThresh(1.0), :47
     Adapter adapt;
     LoopHooks hooks;
     std::string outputPath;

@@ -165,7 +165,9 @@ def test_shim_end_to_end(gpu, oracle, stream640):
     oreb, _ = oracle.voxel_filter(np.concatenate([kf_cloud(poses[2]), kf_cloud(poses[0])]), 0.05)  # ids 8, (9 bad), 10
     cloud_b, off = read_cloud(off)
     assert cloud_b.tobytes() == oreb.tobytes(), "loop-closure rebuild: non-bad key frames in id order"
-    ofin = np.concatenate([oracle.voxel_filter(kf_cloud(T), 0.05)[0] for T in poses])
+    ocat = np.concatenate([oracle.voxel_filter(kf_cloud(T), 0.05)[0] for T in poses])
+    ofin, _ = oracle.statistical_outlier_removal(ocat, 50, 1.0)
+    assert 0 < len(ofin) < len(ocat)
     cloud_c, off = read_cloud(off)
-    assert cloud_c.tobytes() == ofin.tobytes(), "shutdown pass: per-key-frame filtered clouds, concatenated"
+    assert cloud_c.tobytes() == ofin.tobytes(), "shutdown pass: per-key-frame filtered clouds, concatenated, sor.filter"
     assert off == len(buf)
