@@ -80,8 +80,12 @@ int main(void)
     const int v1 = ora_voxel_filter(pts, np, 0.05f, out, &ov);
     pts[0].x = 5000.f;
     const int v2 = ora_voxel_filter(pts, np, 0.001f, out, &ov);
-    printf("sanitizer run ok: %d key points, %d bf matches, %d bow words, %d bow matches, %d / %d voxels (overflow %d)\n", n,
-           nm, nb, nbw, v1, v2, ov);
+    const int nsor = np < 1500 ? np : 1500;
+    float *md = (float *)malloc(sizeof(float) * (size_t)nsor);
+    const int v3 = ora_statistical_outlier_removal(pts, nsor, 50, 1.0, out, md);
+    free(md);
+    printf("sanitizer run ok: %d key points, %d bf matches, %d bow words, %d bow matches, %d / %d voxels (overflow %d), %d of %d "
+           "points kept by the outlier filter\n", n, nm, nb, nbw, v1, v2, ov, v3, nsor);
     ora_vocabulary_destroy(voc);
     ora_extractor_destroy(e);
     free(img), free(kps), free(desc), free(desc2), free(ang), free(match), free(match2), free(parent), free(leaf);
