@@ -795,7 +795,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
                                                   uint16_t *__restrict__ dense_node,
                                                   uint32_t *__restrict__ sel, int sel_cap_total,
                                                   int *__restrict__ nsel, int *__restrict__ ncand, int nlevels,
-                                                  int ncap, int t_ini, int kcap_arg, int ncells_lds, long long *dbg_t)
+                                                  int ncap, int t_ini, int kcap_arg, long long *dbg_t)
 {
     // section timestamps of workgroup (frame 0, level 0) for tools/qt_sections.py; compiled in with -DORBGPU_QT_TIMING
 #ifdef ORBGPU_QT_TIMING
@@ -842,7 +842,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         S.opos = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
         S.order = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
         S.inE = (uint8_t *)p; p += ((size_t)ncap + 3) / 4 * 4;
-        S.soff = (uint32_t *)p; p += sizeof(uint32_t) * ncells_lds;
+        // S.soff lives on the node-bound arrays (bndA + bndB = 4 ncap ints >= the cells of a level), which step 0 does not use
+        S.soff = (uint32_t *)smem;
         lkey = (uint32_t *)p; p += sizeof(uint32_t) * kcap;
         lnode = (uint16_t *)p;
     }
@@ -1210,8 +1211,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     QT_MARK(3)
     // ---- step 3: best response per node, first maximum in vToDistributeKeys order (:741-760): cells row-major
     //      (:789-829), inside a cell cv::FAST's row-major output -- i.e. ascending (cell row, cell column, y, x), all of
-    //      which the key holds.  One 64-bit maximum per node: response, then the inverted order, which is also enough to
-    //      rebuild the winning key.
+    //      which the key holds.  One 64-bit maximum per node: response + 1 (bits 40..), then the inverted order (cell
+    //      row 32..39, cell column 24..31, y 12..23, x 0..11), which is also enough to rebuild the winning key.
     const int n = s_n;
     unsigned long long *best = reinterpret_cast<unsigned long long *>(S.ccnt);  // [ncap*4] ints >= n 64-bit words
     for (int p = tid; p < n; p += nt)
@@ -1236,9 +1237,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             cj -= (cj * g.wcell > x - 3) ? 1 : 0;
             ci += ((ci + 1) * g.hcell <= y - 3) ? 1 : 0;
             ci -= (ci * g.hcell > y - 3) ? 1 : 0;
-            const unsigned long long ord = ((unsigned long long)ci << 31) | ((unsigned long long)cj << 24) | (key[u] >> 8);
+            const unsigned long long ord = ((unsigned long long)ci << 32) | ((unsigned long long)cj << 24) | (key[u] >> 8);
             if (i0 + u * nt < nkeys)
-                atomicMax(&best[nd[u]], ((unsigned long long)(key_resp(key[u]) + 1) << 38) | (0x3FFFFFFFFFull - ord));
+                atomicMax(&best[nd[u]], ((unsigned long long)(key_resp(key[u]) + 1) << 40) | (0xFFFFFFFFFFull - ord));
         }
     }
     __syncthreads();
@@ -1246,8 +1247,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     const bool ok = s_done != 2 && n <= g.sel_cap;
     for (int p = tid; p < n && ok; p += nt) {
         const unsigned long long b = best[p];
-        const uint32_t yx = (uint32_t)((0x3FFFFFFFFFull - b) & 0xFFFFFFull);
-        osel[p] = (yx << 8) | (uint32_t)((b >> 38) - 1ull);
+        const uint32_t yx = (uint32_t)((0xFFFFFFFFFFull - (b & 0xFFFFFFFFFFull)) & 0xFFFFFFull);
+        osel[p] = (yx << 8) | (uint32_t)((b >> 40) - 1ull);
     }
     QT_MARK(4)
     if (tid == 0)
@@ -1667,7 +1668,7 @@ struct orbgpu_extractor {
     size_t frame_pyr = 0, frame_slots = 0;
     int sel_cap_total = 0, ncap = 0, max_kp = 0;
     size_t qt_lds = 0;
-    int qt_kcap = 0, qt_cells = 0;  // keys of a level k_quadtree<true> keeps in LDS; cells of the largest level
+    int qt_kcap = 0;  // keys of a level k_quadtree<true> keeps in LDS
     // device state
     DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt, d_ctab, d_bcol;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
@@ -1894,8 +1895,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     ncap = std::max(ncap, (max_cells_level + 3) / 4);  // the cell scan reuses the [ncap*4] child-count array
     ncap = ((ncap + 7) / 8) * 8;
     const size_t qt_lds = (size_t)ncap * (2 * sizeof(short4) + 2 * sizeof(int) + 8 * sizeof(int) + 2 * sizeof(int) +
-                                          4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1) + 64 +
-                          (size_t)max_cells_level * sizeof(uint32_t);
+                                          4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1) + 64;
     // single frames: keys (4 B) and node ids (2 B) of a level in LDS, as many as fit (never more than a level can hold)
     int max_slots_level = 0;
     for (int l = 0; l < nl; l++)
@@ -1940,8 +1940,8 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
             for (int j = 0; j < g.ncols; j++)
                 if (BORDER0 + j * g.wcell < g.max_bx - 6)
                     ncols_eff++;
-            ORBGPU_REQUIRE(ncols_eff > 0 && g.ncells % ncols_eff == 0 && nbands <= g.ncells / ncols_eff && ncols_eff < 128 &&
-                               g.ncells / ncols_eff < 128 && g.hcell < 128,
+            ORBGPU_REQUIRE(ncols_eff > 0 && g.ncells % ncols_eff == 0 && nbands <= g.ncells / ncols_eff && ncols_eff < 255 &&
+                               g.ncells / ncols_eff < 256 && g.hcell < 128,
                            "unexpected cell grid at level %d", l);
             dgm.first[l] = acc;
             dgm.nsx[l] = nsx;
@@ -2027,7 +2027,6 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     e->ncap = ncap;
     e->qt_lds = qt_lds;
     e->qt_kcap = qt_kcap;
-    e->qt_cells = max_cells_level;
     int max_kp = 0;
     for (int l = 0; l < nl; l++)
         max_kp += geom[l].sel_cap - 1;
@@ -2149,13 +2148,13 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                            e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
-                           e->ncap, std::max(e->prm.ini_th_fast, 1), 0, e->qt_cells, qt_dbg());
+                           e->ncap, std::max(e->prm.ini_th_fast, 1), 0, qt_dbg());
     else
         hipLaunchKernelGGL(k_quadtree<true>, dim3(batch, nl), dim3(w * h >= QT_LARGE_PIXELS ? QT_THREADS : QT_THREADS_SMALL), e->qt_lds + (size_t)e->qt_kcap * 6, st, dg,
                            e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
-                           e->ncap, std::max(e->prm.ini_th_fast, 1), e->qt_kcap, e->qt_cells, qt_dbg());
+                           e->ncap, std::max(e->prm.ini_th_fast, 1), e->qt_kcap, qt_dbg());
     END(ST_QUADTREE, st);
     BEGIN(ST_ORIENT, st);
     const int or_iters = batch >= OR_BATCH_MIN ? OR_ITERS : 1;

@@ -101,9 +101,10 @@ def test_getters_match_oracle(gpu, oracle):
         assert np.array_equal(ge.quotas(), oe.quotas())
 
 
-@pytest.mark.parametrize("w,h", [(333, 251), (752, 480), (1241, 376), (320, 240)])
+@pytest.mark.parametrize("w,h", [(333, 251), (752, 480), (1241, 376), (320, 240), (4000, 1200)])
 def test_ragged_sizes(gpu, oracle, w, h):
-    """Sizes that are not multiples of anything (EuRoC 752x480, KITTI 1241x376, odd)."""
+    """Sizes that are not multiples of anything (EuRoC 752x480, KITTI 1241x376, odd), and one near the 4096-pixel limit of
+    the key format (132 x 38 cells at level 0: the cell indices of the quadtree's order key need 8 bits)."""
     from orb_slam2_map_amd.synth import Stream
     st = Stream(w, h, 77)
     img = st.frame(3)[0]
