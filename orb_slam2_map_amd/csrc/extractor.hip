@@ -1686,6 +1686,7 @@ struct orbgpu_extractor {
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key = 0;
     bool border_fast = false;  // level-0 column table present (width % 4 == 0)
+    bool counters_dirty = false;  // the cell counters may hold counts no k_quadtree has consumed
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
 
@@ -2133,6 +2134,9 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     }
     END(ST_PYRAMID, st);
     BEGIN(ST_FAST, st);
+    if (e->counters_dirty)  // a previous call enqueued the FAST pass but not the quadtree that re-arms the counters
+        ORBGPU_HIP_TRY(hipMemsetAsync(e->d_cellcnt.p, 0, e->d_cellcnt.bytes, st));
+    e->counters_dirty = true;
     {
         const int t_ini = std::max(e->prm.ini_th_fast, 1), t_min = std::max(e->prm.min_th_fast, 1);
         const int nwaves = (e->det_geom.first[nl] + FD_OWN - 1) / FD_OWN;
@@ -2155,6 +2159,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
                            e->ncap, std::max(e->prm.ini_th_fast, 1), e->qt_kcap, qt_dbg());
+    ORBGPU_HIP_TRY(hipGetLastError());
+    e->counters_dirty = false;
     END(ST_QUADTREE, st);
     BEGIN(ST_ORIENT, st);
     const int or_iters = batch >= OR_BATCH_MIN ? OR_ITERS : 1;

@@ -25,7 +25,7 @@ prof) run prof 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-
 pmc) run pmc 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --batch 256 --pool 1024 --no-cpu-baseline --no-secondary --no-self-check > $OUT/pmc1.json 2> $OUT/pmc1.err; tail -2 $OUT/pmc1.err"
      run pmc2 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --batch 256 --pool 1024 --no-cpu-baseline --no-secondary --no-self-check > $OUT/pmc2.json 2> $OUT/pmc2.err; tail -2 $OUT/pmc2.err" ;;
 diag) run diag 420 bash -c "python tools/gpu_diag.py > $OUT/diag.log 2>&1; tail -20 $OUT/diag.log" ;;
-profserial) run profserial 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-self-check --no-overlap-match > $OUT/prof_serial.json 2> $OUT/prof_serial.err; tail -3 $OUT/prof_serial.err" ;;
+profserial) run profserial 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -- python3 $ROOT/bench.py --steps 10 --warmup 2 --batch 256 --no-cpu-baseline --no-secondary --no-self-check --no-overlap-match > $OUT/prof_serial.json 2> $OUT/prof_serial.err; tail -3 $OUT/prof_serial.err" ;;
 extra) run extra 420 bash -c "python tools/bench_extra.py c1 c3 c4 pcie > $OUT/extra.json 2> $OUT/extra.err; cat $OUT/extra.json; tail -5 $OUT/extra.err" ;;
 ubench) run ubench 300 bash -c "cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o valu_rate valu_rate.hip && ./valu_rate > $OUT/valu_rate.txt 2>&1; cat $OUT/valu_rate.txt" ;;
 *) echo "unknown step $step" ;;
