@@ -64,6 +64,10 @@ def main():
                         points_crc=np.array([zlib.crc32(wpts.tobytes())], np.uint32), first_points=wpts[:64],
                         n_vox_001=np.array([len(vox)], np.int32), vox_001_crc=np.array([zlib.crc32(vox.tobytes())], np.uint32),
                         vox_005=vox5)
+    # (8) the outlier filter of the shutdown pass on the 5 cm cloud of (7): mean neighbour distances and the survivors
+    kept, md = O.statistical_outlier_removal(vox5, 50, 1.0)
+    np.savez_compressed(os.path.join(HERE, "sor_cloud_640x480_f0.npz"), mean_dist=md,
+                        kept_crc=np.array([zlib.crc32(kept.tobytes())], np.uint32), n_kept=np.array([len(kept)], np.int32))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -66,3 +66,11 @@ def test_cloud(oracle, stream640):
     assert len(v) == int(g["n_vox_001"][0]) and zlib.crc32(v.tobytes()) == int(g["vox_001_crc"][0])
     v5, _ = oracle.voxel_filter(w, 0.05)
     assert v5.tobytes() == g["vox_005"].tobytes()
+
+
+def test_outlier_filter(oracle):
+    g = np.load(os.path.join(G, "cloud_640x480_f0.npz"))
+    s = np.load(os.path.join(G, "sor_cloud_640x480_f0.npz"))
+    kept, md = oracle.statistical_outlier_removal(g["vox_005"], 50, 1.0)
+    assert np.array_equal(md.view(np.uint32), s["mean_dist"].view(np.uint32))
+    assert len(kept) == int(s["n_kept"][0]) and zlib.crc32(kept.tobytes()) == int(s["kept_crc"][0])

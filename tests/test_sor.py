@@ -132,3 +132,15 @@ def test_gpu_shutdown_sequence(gpu, stream640, tmp_path):
     m.insertKeyFrame(depth, rgb, *camv, poses[1])
     assert m.last_path() == 2 and m.size() > 0
     m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_golden(gpu):
+    import os
+    import zlib
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(G, "cloud_640x480_f0.npz"))
+    s = np.load(os.path.join(G, "sor_cloud_640x480_f0.npz"))
+    kept, md = gpu.statistical_outlier_removal(g["vox_005"], 50, 1.0)
+    assert np.array_equal(md.view(np.uint32), s["mean_dist"].view(np.uint32))
+    assert len(kept) == int(s["n_kept"][0]) and zlib.crc32(kept.tobytes()) == int(s["kept_crc"][0])
