@@ -714,14 +714,19 @@ struct QtShared {
     uint32_t *soff;     // [cells of the level] slot offset of the cell; bit 31: the cell has corners above iniThFAST
 };
 
-__device__ __forceinline__ int quadrant_of(uint32_t key, short4 b)
+// ExtractorNode::DivideNode, ORBextractor.cc:481-484, 513-526: a key goes to child 0..3 by comparing it with the
+// node's split point (UL.x + halfX, UL.y + halfY), halfX = ceil((float)(UR.x - UL.x) / 2) = (d + 1) >> 1 for the
+// non-negative integer d.  The split point is kept per node as one word (x | y << 16) next to the bounds, so that a
+// key sweep reads 4 bytes per node and compares.
+__device__ __forceinline__ uint32_t split_of(short4 b)
 {
-    // ExtractorNode::DivideNode, ORBextractor.cc:481-484, 513-526: halfX = ceil((float)(UR.x - UL.x) / 2), i.e.
-    // (d + 1) >> 1 for the non-negative integer d
-    const int halfx = (b.z - b.x + 1) >> 1;
-    const int halfy = (b.w - b.y + 1) >> 1;
+    const int mx = b.x + ((b.z - b.x + 1) >> 1), my = b.y + ((b.w - b.y + 1) >> 1);
+    return (uint32_t)mx | ((uint32_t)my << 16);
+}
+__device__ __forceinline__ int quadrant_at(uint32_t key, uint32_t split)
+{
     const int x = key_x(key), y = key_y(key);
-    return (x < b.x + halfx) ? ((y < b.y + halfy) ? 0 : 2) : ((y < b.y + halfy) ? 1 : 3);
+    return (x < (int)(split & 0xFFFFu) ? 0 : 1) + (y < (int)(split >> 16) ? 0 : 2);
 }
 
 // workgroup size of k_quadtree: a single frame is bound by the latency of its level-0 workgroup (more threads per
@@ -826,6 +831,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     short4 *bndA, *bndB;
     int *cntA, *cntB;
     uint16_t *creA, *creB;
+    uint32_t *midA, *midB;  // split point of the node (split_of)
     {
         uint8_t *p = smem;
         bndA = (short4 *)p; p += sizeof(short4) * ncap;
@@ -842,6 +848,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         S.opos = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
         S.order = (uint16_t *)p; p += sizeof(uint16_t) * ncap;
         S.inE = (uint8_t *)p; p += ((size_t)ncap + 3) / 4 * 4;
+        midA = (uint32_t *)p; p += sizeof(uint32_t) * ncap;
+        midB = (uint32_t *)p; p += sizeof(uint32_t) * ncap;
         // S.soff lives on the node-bound arrays (bndA + bndB = 4 ncap ints >= the cells of a level), which step 0 does not use
         S.soff = (uint32_t *)smem;
         lkey = (uint32_t *)p; p += sizeof(uint32_t) * kcap;
@@ -979,6 +987,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             if (c > 0) {
                 bndA[n] = make_short4((short)(int)(hx * (float)b), 0, (short)(int)(hx * (float)(b + 1)),
                                           (short)(g.max_by - BORDER0));
+                midA[n] = split_of(bndA[n]);
                 cntA[n] = c;
                 creA[n] = (uint16_t)n;
                 n++;
@@ -1010,7 +1019,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
                 const bool have = i0 + u * nt < nkeys;
                 if (have)
                     set_node(i0 + u * nt, nd[u]);
-                count_runs(S.ccnt_next, nd[u] * 4 + quadrant_of(key[u], bndA[nd[u]]), have && cntA[nd[u]] > 1);
+                count_runs(S.ccnt_next, nd[u] * 4 + quadrant_at(key[u], midA[nd[u]]), have && cntA[nd[u]] > 1);
             }
         }
     }
@@ -1120,6 +1129,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             if (!S.inE[p]) {
                 const int pos = C + S.sa[p];
                 bndB[pos] = bndA[p];
+                midB[pos] = midA[p];
                 cntB[pos] = cntA[p];
                 creB[pos] = creA[p];
                 S.opos[p] = (uint16_t)pos;
@@ -1145,6 +1155,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
                 cb.y = (q & 2) ? my : b.y;
                 cb.w = (q & 2) ? b.w : my;
                 bndB[pos] = cb;
+                midB[pos] = split_of(cb);
                 cntB[pos] = c;
                 creB[pos] = (uint16_t)k;
                 S.cpos[p * 4 + q] = (uint16_t)pos;
@@ -1184,14 +1195,14 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             }
 #pragma unroll
             for (int u = 0; u < QT_ILP; u++)
-                nn[u] = S.inE[nd[u]] ? S.cpos[nd[u] * 4 + quadrant_of(key[u], bndA[nd[u]])] : S.opos[nd[u]];
+                nn[u] = S.inE[nd[u]] ? S.cpos[nd[u] * 4 + quadrant_at(key[u], midA[nd[u]])] : S.opos[nd[u]];
 #pragma unroll
             for (int u = 0; u < QT_ILP; u++) {
                 const bool have = i0 + u * nt < nkeys;
                 if (have)
                     set_node(i0 + u * nt, nn[u]);
                 if (count_next)
-                    count_runs(S.ccnt_next, nn[u] * 4 + quadrant_of(key[u], bndB[nn[u]]), have && cntB[nn[u]] > 1);
+                    count_runs(S.ccnt_next, nn[u] * 4 + quadrant_at(key[u], midB[nn[u]]), have && cntB[nn[u]] > 1);
             }
         }
         __syncthreads();
@@ -1204,6 +1215,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             short4 *tb = bndA; bndA = bndB; bndB = tb;
             int *tc = cntA; cntA = cntB; cntB = tc;
             uint16_t *tr = creA; creA = creB; creB = tr;
+            uint32_t *tm = midA; midA = midB; midB = tm;
         }
         __syncthreads();
     }
@@ -1899,7 +1911,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     ncap = std::max(ncap, (max_cells_level + 3) / 4);  // the cell scan reuses the [ncap*4] child-count array
     ncap = ((ncap + 7) / 8) * 8;
     const size_t qt_lds = (size_t)ncap * (2 * sizeof(short4) + 2 * sizeof(int) + 8 * sizeof(int) + 2 * sizeof(int) +
-                                          4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1) + 64;
+                                          4 * sizeof(uint16_t) + 4 * sizeof(uint16_t) + 1 + 2 * sizeof(uint32_t)) + 64;
     // single frames: keys (4 B) and node ids (2 B) of a level in LDS, as many as fit (never more than a level can hold)
     int max_slots_level = 0;
     for (int l = 0; l < nl; l++)
