@@ -327,8 +327,9 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
 // One kernel, k_fast_detect (below).  The corner score s(x,y) = max over the 16 arcs of 9 contiguous ring pixels of
 // the minimum |centre - ring| (dark and bright polarity), clamped to [0,255]: a pixel is a FAST corner for threshold t
 // <=>  s > t, and cv::FAST's cornerScore is s-1, so one score serves both thresholds.  Register-only streaming like
-// k_blur: a thread owns 4 pixels x the rows of a band, keeps a 7-row x 12-byte window in registers, unpacks ring bytes
-// with v_perm_b32 into packed 16-bit lanes and runs the min/max network with three-input packed extrema
+// k_blur: a thread owns 4 pixels x the rows of a band, keeps a 7-row window in registers -- every row unpacked once
+// with v_perm_b32 into the eight packed-16-bit forms its seven uses need (RowU) -- and runs the min/max network with
+// three-input packed extrema
 // (v_pk_maximum3_f16 / v_pk_minimum3_f16 on the integer bit patterns: two pixels per instruction, no divergence).
 // ---------------------------------------------------------------------------------------------
 constexpr int MAX_CELL = 66;  // max cell interior edge
@@ -405,18 +406,30 @@ struct Row3 {
     uint32_t d[3];  // 12 bytes of one padded row: columns 4c-4 .. 4c+7
 };
 
-// ring bytes of the even (px0,px2) or odd (px1,px3) pixel pair in row window R at horizontal offset dx:
-// window byte 4 + p + dx, zero-extended into packed 16-bit lanes by one v_perm_b32
-template <int DX, int ODD> __device__ __forceinline__ pk16 ring_half(const Row3 &R)
+// A row of the 7-row window in unpacked form: f[o-1] = (byte o, byte o+2) of the 12-byte window as packed 16-bit
+// lanes, o = 1..8.  The even pixel pair (px0, px2) at horizontal offset dx is f at o = 4 + dx, the odd pair (px1, px3)
+// at o = 5 + dx.  A row serves seven steps (as row y+3 down to y-3) and its eight forms are used 30 times in all:
+// unpacking once per row costs 8 v_perm_b32 per step instead of 30 -- at 56 registers for the window instead of 21.
+struct RowU {
+    uint32_t f[8];
+};
+__device__ __forceinline__ void unpack_row(const Row3 &R, RowU &U)
 {
-    constexpr int s = 4 + DX, q = s >> 2, o = s & 3;
-    return as_pk(__builtin_amdgcn_perm(R.d[q + 1], R.d[q], ODD ? ORBGPU_SEL_ODD(o) : ORBGPU_SEL_EVEN(o)));
+#pragma unroll
+    for (int o = 1; o <= 8; o++) {
+        const int q = o >> 2;
+        U.f[o - 1] = __builtin_amdgcn_perm(R.d[q < 2 ? q + 1 : 2], R.d[q], ORBGPU_SEL_EVEN(o & 3));
+    }
+}
+template <int DX, int ODD> __device__ __forceinline__ pk16 ring_half(const RowU &R)
+{
+    return as_pk(R.f[4 + DX + ODD - 1]);
 }
 
 // score of one pixel pair of the strip in the row whose window is r3 (r0..r6 = rows y-3..y+3)
 template <int ODD>
-__device__ __forceinline__ pk16 fast_score_half(const Row3 &r0, const Row3 &r1, const Row3 &r2, const Row3 &r3,
-                                                const Row3 &r4, const Row3 &r5, const Row3 &r6)
+__device__ __forceinline__ pk16 fast_score_half(const RowU &r0, const RowU &r1, const RowU &r2, const RowU &r3,
+                                                const RowU &r4, const RowU &r5, const RowU &r6)
 {
     pk16 p[16];
     const pk16 c = ring_half<0, ODD>(r3);
@@ -469,8 +482,9 @@ struct StripGeom {  // strips of all levels, flattened (k_blur)
 // lower threshold, high half = those above iniThFAST) to reserve slots, positions handed out from LDS.  The keys of
 // a cell land in no particular order: nothing downstream depends on it (k_quadtree's "first maximum" rule rebuilds
 // vToDistributeKeys order from the key itself).
-// Measured (B = 256, 640x480): 390 us against 324 + 158 us for the score-map / per-cell pair it replaces, and
-// 1.8 MB per frame less HBM traffic.
+// Measured (B = 256, 640x480): 375 us against 324 + 158 us for the score-map / per-cell pair it replaces, and
+// 1.8 MB per frame less HBM traffic.  143 VGPRs: three waves per SIMD, which still saturates the VALU (390 us with
+// raw rows in 128 VGPRs and 30 v_perm_b32 per step instead of 8).
 // ---------------------------------------------------------------------------------------------
 constexpr int FD_OWN = 62;    // columns a wave owns (lanes 1..62)
 constexpr int FD_QCAP = 512;  // row records a wave can queue before it falls back to emitting them directly
@@ -507,7 +521,7 @@ __device__ __forceinline__ void detect_record(uint32_t sc4, uint32_t rec, const 
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_detect(const uint8_t *__restrict__ pyr, size_t frame_pyr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_fast_detect(const uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                      const LevelGeom *__restrict__ geom, DetectGeom dg,
                                                      const ColumnInfo *__restrict__ ctab,
                                                      const CellDesc *__restrict__ cells, int ncells_total,
@@ -611,30 +625,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         ScO = so;
     };
 
-    Row3 r0, r1, r2, r3, r4, r5, r6;
-#define FD_LOAD(R, row)                                                                                      \
+    RowU r0, r1, r2, r3, r4, r5, r6;
+#define FD_FETCH(row)                                                                                        \
     {                                                                                                        \
         const uint32_t *qq = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);              \
-        R.d[0] = qq[0];                                                                                      \
-        R.d[1] = qq[1];                                                                                      \
-        R.d[2] = qq[2];                                                                                      \
+        nx.d[0] = qq[0];                                                                                     \
+        nx.d[1] = qq[1];                                                                                     \
+        nx.d[2] = qq[2];                                                                                     \
+    }
+#define FD_LOAD(R, row)                                                                                      \
+    {                                                                                                        \
+        FD_FETCH(row)                                                                                        \
+        unpack_row(nx, R);                                                                                   \
     }
 #define FD_STEP(A, B, C, D, E, F, G, k)                                                                      \
     if ((k) < rows) {                                                                                        \
-        G = nx;                                                                                              \
+        unpack_row(nx, G);                                                                                   \
         if ((k) + 1 < rows)                                                                                  \
-            FD_LOAD(nx, (k) + 7)                                                                             \
+            FD_FETCH((k) + 7)                                                                                \
         const pk16 se = fast_score_half<0>(A, B, C, D, E, F, G);                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         const pk16 so = fast_score_half<1>(A, B, C, D, E, F, G);                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         nms_row(as_u32(se), as_u32(so), (k));                                                                \
     }
-    Row3 nx;  // next input row, fetched one step ahead
+    Row3 nx;  // next input row (raw), fetched one step ahead
     nx.d[0] = nx.d[1] = nx.d[2] = 0u;
+#pragma unroll
+    for (int o = 0; o < 8; o++)
+        r0.f[o] = r1.f[o] = r2.f[o] = r3.f[o] = r4.f[o] = r5.f[o] = r6.f[o] = 0u;
     if (rows > 0) {
         FD_LOAD(r0, 0) FD_LOAD(r1, 1) FD_LOAD(r2, 2) FD_LOAD(r3, 3) FD_LOAD(r4, 4) FD_LOAD(r5, 5)
-        FD_LOAD(nx, 6)
+        FD_FETCH(6)
     }
 #pragma unroll 1
     for (int k = 0; k < rows; k += 7) {
@@ -648,6 +670,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 #undef FD_STEP
 #undef FD_LOAD
+#undef FD_FETCH
     if (rows > 0)
         finish_row(0u, 0u, rows - 1);  // the row below the band counts as 0
 
