@@ -47,7 +47,7 @@ struct CellDesc {
     short addx, addy;      // j*wCell, i*hCell  (ORBextractor.cc:822-823)
     short cap;             // slot capacity
     int slot_off;          // offset of this cell's slots inside one frame's slot block
-    int pitch, plane_off;  // copies of the level's LevelGeom fields (k_fast_cells reads one record per cell)
+    int pitch, plane_off;  // copies of the level's LevelGeom fields
     int pad[1];
 };
 static_assert(sizeof(CellDesc) == 32, "CellDesc is read as two 16-byte words");
@@ -465,7 +465,7 @@ struct StripGeom {  // strips of all levels, flattened (k_blur)
 // the score map never reaches memory.
 //
 // Work item = (level, band, aligned dword column): a band is one row of cells (its interior rows), so a thread scores
-// the 4 pixels of its column for every row of the band exactly like k_fast_score and, one row behind, decides which
+// the 4 pixels of its column for every row of the band and, one row behind, decides which
 // of them survive.  cv::FAST runs on a cell's sub-image, so a neighbour outside the cell interior counts as 0: rows
 // outside the band are zero by construction, and the columns where a cell starts / ends are known per dword column
 // (ColumnInfo) and turn into four constant keep-masks per thread.  With S = the row's scores as packed pairs
@@ -1719,7 +1719,7 @@ struct orbgpu_extractor {
     bool profiling = false;
     std::vector<hipEvent_t> ev;  // PROF_SLOTS * 2 * ST_COUNT slots (ST_COUNT + 1 boundary events used per call), created lazily
     int prof_calls = 0;
-    // host entry points: the 17-launch sequence is captured once per (size, batch, buffers) and replayed as a hipGraph
+    // host entry points: the 14-launch sequence is captured once per (size, batch, buffers) and replayed as a hipGraph
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key = 0;

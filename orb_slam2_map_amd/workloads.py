@@ -155,7 +155,7 @@ def c3(reps=30, device_id=0):
                          "note": "one 10 k-point query set per call: gather-latency / launch bound, not a stream"},
             "extract_roofline": {"bound": "hbm", "achieved": alg_ext / (ms_extract * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": alg_ext / (ms_extract * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "algorithmic_bytes": alg_ext, "note": "single frame: 16 dependent launches"}}
+                                 "algorithmic_bytes": alg_ext, "note": "single frame: 14 dependent launches"}}
 
 
 def c3_batch(n_seq=128, reps=10, device_id=0):
