@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--rehearse-on-device0", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
+    ap.add_argument("--match-after", default="quadtree", choices=["start", "pyramid", "fast", "quadtree", "orient", "blur"],
+                    help="overlapped schedule: the matcher of the previous step starts when the extraction has passed this stage")
     ap.add_argument("--no-overlap-match", dest="overlap_match", action="store_false",
                     help="serialise the matcher behind the extraction (default: the matcher of step i runs on a "
                          "second stream next to the extraction of step i+1)")
@@ -216,7 +218,7 @@ def main():
     # Two output sets (slot 0 of a set carries the previous step's last frame; this step's frames go to
     # slots 1..B).  Extraction runs on the current stream; with --overlap-match the matcher of step i
     # runs on a second stream next to the extraction of step i+1 (no data dependency between them).
-    nsets = 2 if args.overlap_match else 1
+    nsets = (3 if args.match_after != "start" else 2) if args.overlap_match else 1  # a deferred matcher holds its set one step longer
     kps = [torch.zeros((B + 1, cap, 7), dtype=torch.float32, device="cuda") for _ in range(nsets)]
     desc = [torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device="cuda") for _ in range(nsets)]
     nout = [torch.zeros(B + 1, dtype=torch.int32, device="cuda") for _ in range(nsets)]
@@ -225,6 +227,30 @@ def main():
     ev_ext = [torch.cuda.Event() for _ in range(nsets)]
     ev_match = [torch.cuda.Event() for _ in range(nsets)]
     ev_copy = [torch.cuda.Event() for _ in range(nsets)]  # slot B of set k has been carried over to the other set
+
+    # Overlapped schedule: the matcher of step i-1 is enqueued on its own stream while extraction i runs, and starts when
+    # that extraction has passed the stage named by --match-after (the library records ev_mid there).  The brute-force
+    # matcher is matrix-core / LDS work; next to the FAST pass (VALU-bound at three waves per SIMD) or the pyramid
+    # (HBM-bound) it takes more from the extraction than next to the quadtree, whose long level-0 workgroups leave
+    # most of the device idle.
+    ev_mid = torch.cuda.Event()
+    if args.overlap_match and args.match_after != "start":
+        ev_mid.record(s_ext)  # torch creates the hipEvent_t on first use
+        assert ev_mid.cuda_event, "no event handle"
+        ext.set_stage_signal(args.match_after, ev_mid.cuda_event)
+    pending = [None]
+
+    def run_match(k):
+        matcher.match(B, cap, desc[k].data_ptr(), kps[k].data_ptr() + 12, None, nout[k].data_ptr(),
+                      desc[k].data_ptr() + DS, kps[k].data_ptr() + KP + 12, nout[k].data_ptr() + 4, 28, 50, 0.7,
+                      True, match_b.data_ptr(), nmatch.data_ptr(), s_match.cuda_stream)
+
+    def flush_match():
+        if pending[0] is not None:
+            with torch.cuda.stream(s_match):
+                run_match(pending[0])
+                ev_match[pending[0]].record(s_match)
+            pending[0] = None
 
     def step(i):
         k = i % nsets
@@ -245,17 +271,21 @@ def main():
                                  cap, nout[k].data_ptr() + 4, s_ext.cuda_stream)
         if args.overlap_match:
             ev_ext[k].record(s_ext)
+            if pending[0] is not None and args.match_after != "start":
+                s_match.wait_event(ev_mid)  # extraction i has passed the chosen stage: now match step i-1
+            flush_match()
             s_match.wait_event(ev_ext[k])
-        with torch.cuda.stream(s_match):
-            matcher.match(B, cap, desc[k].data_ptr(), kps[k].data_ptr() + 12, None, nout[k].data_ptr(),
-                          desc[k].data_ptr() + DS, kps[k].data_ptr() + KP + 12, nout[k].data_ptr() + 4, 28, 50, 0.7,
-                          True, match_b.data_ptr(), nmatch.data_ptr(), s_match.cuda_stream)
-            if nsets == 1:
+            if args.match_after == "start":
+                pending[0] = k
+                flush_match()  # the original schedule: match step i as soon as its extraction is done
+            else:
+                pending[0] = k
+        else:
+            with torch.cuda.stream(s_match):
+                run_match(k)
                 kps[0][0].copy_(kps[0][B], non_blocking=True)
                 desc[0][0].copy_(desc[0][B], non_blocking=True)
                 nout[0][0:1].copy_(nout[0][B:B + 1], non_blocking=True)
-            if args.overlap_match:
-                ev_match[k].record(s_match)
 
     def barrier():
         torch.cuda.synchronize()
@@ -265,6 +295,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    flush_match()
     barrier()
     # per-stage HIP events (recorded by the library on the launch stream) cost the stream a bubble per event, so
     # they are taken on one timed step in PROF_EVERY; the averages come from those steps of the timed region
@@ -275,6 +306,8 @@ def main():
     for i in range(args.steps):
         ext.set_profiling(i % PROF_EVERY == 0)
         step(args.warmup + i)
+    flush_match()  # the last step's matcher belongs to the timed region
+    s_ext.wait_stream(s_match) if args.overlap_match else None
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -347,7 +380,9 @@ def main():
             "config": {"workload": "C2: synthetic 640x480 RGB-D stream, 1000 features, 8 levels, extract + BF-Hamming "
                                    "match of consecutive frames", "frames_per_step_per_gpu": B,
                        "resident_frame_pool": POOL, "sequences": world, "parallelism": "1 sequence per GPU",
-                       "schedule": "matcher of step i overlapped with extraction of step i+1 (2 streams)"
+                       "schedule": ("matcher of step i-1 on a second stream, started when extraction i has passed its '%s' stage"
+                                    % args.match_after if args.match_after != "start" else
+                                    "matcher of step i overlapped with extraction of step i+1 (2 streams)")
                        if args.overlap_match else "serial, 1 stream"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

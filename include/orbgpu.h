@@ -140,6 +140,10 @@ int orbgpu_extractor_debug_read(orbgpu_extractor *h, int32_t what, int32_t frame
  * third call of a configuration on: *state = 1 graph in use, 0 not captured yet, -1 capture failed (plain launches). */
 int orbgpu_extractor_graph_state(const orbgpu_extractor *h, int32_t *state);
 int orbgpu_extractor_set_profiling(orbgpu_extractor *h, int32_t enable);
+/* Pipelining aid for callers that run other work next to an extraction (bench.py starts the matcher of the previous
+ * batch there): `hip_event` (a hipEvent_t, or NULL to clear) is recorded on the launch stream of every later
+ * orbgpu_extract_batch_device call right after stage `stage` (index as in orbgpu_extractor_stage_name). */
+int orbgpu_extractor_set_stage_signal(orbgpu_extractor *h, int32_t stage, void *hip_event);
 int orbgpu_extractor_stage_count(void);
 const char *orbgpu_extractor_stage_name(int32_t i);
 /* Synchronises the recorded events, returns the AVERAGE ms per stage over the calls profiled since

@@ -1724,6 +1724,7 @@ struct orbgpu_extractor {
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_key = 0;
     bool border_fast = false;  // level-0 column table present (width % 4 == 0)
+    hipEvent_t stage_signal[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // caller's events
     bool counters_dirty = false;  // the cell counters may hold counts no k_quadtree has consumed
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
@@ -2144,7 +2145,13 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
 // one event per stage boundary (an event costs the stream several microseconds): evs[0] before the first stage,
 // evs[1 + stage] after each; stage time = evs[1 + stage] - evs[stage]
 #define BEGIN(stage, s) if (prof && (stage) == 0) ORBGPU_HIP_TRY(hipEventRecord(evs[0], s))
-#define END(stage, s) if (prof) ORBGPU_HIP_TRY(hipEventRecord(evs[1 + (stage)], s))
+#define END(stage, s)                                                          \
+    {                                                                          \
+        if (prof)                                                              \
+            ORBGPU_HIP_TRY(hipEventRecord(evs[1 + (stage)], s));               \
+        if (e->stage_signal[stage])                                            \
+            ORBGPU_HIP_TRY(hipEventRecord(e->stage_signal[stage], s));         \
+    }
     BEGIN(ST_PYRAMID, st);
     {
         const LevelGeom &g = e->geom[0];
@@ -2556,6 +2563,13 @@ int orbgpu_extractor_debug_read(orbgpu_extractor *e, int32_t what, int32_t frame
     }
     set_error("unknown debug selector %d", what);
     return ORBGPU_EINVAL;
+}
+
+int orbgpu_extractor_set_stage_signal(orbgpu_extractor *e, int32_t stage, void *hip_event)
+{
+    ORBGPU_REQUIRE(e && stage >= 0 && stage < ST_COUNT, "bad stage");
+    e->stage_signal[stage] = (hipEvent_t)hip_event;
+    return ORBGPU_OK;
 }
 
 int orbgpu_extractor_set_profiling(orbgpu_extractor *e, int32_t enable)

@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_get_inv_scale_factors", "orbgpu_extractor_get_sigma2", "orbgpu_extractor_get_inv_sigma2",
     "orbgpu_extractor_get_quotas", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
     "orbgpu_extract_batch_device", "orbgpu_extractor_get_pyramid_level", "orbgpu_extractor_debug_read",
-    "orbgpu_extractor_graph_state", "orbgpu_extractor_set_profiling", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
+    "orbgpu_extractor_graph_state", "orbgpu_extractor_set_profiling", "orbgpu_extractor_set_stage_signal", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
     "orbgpu_extractor_stage_times",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
@@ -169,6 +169,7 @@ def lib():
         "orbgpu_extractor_get_pyramid_level": [vp, i32, i32, vp, sz, vp, vp],
         "orbgpu_extractor_debug_read": [vp, i32, i32, i32, vp, sz, vp, vp],
         "orbgpu_extractor_set_profiling": [vp, i32],
+        "orbgpu_extractor_set_stage_signal": [vp, i32, vp],
         "orbgpu_extractor_stage_times": [vp, vp],
         "orbgpu_hamming256": [vp, vp, i32, vp, i32],
         "orbgpu_match_bf": [vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, i32],
@@ -339,6 +340,11 @@ class ORBextractor:
 
     def set_profiling(self, on):
         check(self.L.orbgpu_extractor_set_profiling(self.h, int(on)))
+
+    def set_stage_signal(self, stage_name, hip_event):
+        """hip_event (raw hipEvent_t handle or None) is recorded after the named stage of every later device-batch call."""
+        names = [self.L.orbgpu_extractor_stage_name(i).decode() for i in range(self.L.orbgpu_extractor_stage_count())]
+        check(self.L.orbgpu_extractor_set_stage_signal(self.h, names.index(stage_name), C.c_void_p(hip_event or 0)))
 
     def stage_times(self):
         n = self.L.orbgpu_extractor_stage_count()
