@@ -102,7 +102,9 @@ int ora_match_bf(const uint8_t *desc_a, const float *angle_a, const uint8_t *val
                 best2 = dist;
             }
         }
-        if (best1 <= th_low) {
+        /* bestIdx < 0: every B row is taken.  With the reference's TH_LOW = 50 the test below already fails (best1 is
+         * still 256); the guard only matters for thresholds >= 256, which this entry point accepts */
+        if (best1 <= th_low && bestIdx >= 0) {
             if ((float)best1 < nnratio * (float)best2) {
                 match_b[bestIdx] = i;
                 if (check_orientation) {

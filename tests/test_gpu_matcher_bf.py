@@ -100,6 +100,21 @@ def test_bf_edge_cases(gpu, oracle):
     assert n == no and np.array_equal(mb, mo)
 
 
+def test_bf_more_rows_than_candidates_at_threshold_256(gpu, oracle):
+    """Once every B row is taken a later A row has no candidate left: best distance stays 256 and the best index -1.  The
+    reference's TH_LOW = 50 rejects that row before it looks at the index; with th_low = 256 (this entry point takes the
+    threshold as a parameter) the row must simply not match (found by tools/fuzz_bf.py: the oracle wrote match[-1])."""
+    rng = np.random.default_rng(14)
+    base = rng.integers(0, 256, (100, 32), dtype=np.uint8)
+    a, b = base[rng.integers(0, 100, 683)], base[rng.integers(0, 100, 86)]
+    aa, ab = (rng.random(683) * 360).astype(np.float32), (rng.random(86) * 360).astype(np.float32)
+    for ori in (True, False):
+        ng, mg = gpu.ORBmatcher(10.0, ori).MatchBruteForce(a, aa, b, ab, th_low=256)
+        no, mo = oracle.match_bf(a, aa, b, ab, th_low=256, nnratio=10.0, check_orientation=ori)
+        assert ng == no and np.array_equal(mg, mo)
+        assert ori or ng == 86  # every B row ends up taken
+
+
 def test_bf_batched_device_path(gpu, oracle, stream640):
     """The device-resident batched entry point the benchmark times (pairs of consecutive frames)."""
     torch = pytest.importorskip("torch")
