@@ -449,6 +449,112 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
         return nmatches;
     }
 
+    // int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,
+    //                            std::vector<pair<size_t,size_t>> &vMatchedPairs, const bool bOnlyStereo)
+    // (ORBmatcher.h:79, ORBmatcher.cc:657-823; LocalMapping::CreateNewMapPoints, LocalMapping.cc:268).
+    // KeyFrameT: the members FrameSoA reads (N, mvKeysUn, mvuRight, mGrid, mnMinX.., mvScaleFactors), mFeatVec,
+    // GetMapPoint(idx), fx, fy, cx, cy, mvLevelSigma2.  F12: the 9 floats of the fundamental matrix, row-major;
+    // camera_center(kf, float[3]) / rotation(kf, float[9]) / translation(kf, float[3]) read GetCameraCenter(),
+    // GetRotation(), GetTranslation().
+    template <typename KeyFrameT, typename DescRow, typename Vec3Of, typename Mat3Of, typename Vec3Of2>
+    int SearchForTriangulation(KeyFrameT *pKF1, KeyFrameT *pKF2, const float *F12,
+                               std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo,
+                               DescRow desc_row, Vec3Of camera_center, Mat3Of rotation, Vec3Of2 translation)
+    {
+        // epipole in the second image (:664-670): C2 = R2w * Cw + t2w as cv::gemm computes a 3x3 * 3x1 float product
+        // (products summed left to right, then the C term)
+        float Cw[3], R2w[9], t2w[3], C2[3];
+        camera_center(pKF1, Cw);
+        rotation(pKF2, R2w);
+        translation(pKF2, t2w);
+        for (int r = 0; r < 3; r++) {
+            volatile float a = R2w[3 * r] * Cw[0], b = R2w[3 * r + 1] * Cw[1], c = R2w[3 * r + 2] * Cw[2];
+            volatile float ab = a + b;
+            volatile float abc = ab + c;
+            C2[r] = abc + t2w[r];
+        }
+        const float invz = 1.0f / C2[2];
+        const float ex = pKF2->fx * C2[0] * invz + pKF2->cx;
+        const float ey = pKF2->fy * C2[1] * invz + pKF2->cy;
+        FrameSoA<KeyFrameT> s1(*pKF1, desc_row), s2(*pKF2, desc_row);
+        std::vector<uint8_t> has1(std::max(pKF1->N, 1)), has2(std::max(pKF2->N, 1));
+        for (int i = 0; i < pKF1->N; i++)
+            has1[i] = pKF1->GetMapPoint(i) != nullptr;  // :702-705
+        for (int i = 0; i < pKF2->N; i++)
+            has2[i] = pKF2->GetMapPoint(i) != nullptr;  // :726-729
+        const std::vector<int32_t> node1 = NodeIdsOf(pKF1->mFeatVec, pKF1->N), node2 = NodeIdsOf(pKF2->mFeatVec, pKF2->N);
+        std::vector<int32_t> match12(std::max(pKF1->N, 1), -1);
+        int32_t nmatches = 0;
+        check(orbgpu_search_for_triangulation(&s1.view, has1.data(), node1.data(), &s2.view, has2.data(), node2.data(), F12, ex,
+                                              ey, pKF2->mvLevelSigma2.data(), bOnlyStereo, mbCheckOrientation, match12.data(),
+                                              &nmatches, device_),
+              "SearchForTriangulation");
+        vMatchedPairs.clear();  // :812-820
+        vMatchedPairs.reserve((size_t)nmatches);
+        for (int i = 0; i < pKF1->N; i++)
+            if (match12[i] >= 0)
+                vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)match12[i]));
+        return nmatches;
+    }
+
+    // int Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th=3.0)
+    // (ORBmatcher.h:88, ORBmatcher.cc:825-975; LocalMapping::SearchInNeighbors, LocalMapping.cc:489, 514).
+    // The candidate of every map point (projection, level and chi-square gates, best descriptor within TH_LOW) comes
+    // from the device in one call; the edits of :946-969 -- Replace / AddObservation / AddMapPoint, which mutate the
+    // pointer graph -- are applied here in index order exactly as the reference's loop does, re-checking isBad() and
+    // IsInKeyFrame() since an earlier edit can change them.  pose(kf, float[16]) reads GetPose() (row-major Tcw);
+    // world_pos / normal(pMP) return 3 floats, min_dist / max_dist the protected mfMinDistance / mfMaxDistance,
+    // mp_desc(pMP) the 32 descriptor bytes (as for the Sim3 overload above).
+    template <typename KeyFrameT, typename DescRow, typename PoseOf, typename MpDesc, typename WorldPos, typename Normal,
+              typename MinDist, typename MaxDist>
+    int Fuse(KeyFrameT *pKF, const std::vector<MapPointT *> &vpMapPoints, const float th, DescRow desc_row, PoseOf pose,
+             MpDesc mp_desc, WorldPos world_pos, Normal normal, MinDist min_dist, MaxDist max_dist)
+    {
+        FrameSoA<KeyFrameT> soa(*pKF, desc_row);
+        const int m = (int)vpMapPoints.size();
+        std::vector<uint8_t> bad(std::max(m, 1)), desc((size_t)std::max(m, 1) * 32);
+        std::vector<float> wp((size_t)std::max(m, 1) * 3), nrm((size_t)std::max(m, 1) * 3), dmin(std::max(m, 1)), dmax(std::max(m, 1));
+        for (int i = 0; i < m; i++) {
+            MapPointT *p = vpMapPoints[i];
+            bad[i] = !p || p->isBad() || p->IsInKeyFrame(pKF);  // :843-848
+            if (!p)
+                continue;
+            const float *w = world_pos(p), *nn = normal(p);
+            wp[3 * i] = w[0], wp[3 * i + 1] = w[1], wp[3 * i + 2] = w[2];
+            nrm[3 * i] = nn[0], nrm[3 * i + 1] = nn[1], nrm[3 * i + 2] = nn[2];
+            dmin[i] = min_dist(p), dmax[i] = max_dist(p);
+            std::memcpy(&desc[(size_t)i * 32], mp_desc(p), 32);
+        }
+        orbgpu_points_view pv{m, bad.data(), wp.data(), nrm.data(), dmin.data(), dmax.data(), desc.data()};
+        float Tcw[16];
+        pose(pKF, Tcw);
+        std::vector<int32_t> best(std::max(m, 1), -1);
+        int32_t ncand = 0;
+        check(orbgpu_fuse(&soa.view, Tcw, pKF->fx, pKF->fy, pKF->cx, pKF->cy, pKF->mbf, pKF->mfLogScaleFactor, &pv, th,
+                          pKF->mvInvLevelSigma2.data(), best.data(), &ncand, device_),
+              "Fuse");
+        int nFused = 0;
+        for (int i = 0; i < m; i++) {
+            MapPointT *pMP = vpMapPoints[i];
+            if (best[i] < 0 || !pMP || pMP->isBad() || pMP->IsInKeyFrame(pKF))
+                continue;
+            MapPointT *pMPinKF = pKF->GetMapPoint(best[i]);  // :948
+            if (pMPinKF) {
+                if (!pMPinKF->isBad()) {
+                    if (pMPinKF->Observations() > pMP->Observations())
+                        pMP->Replace(pMPinKF);
+                    else
+                        pMPinKF->Replace(pMP);
+                }
+            } else {
+                pMP->AddObservation(pKF, best[i]);
+                pKF->AddMapPoint(pMP, best[i]);
+            }
+            nFused++;
+        }
+        return nFused;
+    }
+
     // void MapPoint::ComputeDistinctiveDescriptors()  (MapPoint.cc:242-307) for a batch of map points: groups[g] holds
     // the descriptor rows of the non-bad observing key frames of point g (in mObservations order); returns the index
     // of the chosen row per point (-1: no observation, mDescriptor stays).

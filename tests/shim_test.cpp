@@ -23,6 +23,17 @@ struct MapPoint {  // members read by the matcher: MapPoint.h:91-96 + accessors
     int id = -1;
     bool isBad() const { return bad; }
     int Observations() const { return nObs; }
+    // the part of the pointer graph ORBmatcher::Fuse edits (MapPoint.h: AddObservation, Replace, IsInKeyFrame), reduced
+    // to one key frame: which key point of it observes this point, and who replaced it
+    int idxInKF = -1;
+    MapPoint *replacedBy = nullptr;
+    template <typename K> bool IsInKeyFrame(K *) const { return idxInKF >= 0; }
+    template <typename K> void AddObservation(K *, size_t idx)
+    {
+        idxInKF = (int)idx;
+        nObs++;
+    }
+    void Replace(MapPoint *pMP);  // defined after MatchKeyFrame
 };
 
 struct Frame {  // Frame.h:100-190
@@ -40,6 +51,30 @@ struct Frame {  // Frame.h:100-190
     orbgpu_shim::FeatureVector mFeatVec;
     orbgpu_shim::BowVector mBowVec;
 };
+
+struct MatchKeyFrame : Frame {  // the KeyFrame members the background matchers read (KeyFrame.h)
+    std::vector<float> mvLevelSigma2, mvInvLevelSigma2;
+    MapPoint *GetMapPoint(size_t idx) const { return mvpMapPoints[idx]; }
+    void AddMapPoint(MapPoint *p, size_t idx) { mvpMapPoints[idx] = p; }
+};
+static MatchKeyFrame *g_fuse_kf = nullptr;  // the one key frame of the stand-in graph
+inline void MapPoint::Replace(MapPoint *pMP)  // MapPoint.cc:171-212, for the one-key-frame graph
+{
+    if (pMP == this)
+        return;
+    if (idxInKF >= 0 && g_fuse_kf) {
+        if (!pMP->IsInKeyFrame(g_fuse_kf)) {
+            g_fuse_kf->mvpMapPoints[idxInKF] = pMP;  // ReplaceMapPointMatch + AddObservation
+            pMP->idxInKF = idxInKF;
+            pMP->nObs++;
+        } else
+            g_fuse_kf->mvpMapPoints[idxInKF] = nullptr;  // EraseMapPointMatch
+    }
+    idxInKF = -1;
+    nObs = 0;
+    bad = true;
+    replacedBy = pMP;
+}
 
 struct KeyFrame {
     std::vector<float> mImDep;
@@ -235,6 +270,61 @@ int main(int argc, char **argv)
                 int32_t w = (int32_t)kv.first;
                 wr(out, &w, 1);
                 wr(out, &kv.second, 1);
+            }
+        }
+
+        // ---- background matchers through the shim: SearchForTriangulation of the frame against itself (two key frames
+        //      with identical features: every key point's epipolar line under a skew F12 passes through it) and Fuse
+        //      of the local map into the frame as a key frame (the associations SearchByProjection made stay in place)
+        {
+            MatchKeyFrame K1, K2;
+            static_cast<Frame &>(K1) = F;
+            static_cast<Frame &>(K2) = F;
+            K1.mvLevelSigma2 = K2.mvLevelSigma2 = extractor.GetScaleSigmaSquares();
+            K1.mvInvLevelSigma2 = K2.mvInvLevelSigma2 = extractor.GetInverseScaleSigmaSquares();
+            for (int i = 0; i < F.N; i++) {  // every third key point of each already has a map point (:702-705, :726-729)
+                K1.mvpMapPoints[i] = (i % 3 == 0) ? &mps[0] : nullptr;
+                K2.mvpMapPoints[i] = (i % 3 == 1) ? &mps[0] : nullptr;
+            }
+            const float F12[9] = {0.f, -0.f, 0.6f, 0.f, 0.f, -0.8f, -0.6f, 0.8f, 0.f};  // skew of (0.8, 0.6, 0)
+            const float Cw[3] = {0.5f, -0.25f, 0.125f}, R2w[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t2w[3] = {0.25f, 0.5f, 2.0f};
+            orbgpu_shim::ORBmatcherT<Frame, MapPoint> tm(0.6f, true);
+            std::vector<std::pair<size_t, size_t>> pairs;
+            const int nt = tm.SearchForTriangulation(
+                &K1, &K2, F12, pairs, false, [](const MatchKeyFrame &k, int i) { return &k.mDescriptors[(size_t)i * 32]; },
+                [&](MatchKeyFrame *, float *o) { std::memcpy(o, Cw, 12); }, [&](MatchKeyFrame *, float *o) { std::memcpy(o, R2w, 36); },
+                [&](MatchKeyFrame *, float *o) { std::memcpy(o, t2w, 12); });
+            int32_t nt32 = nt, np32 = (int32_t)pairs.size();
+            wr(out, &nt32, 1);
+            wr(out, &np32, 1);
+            for (const auto &pr : pairs) {
+                int32_t ab[2] = {(int32_t)pr.first, (int32_t)pr.second};
+                wr(out, ab, 2);
+            }
+
+            MatchKeyFrame KF;
+            static_cast<Frame &>(KF) = F;  // mvpMapPoints = what SearchByProjection associated above
+            KF.mvLevelSigma2 = K1.mvLevelSigma2, KF.mvInvLevelSigma2 = K1.mvInvLevelSigma2;
+            g_fuse_kf = &KF;
+            for (int j = 0; j < KF.N; j++)
+                if (KF.mvpMapPoints[j])
+                    KF.mvpMapPoints[j]->idxInKF = j;
+            orbgpu_shim::ORBmatcherT<Frame, MapPoint> fm(0.6f, true);
+            const int nfused = fm.Fuse(
+                &KF, vp, cam[5], [](const MatchKeyFrame &k, int i) { return &k.mDescriptors[(size_t)i * 32]; },
+                [&](MatchKeyFrame *, float *T) { std::memcpy(T, Tcw, 64); }, mp_desc, [](MapPoint *p) { return p->world; },
+                [](MapPoint *p) { return p->normal; }, [](MapPoint *p) { return p->minDist; },
+                [](MapPoint *p) { return p->maxDist; });
+            g_fuse_kf = nullptr;
+            int32_t nf32 = nfused;
+            wr(out, &nf32, 1);
+            for (int j = 0; j < KF.N; j++) {
+                int32_t id = KF.mvpMapPoints[j] ? KF.mvpMapPoints[j]->id : -1;
+                wr(out, &id, 1);
+            }
+            for (int i = 0; i < m; i++) {
+                int32_t st[3] = {mps[i].bad ? 1 : 0, mps[i].nObs, mps[i].replacedBy ? mps[i].replacedBy->id : -1};
+                wr(out, st, 3);
             }
         }
 

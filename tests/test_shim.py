@@ -139,6 +139,83 @@ def test_shim_end_to_end(gpu, oracle, stream640):
         off += 12
         assert wid == tf["bow_ids"][t] and val == tf["bow_vals"][t]
 
+    # background matchers through the shim: SearchForTriangulation of the frame against itself, then Fuse
+    nt, npairs = struct.unpack_from("<2i", buf, off)
+    off += 8
+    pairs = np.frombuffer(buf, np.int32, 2 * npairs, off).reshape(npairs, 2)
+    off += 8 * npairs
+    h1 = (np.arange(n) % 3 == 0).astype(np.uint8)
+    h2 = (np.arange(n) % 3 == 1).astype(np.uint8)
+    F12 = np.array([[0, -0.0, 0.6], [0, 0, -0.8], [-0.6, 0.8, 0]], np.float32)
+    f32 = np.float32
+    C2 = [f32(0.5) + f32(0.25), f32(-0.25) + f32(0.5), f32(0.125) + f32(2.0)]
+    invz = f32(1.0) / C2[2]
+    ex = float(f32(f32(f32(st.fx) * C2[0]) * invz) + f32(st.cx))
+    ey = float(f32(f32(f32(st.fy) * C2[1]) * invz) + f32(st.cy))
+    sig2 = oe.sigma2()
+    nto, mto = oracle.search_for_triangulation(of, h1, tf, of, h2, tf, F12, ex, ey, sig2, False, True)
+    want = np.array([(i, mto[i]) for i in range(n) if mto[i] >= 0], np.int32).reshape(-1, 2)
+    assert nt == nto == npairs and np.array_equal(pairs, want) and nto > 100, (nt, nto, npairs)
+    nfused = struct.unpack_from("<i", buf, off)[0]
+    off += 4
+    kf_ids = np.frombuffer(buf, np.int32, n, off)
+    off += 4 * n
+    status = np.frombuffer(buf, np.int32, 3 * len(wp), off).reshape(len(wp), 3)
+    off += 12 * len(wp)
+    # the same edits on the oracle's candidates (ORBmatcher.cc:946-969 over the one-key-frame stand-in graph)
+    m = len(wp)
+    idx_in_kf = np.full(m, -1, np.int64)
+    ids = ko.astype(np.int64).copy()  # SearchByProjection's associations
+    for j in range(n):
+        if ids[j] >= 0:
+            idx_in_kf[ids[j]] = j
+    bad = mp["bad"].astype(bool).copy()
+    nobs = (mp["obs_pos"] != 0).astype(np.int64)
+    repl = np.full(m, -1, np.int64)
+    fpts = dict(pts)
+    fpts["bad"] = (bad | (idx_in_kf >= 0)).astype(np.uint8)
+    inv_s2 = oe.inv_sigma2()
+    _, best = oracle.fuse(of, Tcw, float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), log_sf, fpts, th,
+                          inv_s2)
+
+    def replace(x, y):
+        if x == y:
+            return
+        if idx_in_kf[x] >= 0:
+            if idx_in_kf[y] < 0:
+                ids[idx_in_kf[x]] = y
+                idx_in_kf[y] = idx_in_kf[x]
+                nobs[y] += 1
+            else:
+                ids[idx_in_kf[x]] = -1
+        idx_in_kf[x] = -1
+        nobs[x] = 0
+        bad[x] = True
+        repl[x] = y
+
+    want_fused = 0
+    for i in range(m):
+        if best[i] < 0 or bad[i] or idx_in_kf[i] >= 0:
+            continue
+        j = best[i]
+        pin = ids[j]
+        if pin >= 0:
+            if not bad[pin]:
+                if nobs[pin] > nobs[i]:
+                    replace(i, pin)
+                else:
+                    replace(pin, i)
+        else:
+            idx_in_kf[i] = j
+            nobs[i] += 1
+            ids[j] = i
+        want_fused += 1
+    assert nfused == want_fused and want_fused > 100, (nfused, want_fused)
+    assert np.array_equal(kf_ids, ids)
+    assert np.array_equal(status[:, 0], bad.astype(np.int32)) and np.array_equal(status[:, 1], nobs)
+    assert np.array_equal(status[:, 2], repl)
+    assert (repl >= 0).sum() > 0 and (ids != ko).sum() > 0  # both kinds of edit happened
+
     # point cloud thread: three key frames one per pass, a loop closure (poses moved, one key frame culled, key frames
     # taken in id order = reversed), the shutdown pass
     camv = (float(st.fx), float(st.fy), float(st.cx), float(st.cy))
