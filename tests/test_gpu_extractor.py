@@ -325,3 +325,26 @@ def test_quadtree_keys_beyond_lds(gpu, oracle, stream640, kcap, monkeypatch):
     ok, od = oe.extract(img)
     check_stages(gpu, ge, oe, 0, 8, "qt keys %d" % kcap)
     assert_same_keypoints(gk, gd, ok, od, "qt keys %d" % kcap)
+
+
+def test_device_input_with_unaligned_rows(gpu, oracle, stream640):
+    """The level-0 border kernel has a table-driven fast path for 4-byte aligned rows; a device image whose rows start
+    at odd addresses (stride 641, base pointer + 1) takes the byte-wise kernel and must give the same frame."""
+    torch = pytest.importorskip("torch")
+    img = stream640.frame(9)[0]
+    ok, od = oracle.Extractor(1000).extract(img)
+    ge = gpu.ORBextractor(1000)
+    cap = ge.max_keypoints(640, 480)
+    for stride, shift in ((641, 0), (640, 1), (644, 2), (640, 0)):
+        buf = torch.zeros(480 * stride + 8, dtype=torch.uint8, device="cuda")
+        view = buf[shift:shift + 480 * stride].view(480, stride)
+        view[:, :640] = torch.from_numpy(img).cuda()
+        kps = torch.zeros((1, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device="cuda")
+        nout = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ge.extract_batch_device(buf.data_ptr() + shift, 1, 640, 480, stride, 480 * stride, kps.data_ptr(), desc.data_ptr(),
+                                cap, nout.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        n = int(nout[0])
+        gk = kps[0, :n].cpu().numpy().view(gpu.KEYPOINT_DTYPE).reshape(-1)
+        assert_same_keypoints(gk, desc[0, :n].cpu().numpy(), ok, od, "stride %d shift %d" % (stride, shift))
