@@ -1726,6 +1726,7 @@ struct orbgpu_extractor {
     bool border_fast = false;  // level-0 column table present (width % 4 == 0)
     hipEvent_t stage_signal[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // caller's events
     bool counters_dirty = false;  // the cell counters may hold counts no k_quadtree has consumed
+    bool force_batch_quadtree = false;  // ORBGPU_DEBUG_QT_BATCH: the batch variant of k_quadtree for any batch size (tests)
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
 
@@ -2193,7 +2194,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     }
     END(ST_FAST, st);
     BEGIN(ST_QUADTREE, st);
-    if (batch >= QT_BATCH_MIN)
+    if (batch >= QT_BATCH_MIN || e->force_batch_quadtree)
         hipLaunchKernelGGL(k_quadtree<false>, dim3(batch, nl), dim3(QT_THREADS_BATCH), e->qt_lds, st, dg,
                            e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
@@ -2264,6 +2265,7 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
     e->prm = *p;
     if (e->prm.max_batch < 1)
         e->prm.max_batch = 1;
+    e->force_batch_quadtree = getenv("ORBGPU_DEBUG_QT_BATCH") != nullptr;
     if (const char *q = getenv("ORBGPU_DEBUG_FAST_QUEUE"))  // test hook: forces k_fast_detect's queue-full path
         e->fast_queue_cap = std::min(std::max(atoi(q), 0), FD_QCAP);
     e->nlevels = p->nlevels;
