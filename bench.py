@@ -79,6 +79,25 @@ def pmc_traffic(stage, frames_per_launch):
     return None, None
 
 
+def valu_issue(stage, frames_per_launch, ms_per_launch):
+    """Second bound of the dominant kernel (it is VALU-issue bound, not HBM bound): VALU wave-instructions per launch from
+    the committed SQ counter pass (profiles/r02_pmc_sq.json, rocprofv3 --pmc SQ_INSTS_VALU ... at B = 256), scaled to
+    this launch, against the live launch duration; the ceiling is tools/ubench/valu_rate (profiles/r02_valu_rate.txt)."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+        insts = sum(j["kernels"][kn]["valu_insts_per_launch"] for kn in j["kernels"]
+                    if kn.split("<")[0] in STAGE_KERNELS[stage]) / 256.0 * frames_per_launch
+        cyc = 1024 * ms_per_launch * 1e-3 * 2.4e9 / insts  # 1024 SIMDs at the nominal 2.4 GHz, as in r02_valu_rate.txt
+        return {"valu_wave_insts_per_launch": int(insts), "simd_cycles_per_valu_inst": round(cyc, 2),
+                "measured_issue_ceiling_cycles": {"full_rate_class": 2.5, "half_rate_class": 4.3},
+                "note": "cycles a SIMD has per VALU wave-instruction of this kernel at the live launch time; the kernel's "
+                        "instructions are mostly of the half-rate class (packed 16-bit extrema, v_perm), whose measured issue "
+                        "cost is 4.3 cycles",
+                "source": "profiles/r02_pmc_sq.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE), profiles/r02_valu_rate.txt"}
+    except Exception:
+        return None
+
+
 def _cpu_worker(libpath, frames, seconds_budget, want_stages):
     """extract + BF match vs the previous frame over `frames` (cyclically) until the budget is spent.
     ctypes releases the GIL inside the C oracle, so N of these run on N cores from N threads."""
@@ -389,6 +408,7 @@ def main():
                          "algorithmic_bytes": algorithmic_bytes(dom, n_kp, n_cand) * B,
                          "ms_per_launch": stage_ms[dom], "frames_per_launch": B},
             "stages": per_stage,
+            "valu_issue": valu_issue(dom, B, stage_ms[dom]),
             "extract_ms_per_step": round(sum(stage_ms.values()), 4),
             "extract_roofline": {"achieved": ext_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_ach / HBM_PEAK_GBS,
                                  "algorithmic_bytes": ext_bytes * B,

@@ -347,11 +347,14 @@ __device__ __forceinline__ pk16 pkmax(pk16 a, pk16 b) { return __builtin_element
 // gfx950 has packed THREE-input extrema only for f16 (v_pk_maximum3_f16 / v_pk_minimum3_f16).  A 16-bit lane
 // holding an integer 0..255 is, read as f16, the subnormal n * 2^-24: positive f16 bit patterns order like the
 // integers they are, f16 denormals are never flushed on this target, and no value is a NaN, so the f16 extrema of
-// the bit patterns ARE the integer extrema.  With 3-input ops the 16 circular windows of 9 cost
-//   M3[k] = ext3(v[k], v[k+1], v[k+2])            (16 ops)
-//   W9[k] = ext3(M3[k], M3[k+3], M3[k+6])          (16 ops)
-// and the reduction over the 16 windows 8 more: 40 packed ops per polarity (59 with the two-input van Herk
-// prefix/suffix scheme this replaces, 79 before that).
+// the bit patterns ARE the integer extrema.  Windows are taken in pairs: with M8[j] = ext(v[j..j+7]),
+//   ext'(W9[j-1], W9[j]) = ext'(ext(v[j-1], M8[j]), ext(M8[j], v[j+8])) = ext(M8[j], ext'(v[j-1], v[j+8]))
+// (ext = the window extremum, ext' = the opposite extremum taken over the windows), so only the 8 odd j are needed:
+//   M2[j] = ext(v[j], v[j+1]), M4[j] = ext(M2[j], M2[j+2])      (8 + 8 ops, j odd)
+//   E[j]  = ext'(v[j-1], v[j+8])                                 (8 ops)
+//   T[j]  = ext3(M4[j], M4[j+4], E[j])                           (8 ops)
+// and the reduction over the 8 pairs 4 more: 36 packed ops per polarity (40 with one 3-input window per arc, 59
+// with the two-input van Herk prefix/suffix scheme before that, 79 at the start).
 typedef _Float16 pkh __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pkh as_h(pk16 v) { return __builtin_bit_cast(pkh, v); }
 __device__ __forceinline__ pk16 h_as_pk(pkh v) { return __builtin_bit_cast(pk16, v); }
@@ -366,34 +369,32 @@ __device__ __forceinline__ pkh hmin3(pkh a, pkh b, pkh c)
 
 __device__ __forceinline__ pk16 fast_score_pk(pk16 c, const pk16 p[16])
 {
-    pkh v[16], m3[16];
+    pkh v[16], m2[8], m4[8], t[8];
 #pragma unroll
     for (int k = 0; k < 16; k++)
         v[k] = as_h(p[k]);
-    // ---- dark arcs: A = min over windows of the window maximum
+    // ---- dark arcs: A = min over windows of the window maximum (index i stands for j = 2 i + 1)
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        m3[k] = hmax3(v[k], v[(k + 1) & 15], v[(k + 2) & 15]);
-    pkh w[16];
+    for (int i = 0; i < 8; i++)
+        m2[i] = __builtin_elementwise_maximum(v[2 * i + 1], v[(2 * i + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        w[k] = hmax3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
-    pkh a5[5];
+    for (int i = 0; i < 8; i++)
+        m4[i] = __builtin_elementwise_maximum(m2[i], m2[(i + 1) & 7]);
 #pragma unroll
-    for (int k = 0; k < 5; k++)
-        a5[k] = hmin3(w[3 * k], w[3 * k + 1], w[3 * k + 2]);
-    const pkh A = __builtin_elementwise_minimum(hmin3(a5[0], a5[1], a5[2]), hmin3(a5[3], a5[4], w[15]));
+    for (int i = 0; i < 8; i++)
+        t[i] = hmax3(m4[i], m4[(i + 2) & 7], __builtin_elementwise_minimum(v[2 * i], v[(2 * i + 9) & 15]));
+    const pkh A = __builtin_elementwise_minimum(hmin3(hmin3(t[0], t[1], t[2]), hmin3(t[3], t[4], t[5]), t[6]), t[7]);
     // ---- bright arcs: B = max over windows of the window minimum
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        m3[k] = hmin3(v[k], v[(k + 1) & 15], v[(k + 2) & 15]);
+    for (int i = 0; i < 8; i++)
+        m2[i] = __builtin_elementwise_minimum(v[2 * i + 1], v[(2 * i + 2) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        w[k] = hmin3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);
+    for (int i = 0; i < 8; i++)
+        m4[i] = __builtin_elementwise_minimum(m2[i], m2[(i + 1) & 7]);
 #pragma unroll
-    for (int k = 0; k < 5; k++)
-        a5[k] = hmax3(w[3 * k], w[3 * k + 1], w[3 * k + 2]);
-    const pkh B = __builtin_elementwise_maximum(hmax3(a5[0], a5[1], a5[2]), hmax3(a5[3], a5[4], w[15]));
+    for (int i = 0; i < 8; i++)
+        t[i] = hmin3(m4[i], m4[(i + 2) & 7], __builtin_elementwise_maximum(v[2 * i], v[(2 * i + 9) & 15]));
+    const pkh B = __builtin_elementwise_maximum(hmax3(hmax3(t[0], t[1], t[2]), hmax3(t[3], t[4], t[5]), t[6]), t[7]);
     const pk16 zero = {0, 0};
     return pkmax(pkmax(c - h_as_pk(A), h_as_pk(B) - c), zero);  // values are in [0,255]
 }

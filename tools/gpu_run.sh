@@ -24,6 +24,9 @@ bench) run bench 420 bash -c "python bench.py > $OUT/bench.json 2> $OUT/bench.er
 prof) run prof 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; tail -3 $OUT/prof.err; find $OUT/prof -name '*stats*' | head" ;;
 pmc) run pmc 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --batch 256 --pool 1024 --no-cpu-baseline --no-secondary --no-self-check > $OUT/pmc1.json 2> $OUT/pmc1.err; tail -2 $OUT/pmc1.err"
      run pmc2 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --batch 256 --pool 1024 --no-cpu-baseline --no-secondary --no-self-check > $OUT/pmc2.json 2> $OUT/pmc2.err; tail -2 $OUT/pmc2.err" ;;
+pmcsq) B="--steps 3 --warmup 1 --batch 256 --pool 1024 --no-cpu-baseline --no-secondary --no-self-check --no-overlap-match"
+     run pmcsq1 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq1 -- python3 $ROOT/bench.py $B > $OUT/pmcsq1.json 2> $OUT/pmcsq1.err; tail -2 $OUT/pmcsq1.err"
+     run pmcsq2 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq2 -- python3 $ROOT/bench.py $B > $OUT/pmcsq2.json 2> $OUT/pmcsq2.err; tail -2 $OUT/pmcsq2.err" ;;
 diag) run diag 420 bash -c "python tools/gpu_diag.py > $OUT/diag.log 2>&1; tail -20 $OUT/diag.log" ;;
 profserial) run profserial 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -- python3 $ROOT/bench.py --steps 10 --warmup 2 --batch 256 --no-cpu-baseline --no-secondary --no-self-check --no-overlap-match > $OUT/prof_serial.json 2> $OUT/prof_serial.err; tail -3 $OUT/prof_serial.err" ;;
 extra) run extra 420 bash -c "python tools/bench_extra.py c1 c3 c4 pcie > $OUT/extra.json 2> $OUT/extra.err; cat $OUT/extra.json; tail -5 $OUT/extra.err" ;;
