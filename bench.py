@@ -186,6 +186,11 @@ def main():
                     help="N>1 rehearsal on a 1-GPU box: every rank uses device 0 (use with --backend gloo)")
     ap.add_argument("--match-after", default="quadtree", choices=["start", "pyramid", "fast", "quadtree", "orient", "blur"],
                     help="overlapped schedule: the matcher of the previous step starts when the extraction has passed this stage")
+    ap.add_argument("--parts", type=int, default=1,
+                    help="extraction of a step as this many staggered sub-batches on streams of their own (orbgpu_pipeline); "
+                         "1 = one plain batched call (default: next to the matcher more parts gain 0-6 % and not reliably, "
+                         "DESIGN.md section 5).  Only with the overlapped matcher schedule")
+    ap.add_argument("--match-part", type=int, default=-1, help="part whose --match-after stage starts the previous step's matcher")
     ap.add_argument("--no-overlap-match", dest="overlap_match", action="store_false",
                     help="serialise the matcher behind the extraction (default: the matcher of step i runs on a "
                          "second stream next to the extraction of step i+1)")
@@ -230,6 +235,9 @@ def main():
 
     ext = G.ORBextractor(NFEAT, max_batch=B, device_id=local_rank)
     cap = ext.max_keypoints(W, H)
+    P = args.parts if args.overlap_match else 1
+    pl = G.ExtractorPipeline(NFEAT, max_batch=B, parts=P, device_id=local_rank) if P > 1 else None
+    parts = pl.parts if pl else [ext]  # the handles that run the timed extraction
     matcher = G.BatchMatcher(B, cap, device_id=local_rank)
     match_b = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
     nmatch = torch.zeros(B, dtype=torch.int32, device="cuda")
@@ -256,8 +264,14 @@ def main():
     if args.overlap_match and args.match_after != "start":
         ev_mid.record(s_ext)  # torch creates the hipEvent_t on first use
         assert ev_mid.cuda_event, "no event handle"
-        ext.set_stage_signal(args.match_after, ev_mid.cuda_event)
+        parts[args.match_part % len(parts)].set_stage_signal(args.match_after, ev_mid.cuda_event)
     pending = [None]
+    # pipeline mode: one event gates a call (the matcher that last read the output set has finished and its last frame
+    # has been carried over), one event says the call's parts are all done
+    s_gate = torch.cuda.Stream() if pl else None
+    ev_gate = [torch.cuda.Event() for _ in range(nsets)]
+    for e in ev_gate + ev_ext:
+        e.record(s_ext)  # create the handles
 
     def run_match(k):
         matcher.match(B, cap, desc[k].data_ptr(), kps[k].data_ptr() + 12, None, nout[k].data_ptr(),
@@ -286,10 +300,18 @@ def main():
                     ev_copy[p].record(s_match)
             s_ext.wait_event(ev_match[k])  # the matcher that last read this set has finished
             s_ext.wait_event(ev_copy[k])   # ... and its last frame has been copied out
-        ext.extract_batch_device(src.data_ptr(), B, W, H, W, W * H, kps[k].data_ptr() + KP, desc[k].data_ptr() + DS,
-                                 cap, nout[k].data_ptr() + 4, s_ext.cuda_stream)
+        if pl:
+            s_gate.wait_event(ev_match[k])
+            s_gate.wait_event(ev_copy[k])
+            ev_gate[k].record(s_gate)
+            pl.extract_batch_device(src.data_ptr(), B, W, H, W, W * H, kps[k].data_ptr() + KP, desc[k].data_ptr() + DS,
+                                    cap, nout[k].data_ptr() + 4, ev_gate[k].cuda_event, ev_ext[k].cuda_event)
+        else:
+            ext.extract_batch_device(src.data_ptr(), B, W, H, W, W * H, kps[k].data_ptr() + KP, desc[k].data_ptr() + DS,
+                                     cap, nout[k].data_ptr() + 4, s_ext.cuda_stream)
         if args.overlap_match:
-            ev_ext[k].record(s_ext)
+            if not pl:
+                ev_ext[k].record(s_ext)
             if pending[0] is not None and args.match_after != "start":
                 s_match.wait_event(ev_mid)  # extraction i has passed the chosen stage: now match step i-1
             flush_match()
@@ -323,9 +345,12 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
-        ext.set_profiling(i % PROF_EVERY == 0)
+        for e in parts:
+            e.set_profiling(i % PROF_EVERY == 0)
         step(args.warmup + i)
     flush_match()  # the last step's matcher belongs to the timed region
+    if pl:
+        pl.wait(s_ext.cuda_stream)
     s_ext.wait_stream(s_match) if args.overlap_match else None
     ev1.record()
     torch.cuda.synchronize()
@@ -333,8 +358,13 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    stage_ms = ext.stage_times()
-    ext.set_profiling(False)
+    # per stage: the launches that cover the B frames of a step (one per part; with parts > 1 they run next to other
+    # parts' kernels, so their sum is not a duration of the step)
+    stage_ms = {}
+    for e in parts:
+        for name, v in e.stage_times().items():
+            stage_ms[name] = stage_ms.get(name, 0.0) + v
+        e.set_profiling(False)
     # serial schedule only: what the step spends outside the extraction stages = the matcher (+ 3 small copies);
     # with the matcher on its own stream the difference is not a duration of anything
     match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0) if not args.overlap_match else None
@@ -382,7 +412,10 @@ def main():
                      for k, v in stage_ms.items()}
         traffic, traffic_src = pmc_traffic(dom, B)
         ext_bytes = sum(algorithmic_bytes(k, n_kp, n_cand) for k in ("pyramid", "fast", "blur", "orient", "describe"))
-        ext_ach = ext_bytes * B / (sum(stage_ms.values()) * 1e-3) / 1e9
+        # one part: the six stages follow each other, their sum is the extraction time of a step.  Several parts: the
+        # stages of different parts overlap, so the step time itself (which also holds the matcher) is the denominator
+        ext_ms = sum(stage_ms.values()) if P == 1 else elapsed_max / args.steps * 1e3
+        ext_ach = ext_bytes * B / (ext_ms * 1e-3) / 1e9
         out = {
             "metric": "frames/sec ORB extract+match (640x480, 1000 feat)",
             "value": total_frames / elapsed_max,
@@ -399,20 +432,25 @@ def main():
             "config": {"workload": "C2: synthetic 640x480 RGB-D stream, 1000 features, 8 levels, extract + BF-Hamming "
                                    "match of consecutive frames", "frames_per_step_per_gpu": B,
                        "resident_frame_pool": POOL, "sequences": world, "parallelism": "1 sequence per GPU",
-                       "schedule": ("matcher of step i-1 on a second stream, started when extraction i has passed its '%s' stage"
-                                    % args.match_after if args.match_after != "start" else
-                                    "matcher of step i overlapped with extraction of step i+1 (2 streams)")
-                       if args.overlap_match else "serial, 1 stream"},
+                       "schedule": (("extraction as %d staggered sub-batches on %d streams (orbgpu_pipeline: a part starts when the "
+                                     "previous one has passed its pyramid stage); " % (P, P) if pl else "") +
+                                    ("matcher of step i-1 on a stream of its own, started when extraction i has passed its '%s' stage"
+                                     % args.match_after if args.match_after != "start" else
+                                     "matcher of step i overlapped with extraction of step i+1 (2 streams)"))
+                       if args.overlap_match else "serial, 1 stream", "extraction_parts": P},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": algorithmic_bytes(dom, n_kp, n_cand) * B,
-                         "ms_per_launch": stage_ms[dom], "frames_per_launch": B},
+                         "ms_per_launch": stage_ms[dom], "frames_per_launch": B, "launches": P,
+                         "launch_note": None if P == 1 else "ms_per_launch = the %d sub-batch launches of a step, each timed "
+                         "with HIP events on its own stream while the other parts' kernels share the device" % P},
             "stages": per_stage,
             "valu_issue": valu_issue(dom, B, stage_ms[dom]),
-            "extract_ms_per_step": round(sum(stage_ms.values()), 4),
+            "extract_ms_per_step": round(ext_ms, 4),
             "extract_roofline": {"achieved": ext_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_ach / HBM_PEAK_GBS,
                                  "algorithmic_bytes": ext_bytes * B,
-                                 "note": "all six extraction stages of one step against SURVEY.md 8d's 5.74 MB/frame"},
+                                 "note": "all six extraction stages of one step against SURVEY.md 8d's 5.74 MB/frame" +
+                                         ("" if P == 1 else "; time = the whole step (parts overlap, the matcher runs inside it)")},
             "fast_candidates_per_frame": n_cand,
             "match_ms_per_step": None if match_ms is None else round(match_ms, 4),
             "keypoints_per_frame": n_kp,

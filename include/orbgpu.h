@@ -150,6 +150,25 @@ const char *orbgpu_extractor_stage_name(int32_t i);
  * the last stage_times, and starts a new window. */
 int orbgpu_extractor_stage_times(orbgpu_extractor *h, float *ms_out);
 
+/* Throughput mode of ORBextractor::operator() over a resident batch (no counterpart in the reference, which extracts one
+ * frame per call, Frame.cc:247-253): the batch is cut into `parts` sub-batches, each with an extractor handle and a HIP
+ * stream of its own; part k starts when part k-1 (part 0: the last part of the previous call) has passed its pyramid
+ * stage, so the HBM-bound, VALU-bound and latency-bound stages of neighbouring parts overlap -- across calls too, because
+ * a call only ENQUEUES.  params->max_batch = frames per call.  Results are bit-identical to orbgpu_extract_batch_device.
+ *   wait_event (hipEvent_t or NULL): every part waits for it first (inputs uploaded, output buffers free);
+ *   done_event (hipEvent_t or NULL): recorded when every part of THIS call has finished;
+ *   orbgpu_pipeline_wait: makes `hip_stream` wait for everything enqueued so far (plain stream-ordered use);
+ *   orbgpu_pipeline_part: the handle of part k, for set_profiling / stage_times / set_stage_signal. */
+typedef struct orbgpu_pipeline orbgpu_pipeline;
+int orbgpu_pipeline_create(const orbgpu_extractor_params *params, int32_t parts, orbgpu_pipeline **out);
+int orbgpu_pipeline_destroy(orbgpu_pipeline *pl);
+int orbgpu_pipeline_parts(const orbgpu_pipeline *pl, int32_t *parts);
+int orbgpu_pipeline_part(orbgpu_pipeline *pl, int32_t k, orbgpu_extractor **part);
+int orbgpu_pipeline_extract_device(orbgpu_pipeline *pl, const uint8_t *d_gray, int32_t batch, int32_t width,
+                                   int32_t height, size_t stride, size_t frame_stride, orbgpu_keypoint *d_kps,
+                                   uint8_t *d_desc, int32_t cap, int32_t *d_n_out, void *wait_event, void *done_event);
+int orbgpu_pipeline_wait(orbgpu_pipeline *pl, void *hip_stream);
+
 /* ======================================================================================
  * ORBmatcher  (reference include/ORBmatcher.h:41-106, src/ORBmatcher.cc)
  * ====================================================================================== */

@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 // ---------------------------------------------------------------------------------------------
 constexpr int DP_R = 18;                  // |rotated pattern offset| <= 18 (radius^2 <= 338, A6)
 constexpr int DP_ROWS = 2 * DP_R + 1;     // 37 rows
-constexpr int DP_DW = 10;                 // 37 bytes + up to 3 bytes of alignment slack = 10 dwords per row
+constexpr int DP_DW = 12;                 // 37 bytes + up to 3 bytes of alignment slack = 10 dwords, staged as 3 x 16 bytes
 constexpr int DP_BYTES = DP_ROWS * DP_DW * 4;
 
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, size_t frame_pyr,
@@ -1613,29 +1613,46 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     const float ca = a.ca, sb = a.sb;
     const int xl = a.x + EDGE - DP_R;  // leftmost padded column of the patch
     const int al = xl & 3;
-    const uint8_t *src = blur + (size_t)f * frame_pyr + a.plane_off + (size_t)(a.y + EDGE - DP_R) * a.pitch + (xl - al);
-    uint32_t *pl = reinterpret_cast<uint32_t *>(patch[slot]);
+    // staging: 37 rows x three 16-byte pieces = 111 pieces over the 32 lanes of the key point, four x4 loads per lane (the
+    // 8 bytes past the 40 a row needs are still inside the padded row: the key point is >= 16 pixels from the image edge).
+    // The frame base is wave-uniform and the rest a 32-bit offset
+    const uint8_t *fb = blur + (size_t)f * frame_pyr;
+    const uint32_t vbase = (uint32_t)a.plane_off + (uint32_t)(a.y + EDGE - DP_R) * (uint32_t)a.pitch + (uint32_t)(xl - al);
+    struct __attribute__((packed, aligned(4))) Piece {
+        uint32_t d[4];
+    };
+    constexpr int NPIECE = DP_ROWS * 3, NK = (NPIECE + 31) / 32;  // 111, 4
+    Piece stage[NK];
 #pragma unroll
-    for (int k = 0; k < (DP_ROWS * DP_DW + 31) / 32; k++) {
-        const int idx = byte + 32 * k;
-        if (idx < DP_ROWS * DP_DW) {
-            const int r = idx / DP_DW, c = idx - r * DP_DW;
-            pl[idx] = *reinterpret_cast<const uint32_t *>(src + (size_t)(r) * a.pitch + c * 4);
-        }
+    for (int k = 0; k < NK; k++) {
+        const int q = byte + 32 * k, r = (q * 171) >> 9, part = q - 3 * r;  // q / 3 for 0..127
+        if (q < NPIECE)
+            stage[k] = *reinterpret_cast<const Piece *>(fb + (vbase + (uint32_t)r * (uint32_t)a.pitch + (uint32_t)part * 16u));
     }
+    uint4 *pl = reinterpret_cast<uint4 *>(patch[slot]);
+#pragma unroll
+    for (int k = 0; k < NK; k++)
+        if (byte + 32 * k < NPIECE)
+            pl[byte + 32 * k] = make_uint4(stage[k].d[0], stage[k].d[1], stage[k].d[2], stage[k].d[3]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint8_t *center = patch[slot] + DP_R * (DP_DW * 4) + DP_R + al;
+    // cvRound by the magic constant 1.5 * 2^23: t = v + MAGIC is v rounded to the nearest-even integer (|v| < 2^22), and the
+    // low 24 bits of its pattern are 0x400000 + round(v).  v_mad_u32_u24 reads exactly those bits, so the byte offset
+    // 40 r + c costs one multiply-add and one add of a per-lane constant that takes the biases out (mod 2^32)
+    constexpr float MAGIC = 12582912.0f;
+    constexpr uint32_t BIAS = 0x400000u * (DP_DW * 4) + 0x4B400000u;
+    const uint32_t kc = (uint32_t)(slot * DP_BYTES + DP_R * (DP_DW * 4) + DP_R + al) - BIAS;
+    const uint8_t *lds = &patch[0][0];
     int val = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const float x0 = (float)(int8_t)(pw[k] & 0xFF), y0 = (float)(int8_t)((pw[k] >> 8) & 0xFF);
         const float x1 = (float)(int8_t)((pw[k] >> 16) & 0xFF), y1 = (float)(int8_t)(pw[k] >> 24);
-        const int r0 = __float2int_rn(x0 * sb + y0 * ca), c0 = __float2int_rn(x0 * ca - y0 * sb);
-        const int r1 = __float2int_rn(x1 * sb + y1 * ca), c1 = __float2int_rn(x1 * ca - y1 * sb);
-        const int t0 = center[__mul24(r0, DP_DW * 4) + c0];
-        const int t1 = center[__mul24(r1, DP_DW * 4) + c1];
+        const uint32_t r0b = __float_as_uint((x0 * sb + y0 * ca) + MAGIC), c0b = __float_as_uint((x0 * ca - y0 * sb) + MAGIC);
+        const uint32_t r1b = __float_as_uint((x1 * sb + y1 * ca) + MAGIC), c1b = __float_as_uint((x1 * ca - y1 * sb) + MAGIC);
+        const int t0 = lds[__umul24(r0b, DP_DW * 4) + c0b + kc];
+        const int t1 = lds[__umul24(r1b, DP_DW * 4) + c1b + kc];
         val |= (t0 < t1) << k;
     }
     desc[((size_t)f * cap + kpi) * 32 + byte] = (uint8_t)val;
@@ -1726,6 +1743,7 @@ struct orbgpu_extractor {
     uint64_t graph_key = 0;
     bool border_fast = false;  // level-0 column table present (width % 4 == 0)
     hipEvent_t stage_signal[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // caller's events
+    hipEvent_t pipe_signal[8] = {};  // the same for an orbgpu_pipeline that owns this handle (stagger of its parts)
     bool counters_dirty = false;  // the cell counters may hold counts no k_quadtree has consumed
     bool force_batch_quadtree = false;  // ORBGPU_DEBUG_QT_BATCH: the batch variant of k_quadtree for any batch size (tests)
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
@@ -2153,6 +2171,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
             ORBGPU_HIP_TRY(hipEventRecord(evs[1 + (stage)], s));               \
         if (e->stage_signal[stage])                                            \
             ORBGPU_HIP_TRY(hipEventRecord(e->stage_signal[stage], s));         \
+        if (e->pipe_signal[stage])                                             \
+            ORBGPU_HIP_TRY(hipEventRecord(e->pipe_signal[stage], s));          \
     }
     BEGIN(ST_PYRAMID, st);
     {
@@ -2572,6 +2592,146 @@ int orbgpu_extractor_set_stage_signal(orbgpu_extractor *e, int32_t stage, void *
 {
     ORBGPU_REQUIRE(e && stage >= 0 && stage < ST_COUNT, "bad stage");
     e->stage_signal[stage] = (hipEvent_t)hip_event;
+    return ORBGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// orbgpu_pipeline: a batch as `parts` sub-batches on `parts` streams, each with an extractor handle of its own.  Part k
+// starts when part k-1 has passed the pyramid stage (part 0: the last part of the previous call), so the stages of
+// neighbouring parts -- HBM-bound pyramid / blur / gathers, VALU-bound FAST, latency-bound quadtree -- run next to each
+// other instead of one after the other, across calls as well: a call only enqueues, and hands back an event.
+// ---------------------------------------------------------------------------------------------
+struct orbgpu_pipeline {
+    std::vector<orbgpu_extractor *> part;
+    std::vector<hipStream_t> stream;
+    std::vector<hipEvent_t> ev_stage, ev_done;
+    int device_id = 0;
+    int last_part = -1;  // last part the previous call used (its ev_stage holds a record)
+};
+
+int orbgpu_pipeline_destroy(orbgpu_pipeline *pl)
+{
+    if (!pl)
+        return ORBGPU_OK;
+    select_device(pl->device_id);
+    for (auto st : pl->stream)
+        if (st)
+            (void)hipStreamSynchronize(st);
+    for (auto e : pl->part)
+        orbgpu_extractor_destroy(e);
+    for (auto ev : pl->ev_stage)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    for (auto ev : pl->ev_done)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    for (auto st : pl->stream)
+        if (st)
+            (void)hipStreamDestroy(st);
+    delete pl;
+    return ORBGPU_OK;
+}
+
+int orbgpu_pipeline_create(const orbgpu_extractor_params *p, int32_t parts, orbgpu_pipeline **out)
+{
+    ORBGPU_REQUIRE(p && out, "null argument");
+    ORBGPU_REQUIRE(parts >= 1 && parts <= 16, "parts must be in [1,16]");
+    int rc = select_device(p->device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    orbgpu_pipeline *pl = new (std::nothrow) orbgpu_pipeline();
+    if (!pl) {
+        set_error("out of host memory");
+        return ORBGPU_ENOMEM;
+    }
+    pl->device_id = p->device_id;
+    orbgpu_extractor_params pp = *p;
+    pp.max_batch = (std::max(p->max_batch, 1) + parts - 1) / parts;
+    for (int k = 0; k < parts; k++) {
+        orbgpu_extractor *e = nullptr;
+        if ((rc = orbgpu_extractor_create(&pp, &e)) != ORBGPU_OK) {
+            orbgpu_pipeline_destroy(pl);
+            return rc;
+        }
+        pl->part.push_back(e);
+        hipStream_t st = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        const bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&a, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&b, hipEventDisableTiming) == hipSuccess;
+        pl->stream.push_back(st);
+        pl->ev_stage.push_back(a);
+        pl->ev_done.push_back(b);
+        if (!ok) {
+            orbgpu_pipeline_destroy(pl);
+            set_error("orbgpu_pipeline_create: stream / event creation failed");
+            return ORBGPU_EHIP;
+        }
+        e->pipe_signal[ST_PYRAMID] = a;
+    }
+    *out = pl;
+    return ORBGPU_OK;
+}
+
+int orbgpu_pipeline_parts(const orbgpu_pipeline *pl, int32_t *parts)
+{
+    ORBGPU_REQUIRE(pl && parts, "null argument");
+    *parts = (int32_t)pl->part.size();
+    return ORBGPU_OK;
+}
+
+int orbgpu_pipeline_part(orbgpu_pipeline *pl, int32_t k, orbgpu_extractor **part)
+{
+    ORBGPU_REQUIRE(pl && part && k >= 0 && k < (int)pl->part.size(), "bad part index");
+    *part = pl->part[k];
+    return ORBGPU_OK;
+}
+
+int orbgpu_pipeline_extract_device(orbgpu_pipeline *pl, const uint8_t *d_gray, int32_t batch, int32_t w, int32_t h,
+                                   size_t stride, size_t frame_stride, orbgpu_keypoint *d_kps, uint8_t *d_desc,
+                                   int32_t cap, int32_t *d_n_out, void *wait_event, void *done_event)
+{
+    ORBGPU_REQUIRE(pl && d_gray && d_kps && d_desc && d_n_out, "null argument");
+    ORBGPU_REQUIRE(batch >= 1 && cap >= 1, "bad batch/cap");
+    int rc = select_device(pl->device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    const int P = (int)pl->part.size();
+    const int n = (batch + P - 1) / P;
+    int used = 0;
+    for (int k = 0; k < P && k * n < batch; k++, used++) {
+        const int f0 = k * n, cnt = std::min(n, batch - f0);
+        hipStream_t st = pl->stream[k];
+        if (wait_event)
+            ORBGPU_HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)wait_event, 0));
+        const int prev = k > 0 ? k - 1 : pl->last_part;
+        if (prev >= 0 && prev != k)
+            ORBGPU_HIP_TRY(hipStreamWaitEvent(st, pl->ev_stage[prev], 0));
+        rc = orbgpu_extract_batch_device(pl->part[k], d_gray + (size_t)f0 * frame_stride, cnt, w, h, stride, frame_stride,
+                                         d_kps + (size_t)f0 * cap, d_desc + (size_t)f0 * cap * 32, cap, d_n_out + f0, st);
+        if (rc != ORBGPU_OK)
+            return rc;
+        ORBGPU_HIP_TRY(hipEventRecord(pl->ev_done[k], st));
+    }
+    pl->last_part = used - 1;
+    if (done_event) {
+        // on the last part's stream once it has seen the others finish (a stream of its own for the join cost the step
+        // one more cross-stream hop: 2.27 against 2.13 ms with a single part)
+        for (int k = 0; k + 1 < used; k++)
+            ORBGPU_HIP_TRY(hipStreamWaitEvent(pl->stream[used - 1], pl->ev_done[k], 0));
+        ORBGPU_HIP_TRY(hipEventRecord((hipEvent_t)done_event, pl->stream[used - 1]));
+    }
+    return ORBGPU_OK;
+}
+
+int orbgpu_pipeline_wait(orbgpu_pipeline *pl, void *hip_stream)
+{
+    ORBGPU_REQUIRE(pl, "null argument");
+    int rc = select_device(pl->device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    for (size_t k = 0; k < pl->part.size(); k++)  // an event never recorded is no wait
+        ORBGPU_HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, pl->ev_done[k], 0));
     return ORBGPU_OK;
 }
 

@@ -114,6 +114,8 @@ ABI_SYMBOLS = [
     "orbgpu_extract_batch_device", "orbgpu_extractor_get_pyramid_level", "orbgpu_extractor_debug_read",
     "orbgpu_extractor_graph_state", "orbgpu_extractor_set_profiling", "orbgpu_extractor_set_stage_signal", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
     "orbgpu_extractor_stage_times",
+    "orbgpu_pipeline_create", "orbgpu_pipeline_destroy", "orbgpu_pipeline_parts", "orbgpu_pipeline_part",
+    "orbgpu_pipeline_extract_device", "orbgpu_pipeline_wait",
     "orbgpu_hamming256", "orbgpu_match_bf", "orbgpu_matcher_create", "orbgpu_matcher_destroy",
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
     "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_search_local_points_batch_device", "orbgpu_search_by_projection_last_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
@@ -171,6 +173,12 @@ def lib():
         "orbgpu_extractor_set_profiling": [vp, i32],
         "orbgpu_extractor_set_stage_signal": [vp, i32, vp],
         "orbgpu_extractor_stage_times": [vp, vp],
+        "orbgpu_pipeline_create": [vp, i32, vp],
+        "orbgpu_pipeline_destroy": [vp],
+        "orbgpu_pipeline_parts": [vp, vp],
+        "orbgpu_pipeline_part": [vp, i32, vp],
+        "orbgpu_pipeline_extract_device": [vp, vp, i32, i32, i32, sz, sz, vp, vp, i32, vp, vp, vp],
+        "orbgpu_pipeline_wait": [vp, vp],
         "orbgpu_hamming256": [vp, vp, i32, vp, i32],
         "orbgpu_match_bf": [vp, vp, vp, i32, vp, vp, i32, i32, f32, i32, vp, vp, i32],
         "orbgpu_matcher_create": [i32, i32, i32, vp],
@@ -351,6 +359,57 @@ class ORBextractor:
         ms = np.zeros(n, np.float32)
         check(self.L.orbgpu_extractor_stage_times(self.h, _p(ms)))
         return {self.L.orbgpu_extractor_stage_name(i).decode(): float(ms[i]) for i in range(n)}
+
+
+class _PipelinePart(ORBextractor):
+    """View of one part's handle (set_profiling / stage_times / set_stage_signal / debug reads); the pipeline owns it."""
+
+    def __init__(self, L, h, nfeatures, nlevels):
+        self.L, self.h, self.nfeatures, self.nlevels = L, h, nfeatures, nlevels
+
+    def close(self):
+        self.h = None
+
+    __del__ = close
+
+
+class ExtractorPipeline:
+    """orbgpu_pipeline: a resident batch extracted as `parts` staggered sub-batches on streams of their own (include/orbgpu.h).
+    Calls only enqueue; order consumers with done_event / wait(stream)."""
+
+    def __init__(self, nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device_id=0, max_batch=1,
+                 parts=2):
+        self.L = lib()
+        self.params = ExtractorParams(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id, max_batch)
+        h = C.c_void_p()
+        check(self.L.orbgpu_pipeline_create(C.byref(self.params), parts, C.byref(h)))
+        self.h = h
+        self.parts = []
+        for k in range(parts):
+            ph = C.c_void_p()
+            check(self.L.orbgpu_pipeline_part(self.h, k, C.byref(ph)))
+            self.parts.append(_PipelinePart(self.L, ph, nfeatures, nlevels))
+
+    def close(self):
+        if getattr(self, "h", None):
+            for e in self.parts:
+                e.h = None
+            self.L.orbgpu_pipeline_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def max_keypoints(self, width, height):
+        return self.parts[0].max_keypoints(width, height)
+
+    def extract_batch_device(self, d_gray_ptr, batch, width, height, stride, frame_stride, d_kps_ptr, d_desc_ptr, cap,
+                             d_nout_ptr, wait_event=None, done_event=None):
+        check(self.L.orbgpu_pipeline_extract_device(self.h, d_gray_ptr, batch, width, height, stride, frame_stride, d_kps_ptr,
+                                                    d_desc_ptr, cap, d_nout_ptr, C.c_void_p(wait_event or 0),
+                                                    C.c_void_p(done_event or 0)))
+
+    def wait(self, stream=0):
+        check(self.L.orbgpu_pipeline_wait(self.h, C.c_void_p(stream or 0)))
 
 
 # --------------------------------------------------------------------------------------------
