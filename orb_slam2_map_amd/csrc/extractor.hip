@@ -1345,6 +1345,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
                                                 int cap, int *__restrict__ n_out, int iters)
 {
     __shared__ uint32_t W10[4 * 16 * 9], M01[4 * 16 * 9];
+    __shared__ __align__(16) uint8_t stage[8][31 * 48];
     for (int i = threadIdx.x; i < 4 * 16 * 9; i += 256) {
         const int a = i / (16 * 9), av = (i / 9) % 16, j = i % 9;
         uint32_t w = 0, m = 0;
@@ -1406,20 +1407,44 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     const int a = xl & 3;
     const int v = hl - HALF_PATCH;         // rows -15..15 (lane 31 idles)
     int m10 = 0, m01 = 0;
-    if (hl < 31) {
-        const int av = v < 0 ? -v : v;
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(
-            pyr + (size_t)f * frame_pyr + g.plane_off + rowoff(y + EDGE + v, g.pitch) + (xl - a));
-        const uint32_t *w = &W10[(a * 16 + av) * 9], *m = &M01[(a * 16 + av) * 9];
-        uint32_t sw = 0, sm = 0;
+    {
+        // the disc's 31 rows x 48 bytes staged in LDS as 93 16-byte pieces, lane = (row, piece): a wave-load then touches
+        // ~21 rows instead of 62 (the 12 bytes past the 36 a row needs are inside the padded row)
+        const uint8_t *base = pyr + (size_t)f * frame_pyr + g.plane_off + (xl - a);
+        struct __attribute__((packed, aligned(4))) Piece {
+            uint32_t d[4];
+        };
+        Piece pc[3];
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-            const uint32_t d = row[q];
-            sw = __builtin_amdgcn_udot4(d, w[q], sw, false);
-            sm = __builtin_amdgcn_udot4(d, m[q], sm, false);
+        for (int k = 0; k < 3; k++) {
+            const int q = hl + 32 * k, r = (q * 171) >> 9, part = q - 3 * r;
+            if (q < 93)
+                pc[k] = *reinterpret_cast<const Piece *>(base + rowoff(y + EDGE - HALF_PATCH + r, g.pitch) + part * 16);
         }
-        m10 = (int)sw - 16 * (int)sm;
-        m01 = v * (int)sm;
+        uint4 *pl = reinterpret_cast<uint4 *>(stage[threadIdx.x >> 5]);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (hl + 32 * k < 93)
+                pl[hl + 32 * k] = make_uint4(pc[k].d[0], pc[k].d[1], pc[k].d[2], pc[k].d[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (hl < 31) {
+            const int av = v < 0 ? -v : v;
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(stage[threadIdx.x >> 5]) + hl * 12;
+            const uint32_t *w = &W10[(a * 16 + av) * 9], *m = &M01[(a * 16 + av) * 9];
+            uint32_t sw = 0, sm = 0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                const uint32_t d = row[q];
+                sw = __builtin_amdgcn_udot4(d, w[q], sw, false);
+                sm = __builtin_amdgcn_udot4(d, m[q], sm, false);
+            }
+            m10 = (int)sw - 16 * (int)sm;
+            m01 = v * (int)sm;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next item overwrites the slot
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) {
