@@ -1503,11 +1503,11 @@ __global__ __launch_bounds__(256) void k_trig(KpAux *__restrict__ aux, const int
 // Register-only streaming kernel, no LDS: a thread owns a column strip of 8 output pixels (two
 // aligned dwords of the padded plane) x BLUR_ROWS rows.  Per input row it loads 4 aligned dwords in one
 // 16-byte access (they cover the 14 bytes it needs), forms the eight 7-tap horizontal sums with v_alignbyte +
-// v_dot4_u32_u8, keeps the last 7 row sums in registers and emits 8 bytes per row.  (4 pixels per thread with
+// v_dot4_u32_u8, keeps the last row sums in registers as six PAIRS of consecutive rows (blur_vsum) and emits 8 bytes per row.  (4 pixels per thread with
 // 12-byte loads and 4-byte stores: 176 us against 166 us; a second input row in flight: no gain.)
 // HBM-bound: each pixel is fetched once from HBM (neighbouring strips re-read through L1/L2).
 // ---------------------------------------------------------------------------------------------
-constexpr int BLUR_ROWS = 28;  // output rows per strip (4 x 7: the 7-row register ring unrolls evenly)
+constexpr int BLUR_ROWS = 30;  // output rows per strip (5 x 6: the 6-slot register ring of row pairs unrolls evenly)
 
 __device__ __forceinline__ void blur_hsum(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t h[4])
 {
@@ -1523,21 +1523,28 @@ __device__ __forceinline__ void blur_hsum(uint32_t d0, uint32_t d1, uint32_t d2,
     h[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
 }
 
-__device__ __forceinline__ uint32_t blur_vsum(const uint32_t r0[4], const uint32_t r1[4], const uint32_t r2[4],
-                                              const uint32_t r3[4], const uint32_t r4[4], const uint32_t r5[4],
-                                              const uint32_t r6[4])
+// Vertical pass on PAIRS of row sums.  A row sum is <= 255 * 257 = 65535: it fits 16 bits exactly, so P_r = (h_{r-1},
+// h_r) packs two consecutive rows of a pixel into one register (one v_alignbit when row r arrives) and
+// v_dot2_u32_u16 applies two taps per instruction: for the output row c
+//   s = 32768 + P_{c-2}.(18,34) + P_c.(49,55) + P_{c+2}.(49,34) + P_{c+3}.(0,18)
+// (4 instructions instead of 3 adds + 4 multiply-adds + the rounding add), the ring holds the 6 pairs P_{c-2..c+3}.
+// The four results are narrowed two at a time: v_perm takes the high halves (s >> 16 <= 257), v_pk_min_u16 saturates.
+__device__ __forceinline__ uint32_t blur_vsum(const uint32_t A[4], const uint32_t C[4], const uint32_t E[4],
+                                              const uint32_t F[4])
 {
-    uint32_t out = 0;
+    const us2 K01 = {18, 34}, K23 = {49, 55}, K45 = {49, 34}, K6 = {0, 18};
+    uint32_t sv[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-        // row sums are <= 255 * 257 < 2^24: 24-bit multiply-adds (full rate; a 32-bit v_mul_lo_u32 is quarter rate)
-        uint32_t s = __umul24(18u, r0[p] + r6[p]) + __umul24(34u, r1[p] + r5[p]) + __umul24(49u, r2[p] + r4[p]) +
-                     __umul24(55u, r3[p]);
-        s = (s + 32768u) >> 16;
-        s = s > 255u ? 255u : s;
-        out |= s << (8 * p);
+        uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, A[p]), K01, 32768u, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, C[p]), K23, acc, false);
+        acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, E[p]), K45, acc, false);
+        sv[p] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, F[p]), K6, acc, false);
     }
-    return out;
+    const us2 cap = {255, 255};
+    const us2 lo = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm(sv[1], sv[0], 0x07060302u)), cap);
+    const us2 hi = __builtin_elementwise_min(__builtin_bit_cast(us2, __builtin_amdgcn_perm(sv[3], sv[2], 0x07060302u)), cap);
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
@@ -1564,40 +1571,51 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     struct __attribute__((packed, aligned(4))) Q4 {
         uint32_t d[4];
     };
-    uint32_t r0[8], r1[8], r2[8], r3[8], r4[8], r5[8], r6[8];
+    uint32_t p0[8], p1[8], p2[8], p3[8], p4[8], p5[8], hn[8];  // six row PAIRS (blur_vsum) and the newest row's sums
     Q4 nx;
 #define B8_HSUM(R, Q)                                                                                        \
     {                                                                                                        \
         blur_hsum(Q.d[0], Q.d[1], Q.d[2], R);                                                                \
         blur_hsum(Q.d[1], Q.d[2], Q.d[3], R + 4);                                                            \
     }
-#define B8_LOAD(R, row)                                                                                      \
+// the pair (previous row, this row): the previous row is the high half of the previous pair
+#define B8_PAIR(P, PREV, H)                                                                                  \
+    _Pragma("unroll") for (int p = 0; p < 8; p++) P[p] = __builtin_amdgcn_alignbit(H[p], PREV[p], 16);
+#define B8_LOAD(P, PREV, row)                                                                                \
     {                                                                                                        \
         const Q4 q = *reinterpret_cast<const Q4 *>(src + (size_t)(row) * g.pitch);                           \
-        B8_HSUM(R, q)                                                                                        \
+        B8_HSUM(hn, q)                                                                                       \
+        B8_PAIR(P, PREV, hn)                                                                                 \
     }
-#define B8_STEP(A, B, C, D, E, F, G, k)                                                                      \
+// A = P_{c-2}, C = P_c, E = P_{c+2}; F receives P_{c+3} (it held P_{c-3})
+#define B8_STEP(A, C, E, F, k)                                                                               \
     if ((k) < rows) {                                                                                        \
-        B8_HSUM(G, nx)                                                                                       \
+        B8_HSUM(hn, nx)                                                                                      \
+        B8_PAIR(F, E, hn)                                                                                    \
         if ((k) + 1 < rows)                                                                                  \
             nx = *reinterpret_cast<const Q4 *>(src + (size_t)((k) + 7) * g.pitch);                           \
         uint2 o;                                                                                             \
-        o.x = blur_vsum(A, B, C, D, E, F, G);                                                                \
-        o.y = blur_vsum(A + 4, B + 4, C + 4, D + 4, E + 4, F + 4, G + 4);                                    \
+        o.x = blur_vsum(A, C, E, F);                                                                         \
+        o.y = blur_vsum(A + 4, C + 4, E + 4, F + 4);                                                         \
         *reinterpret_cast<uint2 *>(dst + (size_t)(k) * g.pitch) = o;                                         \
     }
-    B8_LOAD(r0, 0) B8_LOAD(r1, 1) B8_LOAD(r2, 2) B8_LOAD(r3, 3) B8_LOAD(r4, 4) B8_LOAD(r5, 5)
+    // rows y0-3 .. y0+2: the pairs P_{-2} .. P_{2} of the first output row (p5's low half, row y0-4, is never used: zero)
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+        p5[p] = 0;
+    B8_LOAD(p5, p5, 0) B8_LOAD(p0, p5, 1) B8_LOAD(p1, p0, 2) B8_LOAD(p2, p1, 3) B8_LOAD(p3, p2, 4) B8_LOAD(p4, p3, 5)
     nx = *reinterpret_cast<const Q4 *>(src + (size_t)6 * g.pitch);  // next input row, fetched one step ahead (two: no gain)
+    // now p0 = P_{-2} = (row -3, row -2), p1 = P_{-1}, p2 = P_0, p3 = P_1, p4 = P_2; p5 = (-, row -3) is free for P_3
 #pragma unroll 1
-    for (int k = 0; k < BLUR_ROWS; k += 7) {
-        B8_STEP(r0, r1, r2, r3, r4, r5, r6, k)
-        B8_STEP(r1, r2, r3, r4, r5, r6, r0, k + 1)
-        B8_STEP(r2, r3, r4, r5, r6, r0, r1, k + 2)
-        B8_STEP(r3, r4, r5, r6, r0, r1, r2, k + 3)
-        B8_STEP(r4, r5, r6, r0, r1, r2, r3, k + 4)
-        B8_STEP(r5, r6, r0, r1, r2, r3, r4, k + 5)
-        B8_STEP(r6, r0, r1, r2, r3, r4, r5, k + 6)
+    for (int k = 0; k < BLUR_ROWS; k += 6) {
+        B8_STEP(p0, p2, p4, p5, k)
+        B8_STEP(p1, p3, p5, p0, k + 1)
+        B8_STEP(p2, p4, p0, p1, k + 2)
+        B8_STEP(p3, p5, p1, p2, k + 3)
+        B8_STEP(p4, p0, p2, p3, k + 4)
+        B8_STEP(p5, p1, p3, p4, k + 5)
     }
+#undef B8_PAIR
 #undef B8_STEP
 #undef B8_LOAD
 #undef B8_HSUM
