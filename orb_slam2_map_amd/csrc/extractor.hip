@@ -522,7 +522,7 @@ __device__ __forceinline__ void detect_record(uint32_t sc4, uint32_t rec, const 
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_fast_detect(const uint8_t *__restrict__ pyr, size_t frame_pyr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_detect(const uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                      const LevelGeom *__restrict__ geom, DetectGeom dg,
                                                      const ColumnInfo *__restrict__ ctab,
                                                      const CellDesc *__restrict__ cells, int ncells_total,
