@@ -484,8 +484,9 @@ struct StripGeom {  // strips of all levels, flattened (k_blur)
 // a cell land in no particular order: nothing downstream depends on it (k_quadtree's "first maximum" rule rebuilds
 // vToDistributeKeys order from the key itself).
 // Measured (B = 256, 640x480): 375 us against 324 + 158 us for the score-map / per-cell pair it replaces, and
-// 1.8 MB per frame less HBM traffic.  143 VGPRs: three waves per SIMD, which still saturates the VALU (390 us with
-// raw rows in 128 VGPRs and 30 v_perm_b32 per step instead of 8).
+// 1.8 MB per frame less HBM traffic (143 VGPRs, three waves per SIMD, every window row unpacked once; 390 us with raw
+// rows in 128 VGPRs and 30 v_perm_b32 per step instead of 8); 338 us with the paired-window score network below, which
+// also fits four waves per SIMD (121 VGPRs).
 // ---------------------------------------------------------------------------------------------
 constexpr int FD_OWN = 62;    // columns a wave owns (lanes 1..62)
 constexpr int FD_QCAP = 512;  // row records a wave can queue before it falls back to emitting them directly
