@@ -1512,16 +1512,15 @@ constexpr int BLUR_ROWS = 30;  // output rows per strip (5 x 6: the 6-slot regis
 
 __device__ __forceinline__ void blur_hsum(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t h[4])
 {
-    // window bytes 0..11 = padded columns 4s-4 .. 4s+7; output pixel p has its centre at byte 4+p
-    const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);  // taps 0..3
-    const uint32_t K1 = 49u | (34u << 8) | (18u << 16);                 // taps 4..6
-    const uint32_t a1 = __builtin_amdgcn_alignbyte(d1, d0, 1), b1 = __builtin_amdgcn_alignbyte(d2, d1, 1);
-    const uint32_t a2 = __builtin_amdgcn_alignbyte(d1, d0, 2), b2 = __builtin_amdgcn_alignbyte(d2, d1, 2);
-    const uint32_t a3 = __builtin_amdgcn_alignbyte(d1, d0, 3), b3 = __builtin_amdgcn_alignbyte(d2, d1, 3);
-    h[0] = __builtin_amdgcn_udot4(b1, K1, __builtin_amdgcn_udot4(a1, K0, 0u, false), false);
-    h[1] = __builtin_amdgcn_udot4(b2, K1, __builtin_amdgcn_udot4(a2, K0, 0u, false), false);
-    h[2] = __builtin_amdgcn_udot4(b3, K1, __builtin_amdgcn_udot4(a3, K0, 0u, false), false);
-    h[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
+    // window bytes 0..11 = padded columns 4s-4 .. 4s+7; output pixel p has its centre at byte 4+p, its taps at bytes
+    // 1+p .. 7+p.  The taps [18,34,49,55,49,34,18] are laid over the three dwords as per-pixel weight constants, so no
+    // data is shifted: 2 + 3 + 3 + 2 v_dot4_u32_u8 for the four pixels (6 v_alignbyte + 8 v_dot4 before).
+#define W4(a, b, c, d) ((uint32_t)(a) | ((uint32_t)(b) << 8) | ((uint32_t)(c) << 16) | ((uint32_t)(d) << 24))
+    h[0] = __builtin_amdgcn_udot4(d1, W4(55, 49, 34, 18), __builtin_amdgcn_udot4(d0, W4(0, 18, 34, 49), 0u, false), false);
+    h[1] = __builtin_amdgcn_udot4(d2, W4(18, 0, 0, 0), __builtin_amdgcn_udot4(d1, W4(49, 55, 49, 34), __builtin_amdgcn_udot4(d0, W4(0, 0, 18, 34), 0u, false), false), false);
+    h[2] = __builtin_amdgcn_udot4(d2, W4(34, 18, 0, 0), __builtin_amdgcn_udot4(d1, W4(34, 49, 55, 49), __builtin_amdgcn_udot4(d0, W4(0, 0, 0, 18), 0u, false), false), false);
+    h[3] = __builtin_amdgcn_udot4(d2, W4(49, 34, 18, 0), __builtin_amdgcn_udot4(d1, W4(18, 34, 49, 55), 0u, false), false);
+#undef W4
 }
 
 // Vertical pass on PAIRS of row sums.  A row sum is <= 255 * 257 = 65535: it fits 16 bits exactly, so P_r = (h_{r-1},
@@ -1566,9 +1565,14 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int col = (4 + 2 * sx) * 4;  // first of the strip's two padded dword columns
     const int y0 = sy * BLUR_ROWS;
     const int rows = min(BLUR_ROWS, g.h - y0);
-    const size_t plane = (size_t)f * frame_pyr + g.plane_off;
-    const uint8_t *src = pyr + plane + (size_t)(y0 + EDGE - 3) * g.pitch + (col - 4);
-    uint8_t *dst = blur + plane + (size_t)(y0 + EDGE) * g.pitch + col;
+    // wave-uniform frame bases + 32-bit offsets stepped by one pitch per row (a frame's planes are far below 4 GB):
+    // one v_add per access instead of a 64-bit multiply-add
+    const uint8_t *fsrc = pyr + (size_t)f * frame_pyr;
+    uint8_t *fdst = blur + (size_t)f * frame_pyr;
+    const uint32_t pitch = (uint32_t)g.pitch;
+    const uint32_t src0 = (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE - 3) * pitch + (uint32_t)(col - 4);
+    uint32_t soff = src0 + 6u * pitch;  // the row fetched one step ahead
+    uint32_t doff = (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE) * pitch + (uint32_t)col;
     struct __attribute__((packed, aligned(4))) Q4 {
         uint32_t d[4];
     };
@@ -1584,7 +1588,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     _Pragma("unroll") for (int p = 0; p < 8; p++) P[p] = __builtin_amdgcn_alignbit(H[p], PREV[p], 16);
 #define B8_LOAD(P, PREV, row)                                                                                \
     {                                                                                                        \
-        const Q4 q = *reinterpret_cast<const Q4 *>(src + (size_t)(row) * g.pitch);                           \
+        const Q4 q = *reinterpret_cast<const Q4 *>(fsrc + (src0 + (uint32_t)(row) * pitch));                \
         B8_HSUM(hn, q)                                                                                       \
         B8_PAIR(P, PREV, hn)                                                                                 \
     }
@@ -1593,19 +1597,21 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     if ((k) < rows) {                                                                                        \
         B8_HSUM(hn, nx)                                                                                      \
         B8_PAIR(F, E, hn)                                                                                    \
+        soff += pitch;                                                                                       \
         if ((k) + 1 < rows)                                                                                  \
-            nx = *reinterpret_cast<const Q4 *>(src + (size_t)((k) + 7) * g.pitch);                           \
+            nx = *reinterpret_cast<const Q4 *>(fsrc + soff);                                                 \
         uint2 o;                                                                                             \
         o.x = blur_vsum(A, C, E, F);                                                                         \
         o.y = blur_vsum(A + 4, C + 4, E + 4, F + 4);                                                         \
-        *reinterpret_cast<uint2 *>(dst + (size_t)(k) * g.pitch) = o;                                         \
+        *reinterpret_cast<uint2 *>(fdst + doff) = o;                                                         \
+        doff += pitch;                                                                                       \
     }
     // rows y0-3 .. y0+2: the pairs P_{-2} .. P_{2} of the first output row (p5's low half, row y0-4, is never used: zero)
 #pragma unroll
     for (int p = 0; p < 8; p++)
         p5[p] = 0;
     B8_LOAD(p5, p5, 0) B8_LOAD(p0, p5, 1) B8_LOAD(p1, p0, 2) B8_LOAD(p2, p1, 3) B8_LOAD(p3, p2, 4) B8_LOAD(p4, p3, 5)
-    nx = *reinterpret_cast<const Q4 *>(src + (size_t)6 * g.pitch);  // next input row, fetched one step ahead (two: no gain)
+    nx = *reinterpret_cast<const Q4 *>(fsrc + soff);  // next input row, fetched one step ahead (two: no gain)
     // now p0 = P_{-2} = (row -3, row -2), p1 = P_{-1}, p2 = P_0, p3 = P_1, p4 = P_2; p5 = (-, row -3) is free for P_3
 #pragma unroll 1
     for (int k = 0; k < BLUR_ROWS; k += 6) {
