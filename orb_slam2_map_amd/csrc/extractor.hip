@@ -269,8 +269,10 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     const uint32_t bq = strips[strip_off + sdw].base_q;
     const uint4 sel = sels[strip_off + sdw], wt = wts[strip_off + sdw];
     const uint32_t selv[4] = {sel.x, sel.y, sel.z, sel.w}, wv[4] = {wt.x, wt.y, wt.z, wt.w};
-    const uint8_t *base = pyr + (size_t)f * frame_pyr + gs.plane_off + (bq & 0xFFFFu);
-    uint8_t *dst = pyr + (size_t)f * frame_pyr + g.plane_off + sdw * 4;
+    // wave-uniform frame base + 32-bit offsets
+    uint8_t *fb = pyr + (size_t)f * frame_pyr;
+    const uint32_t base = (uint32_t)gs.plane_off + (bq & 0xFFFFu);
+    const uint32_t dst = (uint32_t)g.plane_off + (uint32_t)sdw * 4u;
     // the row table entries of all rows of the item first (one round trip), so that the source loads of a row do
     // not wait for a table load of their own
     YTab yts[PYR_ROWS];
@@ -288,11 +290,11 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
         if (rr >= rows || py >= g.h + 2 * EDGE)
             break;
         const YTab yt = yts[rr];
-        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy1 + EDGE, gs.pitch));
+        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(fb + (base + rowoff(yt.sy1 + EDGE, gs.pitch)));
         const uint32_t c0 = S1[0], c1 = S1[1], c2 = S1[2];
         int t0[4];
         if (!REUSE || (int)yt.sy0 != kept_row) {
-            const uint32_t *S0 = reinterpret_cast<const uint32_t *>(base + rowoff(yt.sy0 + EDGE, gs.pitch));
+            const uint32_t *S0 = reinterpret_cast<const uint32_t *>(fb + (base + rowoff(yt.sy0 + EDGE, gs.pitch)));
             const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
             kept[k] = t1;
         }
         kept_row = yt.sy1;
-        *reinterpret_cast<uint32_t *>(dst + rowoff(py, g.pitch)) = v;
+        *reinterpret_cast<uint32_t *>(fb + (dst + rowoff(py, g.pitch))) = v;
     }
 }
 
@@ -552,8 +554,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int col = (9 + sx) * 4;          // padded byte column of pixel 0: image x = col - 19
     const int y0 = EDGE + band * g.hcell;  // first row of the band (image coordinates)
     const int rows = in_range ? min(g.hcell, g.h - EDGE - y0) : 0;
-    const size_t plane = (size_t)f * frame_pyr + g.plane_off;
-    const uint8_t *src = pyr + plane + (size_t)(y0 + EDGE - 3) * g.pitch + (col - 4);
+    // wave-uniform frame base + 32-bit offset (one v_mad_u32_u24 per row instead of a 64-bit multiply-add)
+    const uint8_t *fsrc = pyr + (size_t)f * frame_pyr;
+    const uint32_t src0 = (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE - 3) * (uint32_t)g.pitch + (uint32_t)(col - 4);
     uint32_t *fslots = slots + (size_t)f * frame_slots;
     int *fcnt = cell_cnt + (size_t)f * ncells_total;
 
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     RowU r0, r1, r2, r3, r4, r5, r6;
 #define FD_FETCH(row)                                                                                        \
     {                                                                                                        \
-        const uint32_t *qq = reinterpret_cast<const uint32_t *>(src + (size_t)(row) * g.pitch);              \
+        const uint32_t *qq = reinterpret_cast<const uint32_t *>(fsrc + (src0 + rowoff((row), g.pitch)));    \
         nx.d[0] = qq[0];                                                                                     \
         nx.d[1] = qq[1];                                                                                     \
         nx.d[2] = qq[2];                                                                                     \
