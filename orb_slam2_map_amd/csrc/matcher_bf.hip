@@ -97,14 +97,15 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // (n * 0x00204081) & 0x01010101 spreads the 4 bits of a nibble to the low bits of 4 bytes (a 24-bit multiply: both
 // factors are small; 32-bit integer multiplies are quarter rate), and the 0 / 1 bytes are themselves the v_perm
 // selector that picks 0xFF or 0x01 out of the constant 0x000001FF.
-__device__ __forceinline__ v4i bf_expand16(uint32_t hw)
+// PM = the two byte values: 0x01FF gives +1 / -1, 0x10F0 gives +16 / -16 (the A rows of k_bf_topk, see there).
+template <uint32_t PM = 0x000001FFu> __device__ __forceinline__ v4i bf_expand16(uint32_t hw)
 {
     v4i r;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t n = (hw >> (4 * q)) & 0xFu;
         const uint32_t w01 = __umul24(n, 0x00204081u) & 0x01010101u;
-        r[q] = (int)__builtin_amdgcn_perm(0u, 0x000001FFu, w01);
+        r[q] = (int)__builtin_amdgcn_perm(0u, PM, w01);
     }
     return r;
 }
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
         const uint32_t *ga = reinterpret_cast<const uint32_t *>(desc_a + ((size_t)pair * cap + min(i, na - 1)) * 32);
 #pragma unroll
         for (int s = 0; s < 8; s++)
-            fa[s] = bf_expand16(ga[s] >> (16 * h));
+            fa[s] = bf_expand16<0x000010F0u>(ga[s] >> (16 * h));  // +-16: the accumulator is 16 x the dot product
     }
     const int per = (nb + nsplit - 1) / nsplit;
     const int jbeg = (int)blockIdx.z * per, jend = min(nb, jbeg + per);
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
         dst[0] = bf_expand16(d);
         dst[1] = bf_expand16(d >> 16);
     };
+    const v16i tag = {15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0};
     uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
     int lim = acc_min;  // accumulator value a distance must reach to be inserted
     uint32_t d_next = 0;
@@ -175,7 +177,10 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
         if (tile + 1 < ntiles)
             stage(d_cur, (tile + 1) & 1);
         const uint8_t *tb = &s_tile[tile & 1][r * BF_TILE_STRIDE + h * 16];
-        v16i acc0 = {0}, acc1 = {0};
+        // The selection below wants every value tagged with its register index, e = dot << 4 | 15 - reg.  The matrix
+        // core does it: the A rows are expanded to +-16 instead of +-1 and the chain starts from the constant accumulator
+        // {15, 14, .., 0}, so acc[reg] IS e (32 v_lshl_or per tile and wave less).
+        v16i acc0 = tag, acc1 = tag;
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             const v4i fb0 = *reinterpret_cast<const v4i *>(tb + s * 32);
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb0, fa[s], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb1, fa[s], acc1, 0, 0, 0);
         }
-        // acc[reg] = 256 - 2 * hamming(A row i, B row j0 + (reg & 3) + 8 (reg >> 2) + 4 h).  Only distances <= dmax
+        // acc[reg] >> 4 = 256 - 2 * hamming(A row i, B row j0 + (reg & 3) + 8 (reg >> 2) + 4 h).  Only distances <= dmax
         // can influence a decision (see the host side), i.e. acc >= acc_min: most row blocks hold no such value for any
         // lane of the wave and are dismissed with 8 v_max3 and one branch.
         // Selection.  A lane's 16 values per row block rarely hold anything that beats its list, but SOME lane of the
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
             int e[16];
 #pragma unroll
             for (int reg = 0; reg < 16; reg++)
-                e[reg] = (acc[reg] << 4) | (15 - reg);
+                e[reg] = acc[reg];
             const int j0 = jbeg + tile * BF_TILE_ROWS + 32 * u + 4 * h;
             for (;;) {
                 int m = max(max(e[0], e[1]), e[2]);
