@@ -110,6 +110,16 @@ template <uint32_t PM = 0x000001FFu> __device__ __forceinline__ v4i bf_expand16(
     return r;
 }
 
+// 16 descriptor bits -> 16 bytes 0 / 1 (the staged B rows of k_bf_topk: one v_perm per dword less than +-1 bytes)
+__device__ __forceinline__ v4i bf_expand16_01(uint32_t hw)
+{
+    v4i r;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        r[q] = (int)(__umul24((hw >> (4 * q)) & 0xFu, 0x00204081u) & 0x01010101u);
+    return r;
+}
+
 // NODES: the node-wise matcher (SearchByBoW on real feature vectors): a B row is a candidate of an A row only if both
 // sit under the same vocabulary node (node_a / node_b, [pairs][cap], < 0 = not in the feature vector).
 template <bool NODES>
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
         const uint32_t *ga = reinterpret_cast<const uint32_t *>(desc_a + ((size_t)pair * cap + min(i, na - 1)) * 32);
 #pragma unroll
         for (int s = 0; s < 8; s++)
-            fa[s] = bf_expand16<0x000010F0u>(ga[s] >> (16 * h));  // +-16: the accumulator is 16 x the dot product
+            fa[s] = bf_expand16<0x000020E0u>(ga[s] >> (16 * h));  // +-32, against B bytes 0 / 1: see the accumulator start below
     }
     const int per = (nb + nsplit - 1) / nsplit;
     const int jbeg = (int)blockIdx.z * per, jend = min(nb, jbeg + per);
@@ -158,10 +168,24 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
     };
     auto stage = [&](uint32_t d, int buf) {
         v4i *dst = reinterpret_cast<v4i *>(&s_tile[buf][sm * BF_TILE_STRIDE + sw * 32]);
-        dst[0] = bf_expand16(d);
-        dst[1] = bf_expand16(d >> 16);
+        dst[0] = bf_expand16_01(d);
+        dst[1] = bf_expand16_01(d >> 16);
     };
-    const v16i tag = {15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0};
+    // Accumulator start.  With a_k = +-1 the A row, b_k = 0 / 1 the B row:  sum 32 a_k b_k = 16 (dot + S_a), dot = sum a_k
+    // (2 b_k - 1) = 256 - 2 hamming and S_a = sum a_k = 2 popcount(A row) - 256, a constant of the lane (the A row is the
+    // accumulator's column).  Starting the chain from (15 - reg) - 16 S_a leaves acc[reg] = dot << 4 | 15 - reg.
+    v16i tag;
+    {
+        const uint32_t *ga = reinterpret_cast<const uint32_t *>(desc_a + ((size_t)pair * cap + min(i, na - 1)) * 32);
+        int pop = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+            pop += __popc(ga[s]);
+        const int sa16 = 16 * (2 * pop - 256);
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++)
+            tag[reg] = (15 - reg) - sa16;
+    }
     uint32_t t[4] = {BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE, BF_KEY_NONE};
     int lim = acc_min;  // accumulator value a distance must reach to be inserted
     uint32_t d_next = 0;
@@ -178,8 +202,8 @@ __global__ __launch_bounds__(BF_TOPK_THREADS) void k_bf_topk(int cap, const uint
             stage(d_cur, (tile + 1) & 1);
         const uint8_t *tb = &s_tile[tile & 1][r * BF_TILE_STRIDE + h * 16];
         // The selection below wants every value tagged with its register index, e = dot << 4 | 15 - reg.  The matrix
-        // core does it: the A rows are expanded to +-16 instead of +-1 and the chain starts from the constant accumulator
-        // {15, 14, .., 0}, so acc[reg] IS e (32 v_lshl_or per tile and wave less).
+        // core does it: the A rows are expanded to +-32 instead of +-1 and the chain starts from the lane's constant
+        // accumulator (above), so acc[reg] IS e (32 v_lshl_or per tile and wave less, and the staged B rows stay 0 / 1).
         v16i acc0 = tag, acc1 = tag;
 #pragma unroll
         for (int s = 0; s < 8; s++) {
