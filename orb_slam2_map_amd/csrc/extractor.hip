@@ -241,10 +241,11 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 // Fast path of K1b: one thread per aligned output dword (4 pixels) of the padded plane.  The 8 source
 // bytes the 4 outputs need per source row lie inside one 12-byte aligned window (true for scale
 // factors <= 2; checked on the host, otherwise k_resize_level runs), which is fetched with 3 dword
-// loads; v_perm_b32 with host-precomputed selectors forms (left tap | right tap << 16) pairs and
-// v_dot2_u32_u16 applies the 11-bit weights.  Same integer arithmetic as k_resize_level.
+// loads and shifted by the column's byte offset (two v_alignbyte) so that they lie in one 8-byte pair; v_perm_b32 with
+// host-precomputed selectors forms (left tap | right tap << 16) pairs and v_dot2_u32_u16 applies the 11-bit weights.
+// Same integer arithmetic as k_resize_level.
 struct ResizeStrip {  // per padded output dword column of a level
-    uint32_t base_q;  // bits 0..15: window base (padded source column, multiple of 4); bits 16..19: pair select
+    uint32_t base_q;  // bits 0..15: window base (padded source column, multiple of 4); bits 16..17: byte shift of the window
 };
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     if (rg * rows >= g.h + 2 * EDGE)
         return;
     const uint32_t bq = strips[strip_off + sdw].base_q;
+    const uint32_t sh = bq >> 16;  // byte shift of the 12-byte window (0..3)
     const uint4 sel = sels[strip_off + sdw], wt = wts[strip_off + sdw];
     const uint32_t selv[4] = {sel.x, sel.y, sel.z, sel.w}, wv[4] = {wt.x, wt.y, wt.z, wt.w};
     // wave-uniform frame base + 32-bit offsets
@@ -296,10 +298,10 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
         if (!REUSE || (int)yt.sy0 != kept_row) {
             const uint32_t *S0 = reinterpret_cast<const uint32_t *>(fb + (base + rowoff(yt.sy0 + EDGE, gs.pitch)));
             const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, sh), hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const bool q = (bq >> (16 + k)) & 1u;
-                const uint32_t p0 = __builtin_amdgcn_perm(q ? a2 : a1, q ? a1 : a0, selv[k]);
+                const uint32_t p0 = __builtin_amdgcn_perm(hi, lo, selv[k]);
                 t0[k] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p0), __builtin_bit_cast(us2, wv[k]), 0u, false);
             }
         } else {
@@ -308,10 +310,10 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
                 t0[k] = kept[k];
         }
         uint32_t v = 0;
+        const uint32_t lo1 = __builtin_amdgcn_alignbyte(c1, c0, sh), hi1 = __builtin_amdgcn_alignbyte(c2, c1, sh);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const bool q = (bq >> (16 + k)) & 1u;
-            const uint32_t p1 = __builtin_amdgcn_perm(q ? c2 : c1, q ? c1 : c0, selv[k]);
+            const uint32_t p1 = __builtin_amdgcn_perm(hi1, lo1, selv[k]);
             const int t1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), __builtin_bit_cast(us2, wv[k]), 0u, false);
             const int o = ((__mul24((int)yt.b0, t0[k] >> 4) >> 16) + (__mul24((int)yt.b1, t1 >> 4) >> 16) + 2) >> 2;  // 12 x 15 bits
             v |= (uint32_t)(o & 0xFF) << (8 * k);
@@ -1986,17 +1988,17 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
                     cr[k] = xt[k]->sx1 + EDGE;
                     mn = std::min(mn, cl[k]);
                 }
-                const int wbase = mn & ~3;
+                // the 12-byte window starts at the aligned column wbase; the kernel shifts it by sh = mn - wbase bytes (two
+                // v_alignbyte per source row) so that all eight taps of the four outputs lie in ONE 8-byte pair
+                const int wbase = mn & ~3, sh = mn - wbase;
                 ResizeStrip rsx;
-                rsx.base_q = (uint32_t)wbase;
+                rsx.base_q = (uint32_t)wbase | ((uint32_t)sh << 16);
                 uint32_t sel[4], wt[4];
                 for (int k = 0; k < 4; k++) {
-                    const int ol = cl[k] - wbase, orr = cr[k] - wbase;
-                    if (ol < 0 || orr < ol || orr > 11)
+                    const int ol = cl[k] - mn, orr = cr[k] - mn;
+                    if (ol < 0 || orr < ol || orr > 7)
                         g.rs_fast = 0;
-                    const int q = ol >= 4 ? 1 : 0;
-                    rsx.base_q |= (uint32_t)q << (16 + k);
-                    sel[k] = (uint32_t)((ol - 4 * q) & 7) | 0x0c00u | ((uint32_t)((orr - 4 * q) & 7) << 16) | 0x0c000000u;
+                    sel[k] = (uint32_t)(ol & 7) | 0x0c00u | ((uint32_t)(orr & 7) << 16) | 0x0c000000u;
                     wt[k] = (uint32_t)xt[k]->a0 | ((uint32_t)xt[k]->a1 << 16);
                 }
                 rstrip.push_back(rsx);
