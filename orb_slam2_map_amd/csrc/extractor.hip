@@ -1337,7 +1337,7 @@ struct UMax {
 
 // Half a wave (32 lanes) per selected key point, lane = one row v of the radius-15 disc.  A lane
 // reads its row as 9 aligned dwords and reduces it with v_dot4_u32_u8 against per-(alignment, |v|)
-// byte-weight tables built once per workgroup in LDS: W10 holds (u+16) inside the disc (0 outside),
+// byte-weight tables (built on the host, copied to LDS by every workgroup): W10 holds (u+16) inside the disc (0 outside),
 // M01 holds 1 inside the disc, so  sum u*I = dot(W10) - 16*dot(M01)  and  sum I = dot(M01).
 // Integer moments: exact in any summation order.
 constexpr int OR_ITERS = 4;  // key points per half wave for full batches (1 below OR_BATCH_MIN frames: latency)
@@ -1346,26 +1346,16 @@ constexpr int OR_BATCH_MIN = 32;
 __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                 const LevelGeom *__restrict__ geom, int nlevels,
                                                 const uint32_t *__restrict__ sel, int sel_cap_total,
-                                                const int *__restrict__ nsel, UMax um,
+                                                const int *__restrict__ nsel, const uint32_t *__restrict__ orw,
                                                 orbgpu_keypoint *__restrict__ kps, KpAux *__restrict__ aux,
                                                 int cap, int *__restrict__ n_out, int iters)
 {
     __shared__ uint32_t W10[4 * 16 * 9], M01[4 * 16 * 9];
     __shared__ __align__(16) uint8_t stage[8][31 * 48];
+    // the weight tables are built once on the host (orient_tables): a workgroup only copies them
     for (int i = threadIdx.x; i < 4 * 16 * 9; i += 256) {
-        const int a = i / (16 * 9), av = (i / 9) % 16, j = i % 9;
-        uint32_t w = 0, m = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int u = 4 * j + k - a - HALF_PATCH;
-            const int au = u < 0 ? -u : u;
-            if (au <= um.v[av]) {
-                w |= (uint32_t)(u + 16) << (8 * k);
-                m |= 1u << (8 * k);
-            }
-        }
-        W10[i] = w;
-        M01[i] = m;
+        W10[i] = orw[i];
+        M01[i] = orw[4 * 16 * 9 + i];
     }
     __syncthreads();
 
@@ -2159,7 +2149,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_rstrip, sizeof(ResizeStrip) * std::max<size_t>(rstrip.size(), 1));
     RSV(e->d_rsel, sizeof(uint4) * std::max<size_t>(rsel.size(), 1));
     RSV(e->d_rwt, sizeof(uint4) * std::max<size_t>(rwt.size(), 1));
-    RSV(e->d_pattern, 1024);
+    RSV(e->d_pattern, 1024 + 2 * 4 * 16 * 9 * sizeof(uint32_t));  // rBRIEF pattern, then k_orient's weight tables
     const size_t B = (size_t)batch;
     RSV(e->d_pyr, e->frame_pyr * B);
     RSV(e->d_blur, e->frame_pyr * B);
@@ -2185,6 +2175,22 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         ORBGPU_HIP_TRY(hipMemcpy(e->d_rwt.p, rwt.data(), sizeof(uint4) * rwt.size(), hipMemcpyHostToDevice));
     }
     ORBGPU_HIP_TRY(hipMemcpy(e->d_pattern.p, k_pattern_host, 1024, hipMemcpyHostToDevice));
+    {
+        // k_orient's byte-weight tables per (alignment a of the disc's first column, |v|, dword j of the 9-dword row):
+        // W10 holds u + 16 inside the disc (0 outside), M01 holds 1 inside the disc
+        std::vector<uint32_t> orw(2 * 4 * 16 * 9, 0u);
+        for (int i = 0; i < 4 * 16 * 9; i++) {
+            const int a = i / (16 * 9), av = (i / 9) % 16, j = i % 9;
+            for (int k = 0; k < 4; k++) {
+                const int u = 4 * j + k - a - HALF_PATCH;
+                if (std::abs(u) <= e->umax.v[av]) {
+                    orw[i] |= (uint32_t)(u + 16) << (8 * k);
+                    orw[4 * 16 * 9 + i] |= 1u << (8 * k);
+                }
+            }
+        }
+        ORBGPU_HIP_TRY(hipMemcpy(e->d_pattern.as<uint8_t>() + 1024, orw.data(), orw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     // the blurred planes are only written inside the image; define the rest once
     ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
     // cell counters start at zero; k_quadtree re-arms them after reading
@@ -2288,7 +2294,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     BEGIN(ST_ORIENT, st);
     const int or_iters = batch >= OR_BATCH_MIN ? OR_ITERS : 1;
     hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 8 * or_iters - 1) / (8 * or_iters), batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
-                       e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->umax, d_kps,
+                       e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(),
+                       reinterpret_cast<const uint32_t *>(e->d_pattern.as<uint8_t>() + 1024), d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out, or_iters);
     hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
                        e->d_aux.as<KpAux>(), d_n_out, cap);
