@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
 
 A *step* = one batch of `--batch` synthetic 640x480 frames already resident in HBM: 8-level ORB
-extraction at 1000 features (pyramid, per-cell FAST, quadtree, orientation, blur, rBRIEF) followed by
+extraction at 1000 features (pyramid, blur, per-cell FAST, quadtree, orientation, rBRIEF) followed by
 `batch` brute-force matches of consecutive frames (frame b vs b-1; the first against the last frame
 of the previous step).  Everything runs through the C ABI of liborbgpu.so on the calling stream;
 torch only owns device memory, the stream and (N>1) the RCCL process group.
