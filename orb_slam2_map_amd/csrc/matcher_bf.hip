@@ -81,9 +81,10 @@ __device__ __forceinline__ void top4_merge(uint32_t t[4], const uint32_t o[4])
 // ratio test (ORBmatcher.cc:228-231), so a list that ends early means "nothing else matters" exactly like a list
 // that ran out of B rows.
 // grid = (ceil(cap / 256), pairs, nsplit): the B rows are split into nsplit contiguous ranges to put enough
-// waves in flight (2 for a full batch, up to BF_MAX_SPLIT for a single pair, where the scan is latency bound);
+// waves in flight (none for a full batch -- every range keeps a top-4 of its own, so two ranges insert almost twice as
+// often as one: 0.30 -> 0.28 ms per 512 pairs --, up to BF_MAX_SPLIT for a single pair, where the scan is latency bound);
 // k_bf_resolve merges the partial lists (4 smallest of their union).
-constexpr int BF_MIN_SPLIT = 2, BF_MAX_SPLIT = 16;
+constexpr int BF_MIN_SPLIT = 1, BF_MAX_SPLIT = 16;
 constexpr size_t BF_RESOLVE_MAX_LDS = 150 * 1024;  // of the CU's 160 KB; static LDS of k_bf_resolve is < 1 KB
 constexpr int BF_TILE_STRIDE = 272;                // bytes per expanded B row in LDS (256 + 16: bank spread)
 constexpr int BF_TILE_ROWS = 64;                   // B rows staged per iteration
