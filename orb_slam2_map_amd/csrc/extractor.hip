@@ -39,6 +39,8 @@ struct LevelGeom {
     int patch;
     int xtab_off, ytab_off;  // resize tables (levels >= 1)
     int rs_off, rs_fast;     // fast-path strip tables (k_resize_fast); rs_fast = 0 -> k_resize_level
+    int ncols_eff;           // cell columns that are not skipped (ORBextractor.cc:797)
+    uint32_t inv_wcell, inv_hcell;  // mul_hi(v, inv) == v / wcell (hcell) for every key coordinate (host-verified)
 };
 
 struct CellDesc {
@@ -560,7 +562,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint8_t *fsrc = pyr + (size_t)f * frame_pyr;
     const uint32_t src0 = (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE - 3) * (uint32_t)g.pitch + (uint32_t)(col - 4);
     uint32_t *fslots = slots + (size_t)f * frame_slots;
-    int *fcnt = cell_cnt + (size_t)f * ncells_total;
+    int *fcnt = cell_cnt + (size_t)f * (ncells_total + ORBGPU_MAX_LEVELS);  // per-cell counters ...
+    int *lcnt = fcnt + ncells_total;                                         // ... then the stored keys of every level
 
     const ColumnInfo ci = in_range ? ctab[dg.ctab_off[level] + sx] : ColumnInfo{0xFFFFFFFFu, 0u};
     {
@@ -604,10 +607,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (slot < qcap)
                 s_q[wave][slot] = make_uint2(sc4, rec);
             else
-                detect_record(sc4, rec, s_lane[wave][lane], [&](int p, int sc, int cell) {  // queue full: one atomic per key
+                detect_record(sc4, rec, s_lane[wave][lane], [&](int p, int sc, int cell) {  // queue full: two atomics per key
                     const DetectLane &dl = s_lane[wave][lane];
-                    const int pos = atomicAdd(&fcnt[cell], 1 + (sc > t_ini ? 65536 : 0)) & 0xFFFF;
-                    fslots[cells[cell].slot_off + pos] = pack_key(dl.xrel + p, dl.yrel + row, sc - 1);
+                    atomicAdd(&fcnt[cell], 1 + (sc > t_ini ? 65536 : 0));
+                    fslots[geom[level].slot_off + atomicAdd(&lcnt[level], 1)] = pack_key(dl.xrel + p, dl.yrel + row, sc - 1);
                 });
         }
     };
@@ -682,8 +685,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         finish_row(0u, 0u, rows - 1);  // the row below the band counts as 0
 
     // ---- the wave's records become keys.  The cells a wave touches are a contiguous range of at most FD_CELLS ids
-    //      (host-checked), so id mod FD_CELLS addresses per-wave counters in LDS: count, reserve the cell's slots with
-    //      one global atomic per (wave, cell), then hand the positions out from LDS.
+    //      (host-checked), so id mod FD_CELLS addresses per-wave counters in LDS.  Per (wave, cell): one global atomic
+    //      on the cell's counter (survivors | those above iniThFAST << 16 -- all the quadtree needs to pick the cell's
+    //      threshold).  Per (wave, level): one global atomic that reserves a range of the level's key array; the keys of
+    //      a level are stored densely, in no particular order.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -698,11 +703,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < FD_CELLS) {
-        const int c = s_cc[wave][lane];
+    {
+        const int c = lane < FD_CELLS ? s_cc[wave][lane] : 0;
+        const int mine = c & 0xFFFF;
+        // the items of a wave are consecutive in (level, band, column) order: its cells belong to the levels of its
+        // first .. last owned lane (one level, two at a boundary, more only for tiny images); a cell belongs to the
+        // last of them whose first cell id is not above its own
+        const int lvmin = __builtin_amdgcn_readlane(level, 1), lvmax = __builtin_amdgcn_readlane(level, FD_OWN);
+        int lv = -1;
         if (c) {
             const int cell = s_cid[wave][lane];
-            s_cc[wave][lane] = cells[cell].slot_off + (atomicAdd(&fcnt[cell], c) & 0xFFFF);  // first slot of this wave's keys
+            atomicAdd(&fcnt[cell], c);
+            lv = lvmin;
+            for (int L = lvmin + 1; L <= lvmax; L++)
+                lv += cell >= geom[L].cell_first ? 1 : 0;
+        }
+        for (int L = lvmin; L <= lvmax; L++) {
+            const int v = lv == L ? mine : 0;
+            int incl = v;
+#pragma unroll
+            for (int off = 1; off < FD_CELLS; off <<= 1) {  // the counts live in lanes 0 .. FD_CELLS-1
+                const int o = __shfl_up(incl, off, 64);
+                incl += lane >= off ? o : 0;
+            }
+            const int total = __shfl(incl, FD_CELLS - 1, 64);
+            int base = 0;
+            if (lane == 0 && total)
+                base = atomicAdd(&lcnt[L], total);
+            base = __shfl(base, 0, 64);
+            if (lv == L)
+                s_cc[wave][lane] = geom[L].slot_off + base + incl - v;  // first position of this wave's keys of the cell
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -843,7 +873,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     extern __shared__ __align__(16) uint8_t smem[];
     __shared__ int s_tmp[16];
     const int kcap = LDS_KEYS ? kcap_arg : 0;
-    __shared__ int s_n, s_phase, s_done, s_nexp, s_cut;
+    __shared__ int s_n, s_phase, s_done, s_nexp, s_cut, s_nst, s_nk;
 
     const int tid = threadIdx.x, nt = blockDim.x;
     // grid = (frames, levels): all workgroups of level 0 (the longest) are dispatched first
@@ -898,105 +928,61 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     };
 
     const uint32_t *fslots = slots + (size_t)f * frame_slots;
-    int *ccounts = cell_cnt + (size_t)f * ncells_total + g.cell_first;
+    int *ccounts = cell_cnt + (size_t)f * (ncells_total + ORBGPU_MAX_LEVELS) + g.cell_first;
+    int *lcount = cell_cnt + (size_t)f * (ncells_total + ORBGPU_MAX_LEVELS) + ncells_total + level;
 
     QT_MARK(0)
-    // ---- step 0: this level's keys, compacted.  k_fast_detect leaves the NMS survivors above the lower threshold in
-    //      every cell's slots, in no particular order, with the counter = survivors | (those above iniThFAST) << 16.
-    //      cv::FAST(iniThFAST) of the cell is the subset above iniThFAST (a survivor of the 3x3 suppression at the lower
-    //      threshold with s > t_hi also survives at t_hi: a neighbour with s_n <= t_hi cannot beat it), and only a cell
-    //      where that is empty keeps the rest (ORBextractor.cc:809-816).  The order inside the dense array is arbitrary;
+    // ---- step 0: this level's keys, filtered and compacted.  k_fast_detect leaves the NMS survivors above the lower
+    //      threshold of the whole level in one dense array (no particular order; *lcount of them) and per cell the
+    //      counter survivors | (those above iniThFAST) << 16.  cv::FAST(iniThFAST) of a cell is the subset above
+    //      iniThFAST (a survivor of the 3x3 suppression at the lower threshold with s > t_hi also survives at t_hi: a
+    //      neighbour with s_n <= t_hi cannot beat it), and only a cell where that is empty keeps the rest
+    //      (ORBextractor.cc:809-816).  The cell of a key follows from its coordinates: a key of cell (i, j) has
+    //      x in [j wCell + 3, (j + 1) wCell + 3), y likewise (:797-825).  The order inside the dense array is arbitrary;
     //      the one place where vToDistributeKeys order matters (step 3) derives it from the key.  On the way the keys
     //      are counted per initial node (:542-585).
     const int n_ini = g.n_ini;
     const float hx = g.hx;
+    const uint32_t *lslots = slots + (size_t)f * frame_slots + g.slot_off;
     for (int b = tid; b < n_ini; b += nt)
         S.sb[b] = 0;
     for (int c = tid; c < g.ncells; c += nt) {
         const int cnt = ccounts[c];
-        ccounts[c] = 0;  // ready for the next extraction
-        const int tot = cnt & 0xFFFF, ni = cnt >> 16;
-        S.ccnt[c] = ni ? ni : tot;
-        S.ccnt_next[c] = tot;
-        S.soff[c] = (uint32_t)cells[g.cell_first + c].slot_off | (ni ? 0x80000000u : 0u);  // bit 31: only keys above iniThFAST count
+        ccounts[c] = 0;                        // ready for the next extraction
+        S.soff[c] = (cnt >> 16) ? 1u : 0u;     // the cell has corners above iniThFAST: only those count
+    }
+    if (tid == 0) {
+        s_nst = *lcount;
+        *lcount = 0;
+        s_nk = 0;
     }
     __syncthreads();
-    const int nkeys = block_excl_scan(S.ccnt, g.ncells, s_tmp);  // ccnt[c] = first dense index of cell c
-    if (LDS_KEYS) {
-        // single frames (one workgroup per CU, latency counts): one thread per cell walks the cell's slots, eight
-        // loads in flight, and appends what the cell keeps at its place in the dense array -- no search, no atomics
-        for (int c = tid; c < g.ncells; c += nt) {
-            const int tot = S.ccnt_next[c];
-            const uint32_t so = S.soff[c];
-            const int thr = (so >> 31) ? t_ini : 0;  // cornerScore = s - 1:  s > t  <=>  response >= t
-            const uint32_t *src = fslots + (so & 0x7FFFFFFFu);
-            int pos = S.ccnt[c];
-            // a cell is narrower than an initial node: its keys fall into one bin or two neighbours
-            int b0 = -1, n0 = 0, n1 = 0;
-            for (int j = 0; j < tot; j += QT_CELL_ILP) {
-                uint32_t key[QT_CELL_ILP];
-    #pragma unroll
-                for (int u = 0; u < QT_CELL_ILP; u++)
-                    key[u] = src[min(j + u, tot - 1)];
-    #pragma unroll
-                for (int u = 0; u < QT_CELL_ILP; u++) {
-                    if (j + u < tot && key_resp(key[u]) >= thr) {
-                        dkey[pos] = key[u];  // also what the debug API reads
-                        if (pos < kcap)
-                            lkey[pos] = key[u];
-                        pos++;
-                        int bin = (int)((float)key_x(key[u]) / hx);
-                        bin = min(max(bin, 0), n_ini - 1);
-                        b0 = b0 < 0 ? bin : b0;
-                        if (bin == b0)
-                            n0++;
-                        else if (bin == b0 + 1)
-                            n1++;
-                        else
-                            atomicAdd(&S.sb[bin], 1);
-                    }
-                }
-            }
-            if (n0)
-                atomicAdd(&S.sb[b0], n0);
-            if (n1)
-                atomicAdd(&S.sb[b0 + 1], n1);
-        }
-    } else {
-        // batches (eight workgroups per CU, throughput counts): one thread per stored key, coalesced; the owning cell
-        // is found by binary search in the scanned stored counts
-        const int nstored = block_excl_scan(S.ccnt_next, g.ncells, s_tmp);  // ccnt_next[c] = first stored key of cell c
-        const int search_steps = 32 - __clz(max(g.ncells - 1, 1));          // halvings that pin one of ncells cells down
-        for (int i0 = tid; i0 - tid < nstored; i0 += QT_ILP * nt) {        // (all lanes iterate: count_runs works wave-wide)
-            int lo[QT_ILP], hi[QT_ILP], idx[QT_ILP];
+    {
+        const int nst = s_nst;
+        const int lane = tid & 63;
+        for (int i0 = tid; i0 - tid < nst; i0 += QT_ILP * nt) {  // (all lanes iterate: ballots and count_runs work wave-wide)
+            uint32_t key[QT_ILP];
+#pragma unroll
+            for (int u = 0; u < QT_ILP; u++)
+                key[u] = lslots[min(i0 + u * nt, nst - 1)];
 #pragma unroll
             for (int u = 0; u < QT_ILP; u++) {
-                idx[u] = min(i0 + u * nt, nstored - 1);
-                lo[u] = 0;  // last cell with start <= idx
-                hi[u] = g.ncells - 1;
-            }
-            for (int it = 0; it < search_steps; it++) {
-#pragma unroll
-                for (int u = 0; u < QT_ILP; u++) {
-                    const int mid = (lo[u] + hi[u] + 1) >> 1;
-                    const bool open = lo[u] < hi[u];
-                    const bool right = S.ccnt_next[mid] <= idx[u];
-                    lo[u] = (open && right) ? mid : lo[u];
-                    hi[u] = (open && !right) ? mid - 1 : hi[u];
-                }
-            }
-            uint32_t so[QT_ILP], key[QT_ILP];
-#pragma unroll
-            for (int u = 0; u < QT_ILP; u++) {
-                so[u] = S.soff[lo[u]];
-                key[u] = fslots[(so[u] & 0x7FFFFFFFu) + (idx[u] - S.ccnt_next[lo[u]])];
-            }
-#pragma unroll
-            for (int u = 0; u < QT_ILP; u++) {
+                const uint32_t cj = __umulhi((uint32_t)max(key_x(key[u]) - 3, 0), g.inv_wcell);
+                const uint32_t ci = __umulhi((uint32_t)max(key_y(key[u]) - 3, 0), g.inv_hcell);
+                const int c = min((int)(ci * (uint32_t)g.ncols_eff + cj), g.ncells - 1);
                 // cornerScore = s - 1:  s > t  <=>  response >= t
-                const bool keep = i0 + u * nt < nstored && (!(so[u] >> 31) || key_resp(key[u]) >= t_ini);
-                if (keep)
-                    dkey[atomicAdd(&S.ccnt[lo[u]], 1)] = key[u];
+                const bool keep = i0 + u * nt < nst && (!S.soff[c] || key_resp(key[u]) >= t_ini);
+                const unsigned long long m = __ballot(keep);
+                int base = 0;
+                if (lane == 0 && m)
+                    base = atomicAdd(&s_nk, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (keep) {
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    dkey[pos] = key[u];  // also what the debug API reads
+                    if (LDS_KEYS && pos < kcap)
+                        lkey[pos] = key[u];
+                }
                 int bin = (int)((float)key_x(key[u]) / hx);
                 bin = min(max(bin, 0), n_ini - 1);
                 count_runs(S.sb, bin, keep);
@@ -1004,6 +990,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         }
     }
     __syncthreads();  // dkey written by this workgroup only; visible after the barrier (same CU)
+    const int nkeys = s_nk;
     if (tid == 0)
         ncand[(size_t)f * nlevels + level] = nkeys;
 
@@ -2049,6 +2036,14 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
             ORBGPU_REQUIRE(ncols_eff > 0 && g.ncells % ncols_eff == 0 && nbands <= g.ncells / ncols_eff && ncols_eff < 255 &&
                                g.ncells / ncols_eff < 256 && g.hcell < 128,
                            "unexpected cell grid at level %d", l);
+            geom[l].ncols_eff = ncols_eff;
+            for (int which = 0; which < 2; which++) {
+                const int d = which ? g.hcell : g.wcell;
+                const uint32_t m = (uint32_t)(((1ull << 32) + (uint64_t)d - 1u) / (uint64_t)d);
+                for (uint32_t v = 0; v < 8192u; v++)
+                    ORBGPU_REQUIRE((uint32_t)(((uint64_t)v * m) >> 32) == v / (uint32_t)d, "cell size %d at level %d has no exact reciprocal", d, l);
+                (which ? geom[l].inv_hcell : geom[l].inv_wcell) = m;
+            }
             dgm.first[l] = acc;
             dgm.nsx[l] = nsx;
             dgm.ncols[l] = ncols_eff;
@@ -2154,7 +2149,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_pyr, e->frame_pyr * B);
     RSV(e->d_blur, e->frame_pyr * B);
     RSV(e->d_slots, sizeof(uint32_t) * e->frame_slots * B);
-    RSV(e->d_cellcnt, sizeof(int) * cells.size() * B);
+    RSV(e->d_cellcnt, sizeof(int) * (cells.size() + ORBGPU_MAX_LEVELS) * B);  // per frame: cell counters, then one stored-key counter per level
     RSV(e->d_dkey, sizeof(uint32_t) * e->frame_slots * B);
     RSV(e->d_dnode, sizeof(uint16_t) * e->frame_slots * B);
     RSV(e->d_sel, sizeof(uint32_t) * (size_t)sel_off * B);
@@ -2194,7 +2189,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     // the blurred planes are only written inside the image; define the rest once
     ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
     // cell counters start at zero; k_quadtree re-arms them after reading
-    ORBGPU_HIP_TRY(hipMemset(e->d_cellcnt.p, 0, sizeof(int) * cells.size() * B));
+    ORBGPU_HIP_TRY(hipMemset(e->d_cellcnt.p, 0, sizeof(int) * (cells.size() + ORBGPU_MAX_LEVELS) * B));
     ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)qt_lds));
     ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree<true>),
