@@ -75,6 +75,23 @@ def test_non_default_parameters(gpu, oracle, stream640, nfeat, sf, nl, ini, mn):
     assert_same_keypoints(gk, gd, ok, od, "params %s" % ((nfeat, sf, nl, ini, mn),))
 
 
+@pytest.mark.parametrize("w,h,sf,nl,batch", [(176, 144, 1.1, 8, 1), (176, 144, 1.1, 8, 40), (220, 170, 1.15, 8, 3)])
+def test_small_image_many_levels(gpu, oracle, w, h, sf, nl, batch):
+    """Small frames with many levels: the top levels are a handful of work items each, so one wave of k_fast_detect spans
+    three or four levels and reserves a range in each level's key array (both quadtree variants: batch 40 and single)."""
+    from orb_slam2_map_amd.synth import Stream
+    st = Stream(w, h, 77)
+    imgs = np.stack([st.frame(t)[0] for t in range(batch)])
+    ge = gpu.ORBextractor(400, sf, nl, 20, 7, max_batch=batch)
+    oe = oracle.Extractor(400, sf, nl, 20, 7)
+    gk, gd = ge.extract_batch(imgs)
+    for f in (0, batch - 1):
+        ok, od = oe.extract(imgs[f])
+        if f == batch - 1:
+            check_stages(gpu, ge, oe, f, nl, "small %dx%d frame %d" % (w, h, f))
+        assert_same_keypoints(gk[f], gd[f], ok, od, "small %dx%d frame %d" % (w, h, f))
+
+
 def test_reconfigure_between_sizes(gpu, oracle):
     """One handle, images of different sizes in sequence (the geometry tables are rebuilt)."""
     from orb_slam2_map_amd.synth import Stream
