@@ -794,6 +794,45 @@ __device__ __forceinline__ int quadrant_at(uint32_t key, uint32_t split)
 constexpr int QT_THREADS = 1024, QT_THREADS_SMALL = 512, QT_THREADS_BATCH = 256, QT_BATCH_MIN = 32;
 constexpr int QT_LARGE_PIXELS = 700000;  // single frames from about 1024x768 use QT_THREADS (measured: 137 -> 128 us at 1280x960, 51 -> 54 us at 640x480)
 
+// Node lists up to this length are processed by one wave (k_quadtree, sections (2)..(6))
+constexpr int QT_SOLO_MAX = 128;
+
+// LDS traffic of one wave is ordered; this keeps the compiler from moving accesses across the point and drains the queue
+__device__ __forceinline__ void qt_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// In-place exclusive scan of an LDS int array by ONE wave (all 64 lanes call); returns the total.
+__device__ int wave_excl_scan(int *a, int n)
+{
+    const int lane = threadIdx.x & 63;
+    const int ipt = (n + 63) / 64;
+    const int beg = min(lane * ipt, n), end = min(beg + ipt, n);
+    int sum = 0;
+    for (int i = beg; i < end; i++)
+        sum += a[i];
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off, 64);
+        if (lane >= off)
+            inc += t;
+    }
+    const int total = __shfl(inc, 63, 64);
+    int run = inc - sum;
+    qt_wave_sync();  // every lane has read its items before any lane overwrites
+    for (int i = beg; i < end; i++) {
+        int t = a[i];
+        a[i] = run;
+        run += t;
+    }
+    qt_wave_sync();
+    return total;
+}
+
 // In-place exclusive scan of an LDS int array by the whole workgroup; returns the total.
 __device__ int block_excl_scan(int *a, int n, int *s_tmp /*>= 16 ints*/)
 {
@@ -1057,144 +1096,158 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         // (1) S.ccnt already holds the child key counts of every node with >1 keys: they are
         //     accumulated by the key loop of the previous pass (or of the initial assignment)
 
-        QT_MARK(10)
-        // (2) processing order of the expandable nodes
-        for (int p = tid; p < n; p += nt)
-            S.sa[p] = cntA[p] > 1 ? 1 : 0;
-        __syncthreads();
-        const int nv = block_excl_scan(S.sa, n, s_tmp);  // sa[p] = rank among expandable (list order)
-        if (phase == 1) {
-            for (int p = tid; p < n; p += nt)
-                if (cntA[p] > 1)
-                    S.order[S.sa[p]] = (uint16_t)p;
-        } else {
-            // sort by (cnt, creation) descending: rank by counting (keys are unique).  The sort keys of the expandable
-            // nodes are first laid out densely (S.sa is free between the scan above and section (4)) and padded with
-            // zeros to a multiple of 4, so that the counting loop reads them four at a time
-            uint32_t *skey = reinterpret_cast<uint32_t *>(S.sa);
-            for (int p = tid; p < n; p += nt)
-                if (cntA[p] > 1)
-                    S.opos[S.sa[p]] = (uint16_t)p;  // opos as temporary list of expandable nodes
-            __syncthreads();  // (also: every S.sa[p] has been read before the array is reused)
-            const int nv4 = (nv + 3) & ~3;
-            for (int a = tid; a < nv4; a += nt) {
-                const int p = S.opos[min(a, nv - 1)];
-                skey[a] = a < nv ? (((uint32_t)cntA[p] << 16) | creA[p]) : 0u;
-            }
-            __syncthreads();
-            for (int a = tid; a < nv; a += nt) {
-                const uint32_t ka = skey[a];
-                int rank = 0;
-                for (int b = 0; b < nv4; b += 4) {
-                    const uint4 kb = *reinterpret_cast<const uint4 *>(&skey[b]);
-                    rank += (kb.x > ka) + (kb.y > ka) + (kb.z > ka) + (kb.w > ka);
+        // Sections (2)..(6) work on the node list (n <= N entries), not on the keys.  While the list is short one wave does
+        // them alone, with wave-level synchronisation and scans -- the other waves of the workgroup would only walk
+        // through the barriers and the scans' bookkeeping (which was over a third of this kernel's instructions); a long
+        // list is shared by the whole workgroup as before.
+        auto node_sections = [&](const int tid_, const int nt_, auto &&SYNC, auto &&SCAN) {
+            QT_MARK(10)
+            // (2) processing order of the expandable nodes
+            for (int p = tid_; p < n; p += nt_)
+                S.sa[p] = cntA[p] > 1 ? 1 : 0;
+            SYNC();
+            const int nv = SCAN(S.sa, n);  // sa[p] = rank among expandable (list order)
+            if (phase == 1) {
+                for (int p = tid_; p < n; p += nt_)
+                    if (cntA[p] > 1)
+                        S.order[S.sa[p]] = (uint16_t)p;
+            } else {
+                // sort by (cnt, creation) descending: rank by counting (keys are unique).  The sort keys of the expandable
+                // nodes are first laid out densely (S.sa is free between the scan above and section (4)) and padded with
+                // zeros to a multiple of 4, so that the counting loop reads them four at a time
+                uint32_t *skey = reinterpret_cast<uint32_t *>(S.sa);
+                for (int p = tid_; p < n; p += nt_)
+                    if (cntA[p] > 1)
+                        S.opos[S.sa[p]] = (uint16_t)p;  // opos as temporary list of expandable nodes
+                SYNC();  // (also: every S.sa[p] has been read before the array is reused)
+                const int nv4 = (nv + 3) & ~3;
+                for (int a = tid_; a < nv4; a += nt_) {
+                    const int p = S.opos[min(a, nv - 1)];
+                    skey[a] = a < nv ? (((uint32_t)cntA[p] << 16) | creA[p]) : 0u;
                 }
-                S.order[rank] = S.opos[a];
+                SYNC();
+                for (int a = tid_; a < nv; a += nt_) {
+                    const uint32_t ka = skey[a];
+                    int rank = 0;
+                    for (int b = 0; b < nv4; b += 4) {
+                        const uint4 kb = *reinterpret_cast<const uint4 *>(&skey[b]);
+                        rank += (kb.x > ka) + (kb.y > ka) + (kb.z > ka) + (kb.w > ka);
+                    }
+                    S.order[rank] = S.opos[a];
+                }
             }
-        }
-        __syncthreads();
+            SYNC();
 
-        QT_MARK(11)
-        // (3) children per expandable node in processing order; find the cut for phase 2
-        for (int j = tid; j < nv; j += nt) {
-            const int p = S.order[j];
-            const int *cc = &S.ccnt[p * 4];
-            S.sb[j] = (cc[0] > 0) + (cc[1] > 0) + (cc[2] > 0) + (cc[3] > 0);
-        }
-        if (tid == 0)
-            s_cut = nv;  // number of nodes to expand
-        __syncthreads();
-        const int call = block_excl_scan(S.sb, nv, s_tmp);  // sb[j] = creation index of first child
-        if (phase == 2) {
-            // list size after expanding j+1 nodes = n + (children so far) - (j+1) >= N ?  (:730-731)
-            for (int j = tid; j < nv; j += nt) {
-                const int kids_incl = (j + 1 < nv) ? S.sb[j + 1] : call;
-                if (n + kids_incl - (j + 1) >= N)
-                    atomicMin(&s_cut, j + 1);
+            QT_MARK(11)
+            // (3) children per expandable node in processing order; find the cut for phase 2
+            for (int j = tid_; j < nv; j += nt_) {
+                const int p = S.order[j];
+                const int *cc = &S.ccnt[p * 4];
+                S.sb[j] = (cc[0] > 0) + (cc[1] > 0) + (cc[2] > 0) + (cc[3] > 0);
             }
-            __syncthreads();
-        }
-        const int nE = s_cut;
-        const int C = (nE < nv) ? S.sb[nE] : call;  // children created in this pass
+            if (tid_ == 0)
+                s_cut = nv;  // number of nodes to expand
+            SYNC();
+            const int call = SCAN(S.sb, nv);  // sb[j] = creation index of first child
+            if (phase == 2) {
+                // list size after expanding j+1 nodes = n + (children so far) - (j+1) >= N ?  (:730-731)
+                for (int j = tid_; j < nv; j += nt_) {
+                    const int kids_incl = (j + 1 < nv) ? S.sb[j + 1] : call;
+                    if (n + kids_incl - (j + 1) >= N)
+                        atomicMin(&s_cut, j + 1);
+                }
+                SYNC();
+            }
+            const int nE = s_cut;
+            const int C = (nE < nv) ? S.sb[nE] : call;  // children created in this pass
 
-        QT_MARK(12)
-        // (4) untouched nodes keep their order behind the children
-        for (int p = tid; p < n; p += nt)
-            S.inE[p] = 0;
+            QT_MARK(12)
+            // (4) untouched nodes keep their order behind the children
+            for (int p = tid_; p < n; p += nt_)
+                S.inE[p] = 0;
+            SYNC();
+            for (int j = tid_; j < nE; j += nt_)
+                S.inE[S.order[j]] = 1;
+            SYNC();
+            for (int p = tid_; p < n; p += nt_)
+                S.sa[p] = S.inE[p] ? 0 : 1;
+            SYNC();
+            const int nkept = SCAN(S.sa, n);
+            const int n2 = C + nkept;
+            if (n2 > ncap) {  // cannot happen for validated geometry; fail safe
+                if (tid_ == 0)
+                    s_done = 2;
+                return;
+            }
+            if (tid_ == 0)
+                s_nexp = 0;
+            SYNC();
+
+            QT_MARK(13)
+            // (5) build the new list
+            for (int p = tid_; p < n; p += nt_) {
+                if (!S.inE[p]) {
+                    const int pos = C + S.sa[p];
+                    bndB[pos] = bndA[p];
+                    midB[pos] = midA[p];
+                    cntB[pos] = cntA[p];
+                    creB[pos] = creA[p];
+                    S.opos[p] = (uint16_t)pos;
+                }
+            }
+            int my_exp = 0;
+            for (int j = tid_; j < nE; j += nt_) {
+                const int p = S.order[j];
+                const short4 b = bndA[p];
+                const int halfx = (int)ceilf((float)(b.z - b.x) / 2);
+                const int halfy = (int)ceilf((float)(b.w - b.y) / 2);
+                const short mx = (short)(b.x + halfx), my = (short)(b.y + halfy);
+                int k = S.sb[j];
+    #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int c = S.ccnt[p * 4 + q];
+                    if (c == 0)
+                        continue;
+                    const int pos = C - 1 - k;
+                    short4 cb;
+                    cb.x = (q & 1) ? mx : b.x;
+                    cb.z = (q & 1) ? b.z : mx;
+                    cb.y = (q & 2) ? my : b.y;
+                    cb.w = (q & 2) ? b.w : my;
+                    bndB[pos] = cb;
+                    midB[pos] = split_of(cb);
+                    cntB[pos] = c;
+                    creB[pos] = (uint16_t)k;
+                    S.cpos[p * 4 + q] = (uint16_t)pos;
+                    my_exp += c > 1;
+                    k++;
+                }
+            }
+            if (my_exp)
+                atomicAdd(&s_nexp, my_exp);
+            SYNC();
+
+            QT_MARK(14)
+            // (6) termination / phase switch (:669-673, :733-734), decided before the key loop so that a
+            //     final pass does not count children
+            if (tid_ == 0) {
+                s_n = n2;
+                if (n2 >= N || n2 == n)
+                    s_done = 1;
+                else if (phase == 1 && n2 + 3 * s_nexp > N)
+                    s_phase = 2;
+            }
+            SYNC();
+        };
+        if (n <= QT_SOLO_MAX) {
+            if ((tid >> 6) == 0)
+                node_sections(tid & 63, 64, [] { qt_wave_sync(); }, [](int *arr, int cnt) { return wave_excl_scan(arr, cnt); });
+        } else
+            node_sections(tid, nt, [] { __syncthreads(); }, [&](int *arr, int cnt) { return block_excl_scan(arr, cnt, s_tmp); });
         __syncthreads();
-        for (int j = tid; j < nE; j += nt)
-            S.inE[S.order[j]] = 1;
-        __syncthreads();
-        for (int p = tid; p < n; p += nt)
-            S.sa[p] = S.inE[p] ? 0 : 1;
-        __syncthreads();
-        const int nkept = block_excl_scan(S.sa, n, s_tmp);
-        const int n2 = C + nkept;
-        if (n2 > ncap) {  // cannot happen for validated geometry; fail safe
-            if (tid == 0)
-                s_done = 2;
-            __syncthreads();
+        if (s_done == 2)
             break;
-        }
-        if (tid == 0)
-            s_nexp = 0;
-        __syncthreads();
-
-        QT_MARK(13)
-        // (5) build the new list
-        for (int p = tid; p < n; p += nt) {
-            if (!S.inE[p]) {
-                const int pos = C + S.sa[p];
-                bndB[pos] = bndA[p];
-                midB[pos] = midA[p];
-                cntB[pos] = cntA[p];
-                creB[pos] = creA[p];
-                S.opos[p] = (uint16_t)pos;
-            }
-        }
-        int my_exp = 0;
-        for (int j = tid; j < nE; j += nt) {
-            const int p = S.order[j];
-            const short4 b = bndA[p];
-            const int halfx = (int)ceilf((float)(b.z - b.x) / 2);
-            const int halfy = (int)ceilf((float)(b.w - b.y) / 2);
-            const short mx = (short)(b.x + halfx), my = (short)(b.y + halfy);
-            int k = S.sb[j];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int c = S.ccnt[p * 4 + q];
-                if (c == 0)
-                    continue;
-                const int pos = C - 1 - k;
-                short4 cb;
-                cb.x = (q & 1) ? mx : b.x;
-                cb.z = (q & 1) ? b.z : mx;
-                cb.y = (q & 2) ? my : b.y;
-                cb.w = (q & 2) ? b.w : my;
-                bndB[pos] = cb;
-                midB[pos] = split_of(cb);
-                cntB[pos] = c;
-                creB[pos] = (uint16_t)k;
-                S.cpos[p * 4 + q] = (uint16_t)pos;
-                my_exp += c > 1;
-                k++;
-            }
-        }
-        if (my_exp)
-            atomicAdd(&s_nexp, my_exp);
-        __syncthreads();
-
-        QT_MARK(14)
-        // (6) termination / phase switch (:669-673, :733-734), decided before the key loop so that a
-        //     final pass does not count children
-        if (tid == 0) {
-            s_n = n2;
-            if (n2 >= N || n2 == n)
-                s_done = 1;
-            else if (phase == 1 && n2 + 3 * s_nexp > N)
-                s_phase = 2;
-        }
-        for (int i = tid; i < n2 * 4; i += nt)
+        for (int i = tid; i < s_n * 4; i += nt)
             S.ccnt_next[i] = 0;
         __syncthreads();
         const bool count_next = s_done == 0;
