@@ -331,7 +331,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            D.barrier(world)
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -356,7 +356,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        dist.barrier()
+        D.barrier(world)
     torch.cuda.synchronize()
     # per stage: the launches that cover the B frames of a step (one per part; with parts > 1 they run next to other
     # parts' kernels, so their sum is not a duration of the step)

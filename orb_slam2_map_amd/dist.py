@@ -34,7 +34,11 @@ def init(backend, rank, world):
 def barrier(world):
     import torch.distributed as dist
     if world > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":  # RCCL: name the rank's own device instead of letting the backend guess one
+            import torch
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def aggregate(elapsed_s, frames, world, device="cpu"):
