@@ -194,6 +194,9 @@ def main():
     ap.add_argument("--no-overlap-match", dest="overlap_match", action="store_false",
                     help="serialise the matcher behind the extraction (default: the matcher of step i runs on a "
                          "second stream next to the extraction of step i+1)")
+    ap.add_argument("--force-group", action="store_true",
+                    help="build the process group for a single rank too: barrier and reductions then run through the "
+                         "backend (RCCL) exactly as on the multi-GPU node -- what a one-GPU box can execute of that path")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -223,7 +226,8 @@ def main():
     if args.rehearse_on_device0:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    D.init(args.backend, rank, world)  # RCCL; carries the barrier and two scalar reductions only
+    # RCCL; carries the barrier and two scalar reductions only (--force-group: through the backend even for one rank)
+    D.init(args.backend, rank, world, force_group=args.force_group)
 
     W, H, NFEAT = 640, 480, 1000
     B, POOL = args.batch, max(args.pool, args.batch)

@@ -139,6 +139,12 @@ int orbgpu_extractor_debug_read(orbgpu_extractor *h, int32_t what, int32_t frame
 /* The host entry points (orbgpu_extract, orbgpu_extract_batch) replay their launch sequence as a hipGraph from the
  * third call of a configuration on: *state = 1 graph in use, 0 not captured yet, -1 capture failed (plain launches). */
 int orbgpu_extractor_graph_state(const orbgpu_extractor *h, int32_t *state);
+/* How DistributeOctTree (ORBextractor.cc:539-763) is launched for a call of `batch` frames at the configured image size:
+ * keys of a level the workgroup keeps in LDS (0 = the batch variant, all keys in memory), threads per workgroup and the
+ * dynamic LDS bytes.  Test aid: the environment hook ORBGPU_DEBUG_QT_KEYS (read by orbgpu_extractor_create) shrinks
+ * the LDS share so that the mixed LDS / memory path runs; this getter tells a test that it really did. */
+int orbgpu_extractor_debug_quadtree_config(const orbgpu_extractor *h, int32_t batch, int32_t *lds_keys, int32_t *threads,
+                                           int32_t *lds_bytes);
 int orbgpu_extractor_set_profiling(orbgpu_extractor *h, int32_t enable);
 /* Pipelining aid for callers that run other work next to an extraction (bench.py starts the matcher of the previous
  * batch there): `hip_event` (a hipEvent_t, or NULL to clear) is recorded on the launch stream of every later

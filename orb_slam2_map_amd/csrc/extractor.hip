@@ -796,6 +796,7 @@ constexpr int QT_LARGE_PIXELS = 700000;  // single frames from about 1024x768 us
 
 // Node lists up to this length are processed by one wave (k_quadtree, sections (2)..(6))
 constexpr int QT_SOLO_MAX = 128;
+constexpr int QT_LDS_MAX = 160 * 1024 - 1024;  // dynamic LDS k_quadtree may be launched with (the CU has 160 KB)
 
 // LDS traffic of one wave is ordered; this keeps the compiler from moving accesses across the point and drains the queue
 __device__ __forceinline__ void qt_wave_sync()
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         S.soff[c] = (cnt >> 16) ? 1u : 0u;     // the cell has corners above iniThFAST: only those count
     }
     if (tid == 0) {
-        s_nst = *lcount;
+        s_nst = min(*lcount, g.slot_cnt);  // (never more than the level's array holds: k_fast_detect's bound; a clamp, not a trust)
         *lcount = 0;
         s_nk = 0;
     }
@@ -1054,6 +1055,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         s_done = 0;
     }
     __syncthreads();
+    // Loop control lives in registers.  s_n / s_phase / s_done are only written by section (6) of a pass, which one wave
+    // may run on its own (QT_SOLO_MAX) while the others wait at the barrier behind the sections: a wave must therefore
+    // never read them between the barrier that ends a pass and the barrier behind the next pass's sections.  They are
+    // read here (the next write is two barriers away) and after the barrier behind the sections of every pass.
+    int n_cur = s_n, phase_cur = s_phase, done_cur = s_done;
     for (int i = tid; i < 4 * n_ini; i += nt)
         S.ccnt_next[i] = 0;
     __syncthreads();
@@ -1089,9 +1095,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     QT_MARK(2)
     // ---- passes
     for (int iter = 0; iter < 64; iter++) {
-        const int n = s_n;
-        const int phase = s_phase;
-        if (s_done || n == 0)
+        const int n = n_cur;
+        const int phase = phase_cur;
+        if (done_cur || n == 0)
             break;
         // (1) S.ccnt already holds the child key counts of every node with >1 keys: they are
         //     accumulated by the key loop of the previous pass (or of the initial assignment)
@@ -1245,12 +1251,16 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         } else
             node_sections(tid, nt, [] { __syncthreads(); }, [&](int *arr, int cnt) { return block_excl_scan(arr, cnt, s_tmp); });
         __syncthreads();
-        if (s_done == 2)
+        // the list of the next pass: written by section (6) above, not written again before the next pass's sections
+        done_cur = s_done;
+        if (done_cur == 2)
             break;
-        for (int i = tid; i < s_n * 4; i += nt)
+        n_cur = s_n;
+        phase_cur = s_phase;
+        for (int i = tid; i < n_cur * 4; i += nt)
             S.ccnt_next[i] = 0;
         __syncthreads();
-        const bool count_next = s_done == 0;
+        const bool count_next = done_cur == 0;
 
         QT_MARK(15)
         // (7) re-label the keys and, in the same sweep, count the children of the NEW list's nodes
@@ -1295,7 +1305,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     //      (:789-829), inside a cell cv::FAST's row-major output -- i.e. ascending (cell row, cell column, y, x), all of
     //      which the key holds.  One 64-bit maximum per node: response + 1 (bits 40..), then the inverted order (cell
     //      row 32..39, cell column 24..31, y 12..23, x 0..11), which is also enough to rebuild the winning key.
-    const int n = s_n;
+    const int n = n_cur;
     unsigned long long *best = reinterpret_cast<unsigned long long *>(S.ccnt);  // [ncap*4] ints >= n 64-bit words
     for (int p = tid; p < n; p += nt)
         best[p] = 0ull;
@@ -1326,7 +1336,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     }
     __syncthreads();
     uint32_t *osel = sel + (size_t)f * sel_cap_total + g.sel_off;
-    const bool ok = s_done != 2 && n <= g.sel_cap;
+    const bool ok = done_cur != 2 && n <= g.sel_cap;
     for (int p = tid; p < n && ok; p += nt) {
         const unsigned long long b = best[p];
         const uint32_t yx = (uint32_t)((0xFFFFFFFFFFull - (b & 0xFFFFFFFFFFull)) & 0xFFFFFFull);
@@ -1831,6 +1841,7 @@ struct orbgpu_extractor {
     hipEvent_t pipe_signal[8] = {};  // the same for an orbgpu_pipeline that owns this handle (stagger of its parts)
     bool counters_dirty = false;  // the cell counters may hold counts no k_quadtree has consumed
     bool force_batch_quadtree = false;  // ORBGPU_DEBUG_QT_BATCH: the batch variant of k_quadtree for any batch size (tests)
+    int qt_keys_hook = -1;  // ORBGPU_DEBUG_QT_KEYS (read at creation): LDS key share of k_quadtree<true>; -1 = as many as fit
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
 
@@ -2046,10 +2057,10 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     for (int l = 0; l < nl; l++)
         max_slots_level = std::max(max_slots_level, geom[l].slot_cnt);
     int qt_kcap = max_slots_level;
-    if (const char *q = getenv("ORBGPU_DEBUG_QT_KEYS"))  // test hook: forces the mixed LDS / memory path
-        qt_kcap = std::max(atoi(q), 0);
+    if (e->qt_keys_hook >= 0)  // test hook: forces the mixed LDS / memory path
+        qt_kcap = e->qt_keys_hook;
     qt_kcap = (int)std::min<size_t>((size_t)(qt_kcap + 7) / 8 * 8, qt_lds < 150 * 1024 ? (150 * 1024 - qt_lds) / 6 / 8 * 8 : 0);
-    ORBGPU_REQUIRE(qt_lds <= 160 * 1024 - 1024, "nfeatures too large for the quadtree kernel (needs %zu B of LDS)", qt_lds);
+    ORBGPU_REQUIRE(qt_lds <= (size_t)QT_LDS_MAX, "nfeatures too large for the quadtree kernel (needs %zu B of LDS)", qt_lds);
     ORBGPU_REQUIRE((size_t)slot_off < (1u << 23), "too many FAST key slots per frame");
 
     e->geom = geom;
@@ -2243,10 +2254,13 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
     // cell counters start at zero; k_quadtree re-arms them after reading
     ORBGPU_HIP_TRY(hipMemset(e->d_cellcnt.p, 0, sizeof(int) * (cells.size() + ORBGPU_MAX_LEVELS) * B));
+    // The attribute belongs to the function (per device), not to this handle: another handle with a larger geometry may
+    // have raised it and still launch, so it is set once to the most the kernel can ever be launched with here
+    // (qt_lds <= 159 KB and qt_lds + 6 qt_kcap <= 150 KB are enforced above; the static part is < 200 B).
     ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)qt_lds));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, QT_LDS_MAX));
     ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_quadtree<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(qt_lds + (size_t)qt_kcap * 6)));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, QT_LDS_MAX));
     e->cfg_w = w;
     e->cfg_h = h;
     e->cfg_batch = batch;
@@ -2398,6 +2412,8 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
     if (e->prm.max_batch < 1)
         e->prm.max_batch = 1;
     e->force_batch_quadtree = getenv("ORBGPU_DEBUG_QT_BATCH") != nullptr;
+    if (const char *q = getenv("ORBGPU_DEBUG_QT_KEYS"))  // test hook, read here like the others (configure() runs at the first extraction)
+        e->qt_keys_hook = std::max(atoi(q), 0);
     if (const char *q = getenv("ORBGPU_DEBUG_FAST_QUEUE"))  // test hook: forces k_fast_detect's queue-full path
         e->fast_queue_cap = std::min(std::max(atoi(q), 0), FD_QCAP);
     e->nlevels = p->nlevels;
@@ -2856,6 +2872,17 @@ int orbgpu_extractor_graph_state(const orbgpu_extractor *e, int32_t *state)
 {
     ORBGPU_REQUIRE(e && state, "null argument");
     *state = e->graph_state;
+    return ORBGPU_OK;
+}
+int orbgpu_extractor_debug_quadtree_config(const orbgpu_extractor *e, int32_t batch, int32_t *lds_keys, int32_t *threads,
+                                           int32_t *lds_bytes)
+{
+    ORBGPU_REQUIRE(e && lds_keys && threads && lds_bytes, "null argument");
+    ORBGPU_REQUIRE(e->cfg_w > 0, "no image size configured yet (call an extraction first)");
+    const bool batch_variant = batch >= QT_BATCH_MIN || e->force_batch_quadtree;
+    *lds_keys = batch_variant ? 0 : e->qt_kcap;
+    *threads = batch_variant ? QT_THREADS_BATCH : (e->cfg_w * e->cfg_h >= QT_LARGE_PIXELS ? QT_THREADS : QT_THREADS_SMALL);
+    *lds_bytes = (int32_t)(e->qt_lds + (batch_variant ? 0 : (size_t)e->qt_kcap * 6));
     return ORBGPU_OK;
 }
 int orbgpu_extractor_stage_count(void) { return ST_COUNT; }

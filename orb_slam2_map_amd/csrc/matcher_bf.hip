@@ -14,6 +14,7 @@
 // those cached lists and fall back to an exact full scan of a row when its list cannot decide.
 #include "common.h"
 #include "matcher_common.h"
+#include "workspace.h"
 
 #include <algorithm>
 #include <climits>
@@ -753,10 +754,10 @@ static int match_host(const uint8_t *desc_a, const float *angle_a, const uint8_t
         hipStream_t st = nullptr;
         DevBuf da, db, aa, ab, va, cnt, mb, nm, nda, ndb;
     };
-    static thread_local Ws ws;
     int rc = select_device(device_id);
     if (rc != ORBGPU_OK)
         return rc;
+    Ws &ws = per_device_workspace<Ws>(device_id);  // stream, matcher handle and buffers of THIS device
     const int need = std::max(na, nb);
     if (ws.device != device_id || ws.cap < need) {
         if (ws.m)

@@ -15,6 +15,7 @@
 // only a row whose 16 cached candidates cannot decide is walked again with the claim filter.
 #include "common.h"
 #include "matcher_common.h"
+#include "workspace.h"
 
 #include <algorithm>
 #include <climits>
@@ -613,6 +614,7 @@ static inline size_t resolve_lds(int /*m*/, int ncap, int *novf)
 struct ProjWorkspace {
     int device = -1;
     hipStream_t stream = nullptr;
+    unsigned attr_set = 0;  // bit per call site: the dynamic-LDS limit of its kernels has been raised ON THIS DEVICE
     DevBuf kp_x, kp_y, kp_octave, u_right, desc, cell_start, cell_items, kp_angle;
     DevBuf queries, row_desc, row_angle, claim_init, topk, match, slow, k2m, out, inv_sigma2, tri, problems, sweeps;
     ~ProjWorkspace()
@@ -623,9 +625,8 @@ struct ProjWorkspace {
 
 static int workspace(int device_id, ProjWorkspace **out)
 {
-    static thread_local ProjWorkspace ws;
-    if (ws.device != device_id) {
-        ws = ProjWorkspace();
+    ProjWorkspace &ws = per_device_workspace<ProjWorkspace>(device_id);  // (the caller has selected device_id)
+    if (ws.device != device_id) {  // first use of this device by this thread
         ws.device = device_id;
         hipError_t e = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
@@ -730,13 +731,12 @@ static int run_projection(ProjWorkspace &ws, const FrameDev &F, const std::vecto
         PJ_TRY(put(ws.row_angle, row_angle_host, sizeof(float) * m, st));
         PJ_TRY(put(ws.kp_angle, kp_angle_host, sizeof(float) * n, st));
     }
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    if (!(ws.attr_set & 1u)) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
-        attr_set = true;
+        ws.attr_set |= 1u;
     }
     hipLaunchKernelGGL(k_proj_lists, dim3((m + PJ_ROWS_PER_BLOCK - 1) / PJ_ROWS_PER_BLOCK), dim3(256), 0, st, m, ws.queries.as<Query>(),
                        ws.row_desc.as<uint8_t>(), F, ws.topk.as<uint32_t>());
@@ -1327,11 +1327,10 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     F.cell_start = f->cell_start;
     F.cell_items = f->cell_items;
     F.inv_sigma2 = nullptr;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    if (!(ws->attr_set & 2u)) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
-        attr_set = true;
+        ws->attr_set |= 2u;
     }
     orbgpu_track_scratch none{};
     const int cover = std::max(m, cap);
@@ -1413,11 +1412,10 @@ int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur,
     F.cell_start = cur->cell_start;
     F.cell_items = cur->cell_items;
     F.inv_sigma2 = nullptr;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    if (!(ws->attr_set & 4u)) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve<1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
-        attr_set = true;
+        ws->attr_set |= 4u;
     }
     const int cover = std::max(m, cap);
     const int kstride = (int)(sizeof(orbgpu_keypoint) / sizeof(float));
@@ -1527,11 +1525,10 @@ int orbgpu_search_local_points_batch_device(int32_t n, const orbgpu_local_points
         oc += (size_t)f->cap;
     }
     ORBGPU_HIP_TRY(hipMemcpyAsync(ws->problems.p, hp.data(), sizeof(ProjProblem) * (size_t)n, hipMemcpyHostToDevice, st));
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    if (!(ws->attr_set & 8u)) {
         ORBGPU_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_proj_resolve_batch),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)PJ_RESOLVE_MAX_LDS + 64));
-        attr_set = true;
+        ws->attr_set |= 8u;
     }
     const ProjProblem *dp = ws->problems.as<ProjProblem>();
     hipLaunchKernelGGL(k_batch_zero_counts, dim3((n + 255) / 256), dim3(256), 0, st, dp, n);

@@ -82,3 +82,54 @@ def test_bench_two_ranks_on_one_gpu():
     frames = out["value"] * out["ms_per_step"] * 1e-3 * out["steps"]
     assert abs(frames - 2 * 2 * 32) < 1e-6 * frames + 1e-3  # frames summed over both ranks
     assert "cpu_baseline" not in out
+
+
+def _single_rank(backend, device, port):
+    """Body of the one-rank tests; runs in a child process so that the process group never leaks into pytest."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = '%d'\n"
+        "import torch\n"
+        "import torch.distributed as dist\n"
+        "from orb_slam2_map_amd import dist as D\n"
+        "if %r == 'cuda': torch.cuda.set_device(0)\n"
+        "D.init(%r, 0, 1, force_group=True)\n"
+        "assert dist.is_initialized() and dist.get_backend() == %r and dist.get_world_size() == 1\n"
+        "D.barrier(1)\n"
+        "t, n = D.aggregate(1.25, 640, 1, device=%r)\n"
+        "assert (t, n) == (1.25, 640.0), (t, n)\n"
+        "D.barrier(1)\n"
+        "D.finalize(1)\n"
+        "assert not dist.is_initialized()\n"
+        "print('single-rank %s ok')\n" % (root, port, device, backend, backend, device, backend))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "single-rank %s ok" % backend in r.stdout, r.stdout[-3000:]
+
+
+def test_forced_single_rank_group_gloo():
+    """force_group: init / barrier / all-reduce / finalize go through the backend for one rank as well."""
+    _single_rank("gloo", "cpu", 29900 + os.getpid() % 90)
+
+
+@pytest.mark.gpu
+def test_rccl_single_rank_on_gpu():
+    """The RCCL branches of dist.py (communicator bound to the rank's device, barrier with device_ids, all-reduce of
+    CUDA tensors) executed on hardware: a one-rank communicator is what a one-GPU box can run of them."""
+    _single_rank("nccl", "cuda", 29800 + os.getpid() % 90)
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_through_rccl():
+    """bench.py itself with its barrier / reductions going through RCCL (world 1, --force-group)."""
+    import json
+    r = _run_bench(["--backend", "nccl", "--force-group", "--steps", "2", "--warmup", "1", "--batch", "32", "--pool", "64",
+                    "--no-cpu-baseline", "--no-secondary"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["value"] > 0

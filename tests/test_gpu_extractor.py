@@ -329,19 +329,45 @@ def test_host_entry_replays_a_graph(gpu, oracle, stream640):
     assert k.tobytes() == ok.tobytes()
 
 
-@pytest.mark.parametrize("kcap", [0, 1000])
-def test_quadtree_keys_beyond_lds(gpu, oracle, stream640, kcap, monkeypatch):
-    """Single frames: k_quadtree keeps the first keys of a level in LDS and the rest in memory; the test hook shrinks
-    the LDS share so that both kinds of key take part in every sweep."""
-    monkeypatch.setenv("ORBGPU_DEBUG_QT_KEYS", str(kcap))
-    ge = gpu.ORBextractor(1000)
-    monkeypatch.delenv("ORBGPU_DEBUG_QT_KEYS")
-    oe = oracle.Extractor(1000)
-    img = stream640.frame(2)[0]
-    gk, gd = ge(img)
+@pytest.mark.parametrize("w,h,nfeat", [(640, 480, 1000), (1280, 960, 2000)])
+@pytest.mark.parametrize("kcap", [0, 8, 512, "last"])
+def test_quadtree_keys_beyond_lds(gpu, oracle, w, h, nfeat, kcap, monkeypatch):
+    """Single frames: k_quadtree keeps the first keys of a level in LDS and the rest in memory; the test hook
+    (ORBGPU_DEBUG_QT_KEYS, read by orbgpu_extractor_create) shrinks the LDS share so that both kinds of key take part
+    in every sweep.  kcap 512 at 1280x960 / 2000 features are the parameters of the run that faulted in round 2's
+    scratch (gpurun_out/qts_512.log); "last" puts the boundary one key before the end of level 0."""
+    from orb_slam2_map_amd.synth import Stream
+    img = Stream(w, h, 1234).frame(2)[0]
+    oe = oracle.Extractor(nfeat)
     ok, od = oe.extract(img)
-    check_stages(gpu, ge, oe, 0, 8, "qt keys %d" % kcap)
-    assert_same_keypoints(gk, gd, ok, od, "qt keys %d" % kcap)
+    if kcap == "last":
+        kcap = max(len(oe.level_candidates(0)) - 1, 1)
+    monkeypatch.setenv("ORBGPU_DEBUG_QT_KEYS", str(kcap))
+    ge = gpu.ORBextractor(nfeat)
+    monkeypatch.delenv("ORBGPU_DEBUG_QT_KEYS")
+    for rep in range(3):  # plain launches, graph capture, graph replay
+        gk, gd = ge(img)
+        lds_keys, threads, lds_bytes = ge.quadtree_config(1)
+        assert lds_keys == (kcap + 7) // 8 * 8, "the hook did not take: %d keys in LDS, asked for %d" % (lds_keys, kcap)
+        assert threads == (1024 if w * h >= 700000 else 512) and lds_bytes <= 159 * 1024
+        check_stages(gpu, ge, oe, 0, 8, "%dx%d qt keys %d rep %d" % (w, h, kcap, rep))
+        assert_same_keypoints(gk, gd, ok, od, "%dx%d qt keys %d rep %d" % (w, h, kcap, rep))
+    assert len(oe.level_candidates(0)) > lds_keys, "level 0 must have keys beyond the LDS share"
+
+
+def test_two_handles_share_the_quadtree_kernel(gpu, oracle, stream640, stream1280):
+    """The dynamic-LDS limit of k_quadtree is a property of the kernel, not of a handle: a handle configured for a
+    small geometry must not take away what a handle with a large one launches with."""
+    big, small = gpu.ORBextractor(2000), gpu.ORBextractor(300)
+    img_b, img_s = stream1280.frame(1)[0], np.ascontiguousarray(stream640.frame(1)[0][:240, :320])
+    kb, db = big(img_b)
+    ks, ds = small(img_s)      # configures (and used to lower the limit) after `big`
+    kb2, db2 = big(img_b)      # must still launch
+    assert kb.tobytes() == kb2.tobytes() and np.array_equal(db, db2)
+    ok, od = oracle.Extractor(2000).extract(img_b)
+    assert_same_keypoints(kb2, db2, ok, od, "big handle after a small one configured")
+    ok, od = oracle.Extractor(300).extract(img_s)
+    assert_same_keypoints(ks, ds, ok, od, "small handle")
 
 
 def test_device_input_with_unaligned_rows(gpu, oracle, stream640):

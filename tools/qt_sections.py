@@ -22,8 +22,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     G.lib().orbgpu_qt_dbg_dump()
     sys.exit(0)
 args = sys.argv[1:5] if len(sys.argv) >= 5 else ["1280", "960", "2000", "1"]
-out = subprocess.run([sys.executable, __file__, "--child"] + args, stdout=subprocess.PIPE, text=True).stdout
-rows = [(int(a), int(b)) for a, b in re.findall(r"mark (\d+) t (\d+)", out)]
+child = subprocess.run([sys.executable, __file__, "--child"] + args, stdout=subprocess.PIPE, text=True)
+if child.returncode != 0:
+    sys.exit("qt_sections: the child process failed with exit code %d (its stderr is above)" % child.returncode)
+rows = [(int(a), int(b)) for a, b in re.findall(r"mark (\d+) t (\d+)", child.stdout)]
+if not rows:
+    sys.exit("qt_sections: no marks -- is liborbgpu.so built with -DORBGPU_QT_TIMING?")
 t0, prev = rows[0][1], rows[0][1]
 for m, t in rows:
     print("mark %2d  %8.2f us  +%7.2f" % (m, (t - t0) / 100.0, (t - prev) / 100.0))
