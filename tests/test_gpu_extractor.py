@@ -335,13 +335,13 @@ def test_quadtree_keys_beyond_lds(gpu, oracle, w, h, nfeat, kcap, monkeypatch):
     """Single frames: k_quadtree keeps the first keys of a level in LDS and the rest in memory; the test hook
     (ORBGPU_DEBUG_QT_KEYS, read by orbgpu_extractor_create) shrinks the LDS share so that both kinds of key take part
     in every sweep.  kcap 512 at 1280x960 / 2000 features are the parameters of the run that faulted in round 2's
-    scratch (gpurun_out/qts_512.log); "last" puts the boundary one key before the end of level 0."""
+    scratch (gpurun_out/qts_512.log); "last" puts the boundary 1..8 keys before the end of level 0."""
     from orb_slam2_map_amd.synth import Stream
     img = Stream(w, h, 1234).frame(2)[0]
     oe = oracle.Extractor(nfeat)
     ok, od = oe.extract(img)
     if kcap == "last":
-        kcap = max(len(oe.level_candidates(0)) - 1, 1)
+        kcap = (len(oe.level_candidates(0)) - 1) // 8 * 8  # (the share is a multiple of 8): 1..8 keys stay in memory
     monkeypatch.setenv("ORBGPU_DEBUG_QT_KEYS", str(kcap))
     ge = gpu.ORBextractor(nfeat)
     monkeypatch.delenv("ORBGPU_DEBUG_QT_KEYS")
