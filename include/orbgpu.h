@@ -405,6 +405,77 @@ typedef struct {
 int orbgpu_search_by_projection(const orbgpu_frame_view *f, const orbgpu_mappoint_view *mp, float th,
                                 float nnratio, int32_t *kp_to_mp, int32_t *nmatches, int32_t device_id);
 
+/* ---- Device-resident MapPoint table ("Host-side gather cost") -------------------------------------
+ * What the projection matchers read of a map point -- GetWorldPos(), GetNormal(), mfMinDistance / mfMaxDistance,
+ * GetDescriptor() (a per-point mutex + 32-byte clone in the reference, MapPoint.cc:309-313), isBad(), Observations() > 0
+ * (ORBmatcher.cc:53-63, 88) -- kept in HBM, keyed by MapPoint::mnId (MapPoint.h:84).  The table is edited where the
+ * reference edits the object (INTEGRATION.md section 2c lists the one-line hooks):
+ *   upsert            MapPoint::MapPoint (MapPoint.cc:32-71), SetWorldPos (:73-78), UpdateNormalAndDepth (:330-371),
+ *                     ComputeDistinctiveDescriptors (:242-307); RGB-D temporal points (Tracking::UpdateLastFrame) with
+ *                     n_obs = 0
+ *   set_observations  AddObservation / EraseObservation (:98-149)
+ *   set_bad           SetBadFlag (:151-175), Replace (:177-228)
+ * Per frame the caller passes ids; id -> row lookup, the gather of the call's local map and the translation of the
+ * frame's existing associations run on the device.  A table is used by one host thread at a time (the reference's
+ * callers hold Map::mMutexMapUpdate around these edits); every call returns synchronised. */
+typedef struct orbgpu_mappoint_table orbgpu_mappoint_table;
+int orbgpu_mappoint_table_create(int32_t device_id, int32_t initial_rows, orbgpu_mappoint_table **out);
+int orbgpu_mappoint_table_destroy(orbgpu_mappoint_table *t);
+/* Distinct ids ever inserted (rows are never recycled: a bad point keeps its row, flagged). */
+int orbgpu_mappoint_table_rows(const orbgpu_mappoint_table *t, int32_t *rows);
+/* Inserts or updates n points (ids distinct within a call, >= 0; host arrays).  An attribute array may be NULL: known
+ * ids keep that attribute, new ids get zeros (n_obs NULL: a new point counts as observed).  world_pos / normal
+ * [n][3], desc [n][32], n_obs = Observations(). */
+int orbgpu_mappoint_table_upsert(orbgpu_mappoint_table *t, int32_t n, const int64_t *ids, const float *world_pos,
+                                 const float *normal, const float *min_dist, const float *max_dist, const uint8_t *desc,
+                                 const int32_t *n_obs);
+/* Ids the table does not know are ignored; *known (optional) = how many it knew. */
+int orbgpu_mappoint_table_set_bad(orbgpu_mappoint_table *t, int32_t n, const int64_t *ids, int32_t *known);
+int orbgpu_mappoint_table_set_observations(orbgpu_mappoint_table *t, int32_t n, const int64_t *ids, const int32_t *n_obs,
+                                           int32_t *known);
+/* One row back to the host (tests, debugging); any output may be NULL. */
+int orbgpu_mappoint_table_read(orbgpu_mappoint_table *t, int64_t id, float *world_pos, float *normal, float *min_dist,
+                               float *max_dist, uint8_t *desc, int32_t *has_observations, int32_t *bad);
+
+/* A Frame's matcher-side members (orbgpu_frame_view: mvKeysUn, mvuRight, mDescriptors, mGrid, bounds, scale factors)
+ * uploaded ONCE and kept on the device: the same frame is the current frame of SearchByProjection(Cur, Last) and of
+ * SearchLocalPoints, and the last frame of the next call.  Uploads return synchronised. */
+typedef struct orbgpu_frame orbgpu_frame;
+int orbgpu_frame_create(int32_t device_id, orbgpu_frame **out);
+int orbgpu_frame_destroy(orbgpu_frame *fr);
+int orbgpu_frame_upload(orbgpu_frame *fr, const orbgpu_frame_view *host_view);
+/* The device pointers of the uploaded frame (valid until the next upload / destroy), for the *_device entry points. */
+int orbgpu_frame_device_view(const orbgpu_frame *fr, orbgpu_device_frame_view *view, int32_t *n);
+
+/* Tracking::SearchLocalPoints (Tracking.cc:1447-1497) / ORBmatcher::SearchByProjection(F, vpMapPoints, th)
+ * (ORBmatcher.cc:45-129) over the table.  ids [m] (host) = mvpLocalMapPoints[i]->mnId; skip [m] or NULL = the host-only
+ * part of Tracking.cc:1474 (mnLastFrameSeen == F.mnId); isBad() comes from the table.
+ *   scratch != NULL: drop-in at the ORBmatcher level -- the caller's Frame::isInFrustum has filled the mTrack* members;
+ *                    in_view, level, view_cos, proj_x, proj_y, proj_xr [m] are uploaded (the struct's bad / obs_pos /
+ *                    desc fields are ignored: they come from the table).  ORBGPU_ELEVEL as orbgpu_search_by_projection.
+ *   scratch == NULL: isInFrustum + PredictScale run on the device from Tcw and the camera (as
+ *                    orbgpu_search_local_points_device); track_out (optional, HOST arrays [m], any may be NULL) receives
+ *                    mbTrackInView etc. so that the caller can IncreaseVisible() (Tracking.cc:1479-1483).
+ * kp_ids [n] or NULL (host): mnId of F.mvpMapPoints[j], -1 = none.  kp_to_mp [n] (host, out): position in ids[] of the
+ * point key point j holds after the call, -1 none, -2 a point outside the list that has observations (untouched).
+ * An id the table does not know is an error (ORBGPU_EINVAL): the table must mirror the map. */
+int orbgpu_search_local_points_table(const orbgpu_frame *fr, orbgpu_mappoint_table *t, int32_t m, const int64_t *ids,
+                                     const uint8_t *skip, const orbgpu_mappoint_view *scratch, const float *Tcw, float fx,
+                                     float fy, float cx, float cy, float mbf, float log_scale_factor, float cos_limit,
+                                     float th, float nnratio, const int64_t *kp_ids, int32_t *kp_to_mp, int32_t *nmatches,
+                                     orbgpu_track_scratch *track_out);
+
+/* ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1328-1470) over the table: both
+ * frames are device-resident; last_ids [last n] (host) = mnId of LastFrame.mvpMapPoints[i] or -1, last_outlier [last n]
+ * or NULL = LastFrame.mvbOutlier, cur_kp_ids [cur n] or NULL = mnId of CurrentFrame.mvpMapPoints[j] or -1.
+ * kp_to_mp [cur n] (host, out): index i of the last-frame key point whose map point key point j now holds, -1, -2. */
+int orbgpu_search_by_projection_last_table(const orbgpu_frame *cur, const float *cur_Tcw, const orbgpu_frame *last,
+                                           const float *last_Tcw, orbgpu_mappoint_table *t, const int64_t *last_ids,
+                                           const uint8_t *last_outlier, const int64_t *cur_kp_ids, float fx, float fy,
+                                           float cx, float cy, float mbf, float mb, float th, int32_t mono,
+                                           int32_t check_orientation, int32_t *kp_to_mp, int32_t *nmatches);
+
+
 /* LastFrame members read by SearchByProjection(CurrentFrame, LastFrame, th, bMono). */
 typedef struct {
     int32_t n;

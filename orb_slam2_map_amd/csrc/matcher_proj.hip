@@ -16,6 +16,7 @@
 #include "common.h"
 #include "matcher_common.h"
 #include "workspace.h"
+#include "proj_internal.h"
 
 #include <algorithm>
 #include <climits>
@@ -649,7 +650,7 @@ static int put(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
     return ORBGPU_OK;
 }
 
-static int validate_frame(const orbgpu_frame_view *f)
+int validate_frame(const orbgpu_frame_view *f)
 {
     ORBGPU_REQUIRE(f, "null frame view");
     ORBGPU_REQUIRE(f->n >= 0 && f->n <= 16384, "frame key point count out of range (max 16384)");
@@ -895,6 +896,46 @@ __global__ __launch_bounds__(256) void k_frustum_queries(int m, const float *__r
 {
     frustum_queries_body(m, world_pos, normal, min_dist, max_dist, skip, obs_pos, P, q, cap, kp_to_mp, claim_init, out,
                          bad_levels);
+}
+
+// The same rows from MapPoint::mTrack* members the caller's own Frame::isInFrustum already filled (the drop-in at the
+// ORBmatcher level: ORBmatcher.cc:53-75 reads mbTrackInView, mnTrackScaleLevel, mTrackViewCos, mTrackProjX/Y/XR); the
+// arrays were uploaded for this call, skip / obs_pos come from the device-resident MapPoint table.
+__global__ __launch_bounds__(256) void k_scratch_queries(int m, ScratchDev sc, const uint8_t *__restrict__ skip,
+                                                         const uint8_t *__restrict__ obs_pos, float th, int nlevels,
+                                                         FrustumParams P, Query *__restrict__ q, int cap,
+                                                         const int *__restrict__ kp_to_mp, int *__restrict__ claim_init,
+                                                         int *__restrict__ bad_levels)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        const int v = kp_to_mp[i];
+        const bool held = v == -2 || (v >= 0 && v < m && (obs_pos ? obs_pos[v] != 0 : true));
+        claim_init[i] = held ? -1 : INT_MAX;
+    }
+    if (i >= m)
+        return;
+    Query Q{};
+    Q.blocking = obs_pos ? (obs_pos[i] != 0) : 1;
+    if (sc.in_view[i] && !(skip && skip[i])) {
+        const int lvl = sc.level[i];
+        if (lvl < 0 || lvl >= nlevels) {
+            atomicAdd(bad_levels, 1);  // H5: the reference indexes mvScaleFactors out of range
+        } else {
+            float r = (double)sc.view_cos[i] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos, ORBmatcher.cc:131-137
+            if (th != 1.0f)
+                r *= th;
+            Q.r = r * P.scale_factors[lvl];
+            Q.x = sc.proj_x[i];
+            Q.y = sc.proj_y[i];
+            Q.ur = sc.proj_xr[i];
+            Q.min_level = lvl - 1;
+            Q.max_level = lvl;
+            Q.check_ur = 1;
+            Q.active = 1;
+        }
+    }
+    q[i] = Q;
 }
 
 // ---- many independent SearchLocalPoints problems (one per sequence) in three launches ------------------------
@@ -1275,14 +1316,28 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
                                       int32_t *d_kp_to_mp, int32_t *d_counts, const orbgpu_track_scratch *d_track,
                                       int32_t device_id, void *hip_stream)
 {
-    ORBGPU_REQUIRE(f && mp && Tcw && d_kp_to_mp && d_counts, "null argument");
+    return orbgpu::search_local_points_device_impl(f, mp, nullptr, Tcw, fx, fy, cx, cy, mbf, log_scale_factor, cos_limit,
+                                                   th, nnratio, d_kp_to_mp, d_counts, d_track, device_id, hip_stream);
+}
+} // extern "C"
+
+// scratch != nullptr: the rows come from uploaded mTrack* members (k_scratch_queries; Tcw and the camera are not read),
+// otherwise from Frame::isInFrustum on the device (k_frustum_queries)
+int orbgpu::search_local_points_device_impl(const orbgpu_device_frame_view *f, const orbgpu_device_mappoint_table *mp,
+                                            const ScratchDev *scratch, const float *Tcw, float fx, float fy, float cx,
+                                            float cy, float mbf, float log_scale_factor, float cos_limit, float th,
+                                            float nnratio, int32_t *d_kp_to_mp, int32_t *d_counts,
+                                            const orbgpu_track_scratch *d_track, int32_t device_id, void *hip_stream)
+{
+    ORBGPU_REQUIRE(f && mp && (Tcw || scratch) && d_kp_to_mp && d_counts, "null argument");
     ORBGPU_REQUIRE(f->cap >= 1 && f->cap <= 16384, "frame capacity out of range (max 16384)");
     ORBGPU_REQUIRE(f->n && f->kps && f->desc && f->u_right && f->cell_start && f->cell_items, "null frame arrays");
     ORBGPU_REQUIRE(f->nlevels >= 1 && f->nlevels <= ORBGPU_MAX_LEVELS && f->scale_factors, "bad scale factors");
     ORBGPU_REQUIRE(f->max_x > f->min_x && f->max_y > f->min_y, "empty image bounds");
     ORBGPU_REQUIRE(mp->m >= 0 && mp->m < (1 << 20), "bad map point count");
     if (mp->m > 0)
-        ORBGPU_REQUIRE(mp->world_pos && mp->normal && mp->min_dist && mp->max_dist && mp->desc, "null map point arrays");
+        ORBGPU_REQUIRE(mp->desc && (scratch || (mp->world_pos && mp->normal && mp->min_dist && mp->max_dist)),
+                       "null map point arrays");
     int rc = select_device(device_id);
     if (rc != ORBGPU_OK)
         return rc;
@@ -1300,11 +1355,13 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     PJ_TRY(ws->match.reserve(sizeof(int) * (size_t)m));
     PJ_TRY(ws->slow.reserve(sizeof(int) * (size_t)m));
     PJ_TRY(ws->out.reserve(4 * sizeof(int)));
-    FrustumParams P;
-    for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 4; c++)
-            P.T[4 * r + c] = Tcw[4 * r + c];
-    minus_rt_t(Tcw, P.Ow);
+    FrustumParams P{};
+    if (!scratch) {
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++)
+                P.T[4 * r + c] = Tcw[4 * r + c];
+        minus_rt_t(Tcw, P.Ow);
+    }
     P.fx = fx, P.fy = fy, P.cx = cx, P.cy = cy, P.mbf = mbf;
     P.min_x = f->min_x, P.max_x = f->max_x, P.min_y = f->min_y, P.max_y = f->max_y;
     P.log_sf = log_scale_factor, P.cos_limit = cos_limit, P.th = th;
@@ -1334,9 +1391,14 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     }
     orbgpu_track_scratch none{};
     const int cover = std::max(m, cap);
-    hipLaunchKernelGGL(k_frustum_queries, dim3((cover + 255) / 256), dim3(256), 0, st, m, mp->world_pos, mp->normal,
-                       mp->min_dist, mp->max_dist, mp->skip, mp->obs_pos, P, ws->queries.as<Query>(), cap, d_kp_to_mp,
-                       ws->claim_init.as<int>(), d_track ? *d_track : none, d_counts + 1);
+    if (scratch)
+        hipLaunchKernelGGL(k_scratch_queries, dim3((cover + 255) / 256), dim3(256), 0, st, m, *scratch, mp->skip, mp->obs_pos,
+                           th, f->nlevels, P, ws->queries.as<Query>(), cap, d_kp_to_mp, ws->claim_init.as<int>(),
+                           d_counts + 1);
+    else
+        hipLaunchKernelGGL(k_frustum_queries, dim3((cover + 255) / 256), dim3(256), 0, st, m, mp->world_pos, mp->normal,
+                           mp->min_dist, mp->max_dist, mp->skip, mp->obs_pos, P, ws->queries.as<Query>(), cap, d_kp_to_mp,
+                           ws->claim_init.as<int>(), d_track ? *d_track : none, d_counts + 1);
     hipLaunchKernelGGL(k_proj_lists, dim3((m + PJ_ROWS_PER_BLOCK - 1) / PJ_ROWS_PER_BLOCK), dim3(256), 0, st, m, ws->queries.as<Query>(), mp->desc, F,
                        ws->topk.as<uint32_t>());
     int novf = 0;
@@ -1348,6 +1410,8 @@ int orbgpu_search_local_points_device(const orbgpu_device_frame_view *f, const o
     ORBGPU_HIP_TRY(hipGetLastError());
     return ORBGPU_OK;
 }
+
+extern "C" {
 
 int orbgpu_search_by_projection_last_device(const orbgpu_device_frame_view *cur, const float *cur_Tcw,
                                             const orbgpu_device_lastframe_view *last, const float *last_Tcw, float fx,

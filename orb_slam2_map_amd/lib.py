@@ -120,6 +120,10 @@ ABI_SYMBOLS = [
     "orbgpu_match_bf_batch_device", "orbgpu_matcher_last_sweeps", "orbgpu_assign_features_to_grid",
     "orbgpu_frame_glue_batch_device", "orbgpu_undistort_points", "orbgpu_search_local_points_device", "orbgpu_search_local_points_batch_device", "orbgpu_search_by_projection_last_device", "orbgpu_projection_last_sweeps", "orbgpu_distinctive_descriptors", "orbgpu_search_by_projection_sim3",
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
+    "orbgpu_mappoint_table_create", "orbgpu_mappoint_table_destroy", "orbgpu_mappoint_table_rows",
+    "orbgpu_mappoint_table_upsert", "orbgpu_mappoint_table_set_bad", "orbgpu_mappoint_table_set_observations",
+    "orbgpu_mappoint_table_read", "orbgpu_frame_create", "orbgpu_frame_destroy", "orbgpu_frame_upload",
+    "orbgpu_frame_device_view", "orbgpu_search_local_points_table", "orbgpu_search_by_projection_last_table",
     "orbgpu_vocabulary_create", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_size", "orbgpu_bow_transform",
     "orbgpu_bow_transform_batch_device", "orbgpu_search_by_bow", "orbgpu_search_by_bow_batch_device",
     "orbgpu_search_by_bow_keyframes", "orbgpu_search_for_triangulation", "orbgpu_search_for_initialization", "orbgpu_fuse", "orbgpu_fuse_sim3",
@@ -508,6 +512,165 @@ def search_by_projection_last_device(cur_view, cur_Tcw, last_view, last_Tcw, fx,
     check(L.orbgpu_search_by_projection_last_device(C.byref(cur_view), _p(Tc), C.byref(last_view), _p(Tl), fx, fy, cx, cy,
                                                     mbf, mb, th, int(mono), int(check_ori), d_kp_to_mp, d_counts,
                                                     device_id, stream))
+
+
+class MapPointTable:
+    """Device-resident MapPoint table keyed by mnId (orbgpu_mappoint_table_*)."""
+
+    def __init__(self, initial_rows=0, device_id=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        check(self.L.orbgpu_mappoint_table_create(device_id, int(initial_rows), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.orbgpu_mappoint_table_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rows(self):
+        v = C.c_int32()
+        check(self.L.orbgpu_mappoint_table_rows(self.h, C.byref(v)))
+        return v.value
+
+    def upsert(self, ids, world_pos=None, normal=None, min_dist=None, max_dist=None, desc=None, n_obs=None):
+        ids = np.ascontiguousarray(ids, np.int64)
+        keep = [ids]
+
+        def arr(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return _p(a)
+        self.L.orbgpu_mappoint_table_upsert.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 7
+        check(self.L.orbgpu_mappoint_table_upsert(self.h, len(ids), _p(ids), arr(world_pos, np.float32), arr(normal, np.float32),
+                                                  arr(min_dist, np.float32), arr(max_dist, np.float32), arr(desc, np.uint8),
+                                                  arr(n_obs, np.int32)))
+
+    def set_bad(self, ids):
+        ids = np.ascontiguousarray(ids, np.int64)
+        k = C.c_int32()
+        self.L.orbgpu_mappoint_table_set_bad.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        check(self.L.orbgpu_mappoint_table_set_bad(self.h, len(ids), _p(ids), C.byref(k)))
+        return k.value
+
+    def set_observations(self, ids, n_obs):
+        ids = np.ascontiguousarray(ids, np.int64)
+        n_obs = np.ascontiguousarray(n_obs, np.int32)
+        k = C.c_int32()
+        self.L.orbgpu_mappoint_table_set_observations.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self.L.orbgpu_mappoint_table_set_observations(self.h, len(ids), _p(ids), _p(n_obs), C.byref(k)))
+        return k.value
+
+    def read(self, id_):
+        wp, nr, ds = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(32, np.uint8)
+        mn, mx, ob, bad = C.c_float(), C.c_float(), C.c_int32(), C.c_int32()
+        self.L.orbgpu_mappoint_table_read.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 7
+        check(self.L.orbgpu_mappoint_table_read(self.h, int(id_), _p(wp), _p(nr), C.byref(mn), C.byref(mx), _p(ds), C.byref(ob),
+                                                C.byref(bad)))
+        return {"world_pos": wp, "normal": nr, "min_dist": mn.value, "max_dist": mx.value, "desc": ds,
+                "has_observations": ob.value, "bad": bad.value}
+
+
+class DeviceFrame:
+    """A Frame's matcher-side members uploaded once and kept on the device (orbgpu_frame_*)."""
+
+    def __init__(self, device_id=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.n = 0
+        check(self.L.orbgpu_frame_create(device_id, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.orbgpu_frame_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, frame):
+        """frame: lib.Frame (host SoA)."""
+        v = frame.view()
+        self.L.orbgpu_frame_upload.argtypes = [C.c_void_p, C.c_void_p]
+        check(self.L.orbgpu_frame_upload(self.h, C.byref(v)))
+        self.n = frame.n
+        return self
+
+    def device_view(self):
+        v, n = DeviceFrameView(), C.c_int32()
+        self.L.orbgpu_frame_device_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self.L.orbgpu_frame_device_view(self.h, C.byref(v), C.byref(n)))
+        return v, n.value
+
+
+def search_local_points_table(dframe, table, ids, Tcw, fx, fy, cx, cy, mbf, log_sf, th, nnratio, skip=None, scratch=None,
+                              kp_ids=None, want_track=False, cos_limit=0.5):
+    """Tracking::SearchLocalPoints over the MapPoint table (orbgpu_search_local_points_table).
+    scratch: dict with in_view, level, view_cos, proj_x, proj_y, proj_xr (the mTrack* members filled on the host) or None
+    (isInFrustum on the device).  Returns (nmatches, kp_to_mp[, track dict])."""
+    L = lib()
+    ids = np.ascontiguousarray(ids, np.int64)
+    m, n = len(ids), dframe.n
+    keep = []
+
+    def arr(a, dt):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return _p(a)
+    mv = None
+    if scratch is not None:
+        mv = MapPointView()
+        mv.m = m
+        mv.in_view, mv.level, mv.view_cos = arr(scratch["in_view"], np.uint8), arr(scratch["level"], np.int32), arr(scratch["view_cos"], np.float32)
+        mv.proj_x, mv.proj_y, mv.proj_xr = (arr(scratch["proj_x"], np.float32), arr(scratch["proj_y"], np.float32),
+                                            arr(scratch["proj_xr"], np.float32))
+    T = np.ascontiguousarray(Tcw, np.float32) if Tcw is not None else None
+    out = np.zeros(max(n, 1), np.int32)
+    nm = C.c_int32()
+    trk, ts = None, None
+    if want_track:
+        trk = {"in_view": np.zeros(m, np.uint8), "proj_x": np.zeros(m, np.float32), "proj_y": np.zeros(m, np.float32),
+               "proj_xr": np.zeros(m, np.float32), "view_cos": np.zeros(m, np.float32), "level": np.zeros(m, np.int32)}
+        ts = TrackScratch()
+        for k in trk:
+            setattr(ts, k, _p(trk[k]))
+    L.orbgpu_search_local_points_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p] + [C.c_float] * 9 + [C.c_void_p] * 4
+    check(L.orbgpu_search_local_points_table(dframe.h, table.h, m, _p(ids), arr(skip, np.uint8),
+                                             C.byref(mv) if mv is not None else None, _p(T) if T is not None else None,
+                                             fx, fy, cx, cy, mbf, log_sf, cos_limit, th, nnratio, arr(kp_ids, np.int64), _p(out),
+                                             C.byref(nm), C.byref(ts) if ts is not None else None))
+    return (nm.value, out[:n], trk) if want_track else (nm.value, out[:n])
+
+
+def search_by_projection_last_table(cur, cur_Tcw, last, last_Tcw, table, last_ids, fx, fy, cx, cy, mbf, mb, th, mono,
+                                    check_ori, last_outlier=None, cur_kp_ids=None):
+    """SearchByProjection(CurrentFrame, LastFrame, th, bMono) over the MapPoint table; cur / last: DeviceFrame."""
+    L = lib()
+    last_ids = np.ascontiguousarray(last_ids, np.int64)
+    lo = np.ascontiguousarray(last_outlier, np.uint8) if last_outlier is not None else None
+    ck = np.ascontiguousarray(cur_kp_ids, np.int64) if cur_kp_ids is not None else None
+    Tc, Tl = np.ascontiguousarray(cur_Tcw, np.float32), np.ascontiguousarray(last_Tcw, np.float32)
+    out = np.zeros(max(cur.n, 1), np.int32)
+    nm = C.c_int32()
+    L.orbgpu_search_by_projection_last_table.argtypes = [C.c_void_p] * 8 + [C.c_float] * 7 + [C.c_int32, C.c_int32, C.c_void_p,
+                                                                                              C.c_void_p]
+    check(L.orbgpu_search_by_projection_last_table(cur.h, _p(Tc), last.h, _p(Tl), table.h, _p(last_ids),
+                                                   _p(lo) if lo is not None else None, _p(ck) if ck is not None else None,
+                                                   fx, fy, cx, cy, mbf, mb, th, int(mono), int(check_ori), _p(out), C.byref(nm)))
+    return nm.value, out[:cur.n]
 
 
 def distinctive_descriptors(groups, device_id=0):
