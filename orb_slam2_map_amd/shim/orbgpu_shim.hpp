@@ -218,6 +218,178 @@ template <typename FrameT> struct FrameSoA {
     }
 };
 
+// Positions of a few pointers inside a long pointer list in O(list + queries): the queries go into a small
+// open-addressing set (cache resident), the list is walked once.  Replaces the per-key-point linear search over
+// vpMapPoints (2 016 x 10 059 pointer compares per SearchByProjection call at C3's size).
+template <typename T> class PtrIndex {
+  public:
+    // keys: the pointers to look for (nullptr entries are ignored)
+    template <typename It> PtrIndex(It first, It last)
+    {
+        size_t n = 0;
+        for (It it = first; it != last; ++it)
+            n += *it != nullptr;
+        size_t cap = 16;
+        while (cap < 2 * n + 2)
+            cap *= 2;
+        mask_ = cap - 1;
+        key_.assign(cap, nullptr);
+        val_.assign(cap, -1);
+        for (It it = first; it != last; ++it)
+            if (*it != nullptr)
+                slot(*it, true);
+    }
+    // first position of every key inside [list, list + m)
+    void locate(T *const *list, int m)
+    {
+        for (int i = 0; i < m; i++) {
+            const long s = slot(list[i], false);
+            if (s >= 0 && val_[(size_t)s] < 0)
+                val_[(size_t)s] = i;
+        }
+    }
+    int position(T *p) const
+    {
+        if (!p)
+            return -1;
+        for (size_t s = hash(p) & mask_;; s = (s + 1) & mask_) {
+            if (key_[s] == p)
+                return val_[s];
+            if (!key_[s])
+                return -1;
+        }
+    }
+
+  private:
+    static size_t hash(const T *p) { return (size_t)(((uintptr_t)p >> 4) * 0x9E3779B97F4A7C15ull >> 20); }
+    long slot(T *p, bool insert)
+    {
+        if (!p)
+            return -1;
+        for (size_t s = hash(p) & mask_;; s = (s + 1) & mask_) {
+            if (key_[s] == p)
+                return (long)s;
+            if (!key_[s]) {
+                if (!insert)
+                    return -1;
+                key_[s] = p;
+                return (long)s;
+            }
+        }
+    }
+    std::vector<T *> key_;
+    std::vector<int> val_;
+    size_t mask_ = 0;
+};
+
+// --------------------------------------------------------------------------------------------
+// Device-resident MapPoint table (orbgpu_mappoint_table_*): what the matchers read of every map point, keyed by
+// MapPoint::mnId (MapPoint.h:84), so that a matcher call hands over ids instead of locking and cloning 10 k objects
+// (MapPoint::GetDescriptor, MapPoint.cc:309-313).  MapPointT needs mnId; the accessors are the same callables the
+// matcher overloads take.  INTEGRATION.md section 2c lists where the reference calls these.
+// --------------------------------------------------------------------------------------------
+template <typename MapPointT> class MapPointTableT {
+  public:
+    explicit MapPointTableT(int device_id = 0, int initial_rows = 0)
+    {
+        check(orbgpu_mappoint_table_create(device_id, initial_rows, &h_), "MapPointTable");
+    }
+    ~MapPointTableT() { orbgpu_mappoint_table_destroy(h_); }
+    MapPointTableT(const MapPointTableT &) = delete;
+    MapPointTableT &operator=(const MapPointTableT &) = delete;
+    orbgpu_mappoint_table *handle() const { return h_; }
+    int rows() const
+    {
+        int32_t r = 0;
+        check(orbgpu_mappoint_table_rows(h_, &r), "MapPointTable::rows");
+        return r;
+    }
+
+    // every attribute of a batch of points (new key frame: MapPoint constructors, UpdateNormalAndDepth,
+    // ComputeDistinctiveDescriptors of the points it created or observed)
+    template <typename WorldPos, typename Normal, typename MinDist, typename MaxDist, typename MpDesc>
+    void Upsert(const std::vector<MapPointT *> &pts, WorldPos world_pos, Normal normal, MinDist min_dist, MaxDist max_dist,
+                MpDesc mp_desc)
+    {
+        const size_t n = pts.size();
+        ids_.resize(n), wp_.resize(3 * n), nr_.resize(3 * n), mn_.resize(n), mx_.resize(n), ds_.resize(32 * n), ob_.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            MapPointT *p = pts[i];
+            ids_[i] = (int64_t)p->mnId;
+            const float *w = world_pos(p), *nn = normal(p);
+            for (int c = 0; c < 3; c++)
+                wp_[3 * i + c] = w[c], nr_[3 * i + c] = nn[c];
+            mn_[i] = min_dist(p), mx_[i] = max_dist(p);
+            std::memcpy(&ds_[32 * i], mp_desc(p), 32);
+            ob_[i] = p->Observations();
+        }
+        check(orbgpu_mappoint_table_upsert(h_, (int32_t)n, ids_.data(), wp_.data(), nr_.data(), mn_.data(), mx_.data(),
+                                           ds_.data(), ob_.data()),
+              "MapPointTable::Upsert");
+        for (size_t i = 0; i < n; i++)
+            if (pts[i]->isBad())
+                bad_.push_back(ids_[i]);
+        if (!bad_.empty()) {
+            check(orbgpu_mappoint_table_set_bad(h_, (int32_t)bad_.size(), bad_.data(), nullptr), "MapPointTable::SetBad");
+            bad_.clear();
+        }
+    }
+    // MapPoint::SetWorldPos (MapPoint.cc:73-78)
+    void SetWorldPos(MapPointT *p, const float *w)
+    {
+        const int64_t id = (int64_t)p->mnId;
+        check(orbgpu_mappoint_table_upsert(h_, 1, &id, w, nullptr, nullptr, nullptr, nullptr, nullptr), "SetWorldPos");
+    }
+    // MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242-307): the chosen descriptor
+    void SetDescriptor(MapPointT *p, const uint8_t *d)
+    {
+        const int64_t id = (int64_t)p->mnId;
+        check(orbgpu_mappoint_table_upsert(h_, 1, &id, nullptr, nullptr, nullptr, nullptr, d, nullptr), "SetDescriptor");
+    }
+    // MapPoint::AddObservation / EraseObservation (MapPoint.cc:98-149)
+    void SetObservations(MapPointT *p)
+    {
+        const int64_t id = (int64_t)p->mnId;
+        const int32_t n = p->Observations();
+        check(orbgpu_mappoint_table_set_observations(h_, 1, &id, &n, nullptr), "SetObservations");
+    }
+    // MapPoint::SetBadFlag (MapPoint.cc:151-175), MapPoint::Replace (:177-228)
+    void SetBad(MapPointT *p)
+    {
+        const int64_t id = (int64_t)p->mnId;
+        check(orbgpu_mappoint_table_set_bad(h_, 1, &id, nullptr), "SetBad");
+    }
+
+  private:
+    orbgpu_mappoint_table *h_ = nullptr;
+    std::vector<int64_t> ids_, bad_;
+    std::vector<float> wp_, nr_, mn_, mx_;
+    std::vector<uint8_t> ds_;
+    std::vector<int32_t> ob_;
+};
+
+// A Frame's matcher-side members on the device (orbgpu_frame_*): uploaded once per frame, then current frame of
+// SearchByProjection(Cur, Last) and of SearchLocalPoints, and last frame of the next call.
+template <typename FrameT> class DeviceFrameT {
+  public:
+    explicit DeviceFrameT(int device_id = 0) { check(orbgpu_frame_create(device_id, &h_), "DeviceFrame"); }
+    ~DeviceFrameT() { orbgpu_frame_destroy(h_); }
+    DeviceFrameT(const DeviceFrameT &) = delete;
+    DeviceFrameT &operator=(const DeviceFrameT &) = delete;
+    template <typename DescRow> void Upload(const FrameT &F, DescRow desc_row)
+    {
+        FrameSoA<FrameT> soa(F, desc_row);
+        check(orbgpu_frame_upload(h_, &soa.view), "DeviceFrame::Upload");
+        n_ = F.N;
+    }
+    orbgpu_frame *handle() const { return h_; }
+    int N() const { return n_; }
+
+  private:
+    orbgpu_frame *h_ = nullptr;
+    int n_ = 0;
+};
+
 template <typename FrameT, typename MapPointT> class ORBmatcherT {
   public:
     static const int TH_LOW = ORBGPU_TH_LOW, TH_HIGH = ORBGPU_TH_HIGH, HISTO_LENGTH = ORBGPU_HISTO_LENGTH;
@@ -260,14 +432,13 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
                                 vcos.data(), px.data(),      py.data(),  pxr.data(), desc.data()};
         // F.mvpMapPoints -> indices: points of the list by position, others by their Observations()
         std::vector<int32_t> k2m(F.N, -1);
+        PtrIndex<MapPointT> held(F.mvpMapPoints.begin(), F.mvpMapPoints.end());
+        held.locate(vpMapPoints.data(), m);
         for (int j = 0; j < F.N; j++) {
             MapPointT *p = F.mvpMapPoints[j];
             if (!p)
                 continue;
-            int idx = -1;
-            for (int i = 0; i < m && idx < 0; i++)
-                if (vpMapPoints[i] == p)
-                    idx = i;
+            const int idx = held.position(p);
             k2m[j] = idx >= 0 ? idx : (p->Observations() > 0 ? -2 : -1);
         }
         std::vector<int32_t> before = k2m;
@@ -322,6 +493,83 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
                 continue;
             CurrentFrame.mvpMapPoints[j] = k2m[j] >= 0 ? LastFrame.mvpMapPoints[k2m[j]] : nullptr;  // :1428, :1461
         }
+        return nmatches;
+    }
+
+    // ---- the same two matchers over the device-resident MapPoint table ------------------------------------------------
+    // SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:45-129) as a drop-in at the ORBmatcher level: the mTrack*
+    // members Frame::isInFrustum filled are uploaded (7 values per point); descriptors, isBad() and Observations() come
+    // from the table by mnId.  dF holds F's matcher-side members on the device (DeviceFrameT::Upload, once per frame).
+    int SearchByProjection(FrameT &F, const DeviceFrameT<FrameT> &dF, const std::vector<MapPointT *> &vpMapPoints,
+                           const float th, MapPointTableT<MapPointT> &table)
+    {
+        const int m = (int)vpMapPoints.size();
+        ids_.resize(m), b0_.resize(m), i0_.resize(m), f0_.resize(m), f1_.resize(m), f2_.resize(m), f3_.resize(m);
+        for (int i = 0; i < m; i++) {
+            const MapPointT *p = vpMapPoints[i];
+            ids_[i] = (int64_t)p->mnId;
+            b0_[i] = p->mbTrackInView;
+            i0_[i] = p->mnTrackScaleLevel;
+            f0_[i] = p->mTrackViewCos, f1_[i] = p->mTrackProjX, f2_[i] = p->mTrackProjY, f3_[i] = p->mTrackProjXR;
+        }
+        orbgpu_mappoint_view sc{m, b0_.data(), nullptr, nullptr, i0_.data(), f0_.data(), f1_.data(), f2_.data(), f3_.data(), nullptr};
+        return run_local(F, dF, vpMapPoints, table, nullptr, &sc, nullptr, 0, 0, 0, 0, 0, 0, 0.5f, th, nullptr);
+    }
+
+    // Tracking::SearchLocalPoints (Tracking.cc:1468-1496) in one call: Frame::isInFrustum + MapPoint::PredictScale run on
+    // the device over the table, then SearchByProjection(F, vpLocalMapPoints, th).  skip(pMP) is the host-only half of
+    // :1474 (pMP->mnLastFrameSeen == F.mnId); isBad() comes from the table.  Returns the match count; *nToMatch
+    // (optional) = points in the frustum; in_view(pMP, bool) is called for every listed point so that the caller can do
+    // IncreaseVisible() and keep mbTrackInView current (:1479-1483).
+    template <typename Skip, typename TcwOf, typename InView>
+    int SearchLocalPoints(FrameT &F, const DeviceFrameT<FrameT> &dF, const std::vector<MapPointT *> &vpLocalMapPoints,
+                          const float th, MapPointTableT<MapPointT> &table, Skip skip, TcwOf Tcw, InView in_view,
+                          int *nToMatch = nullptr)
+    {
+        const int m = (int)vpLocalMapPoints.size();
+        ids_.resize(m), b0_.resize(m), b1_.resize(m);
+        for (int i = 0; i < m; i++) {
+            ids_[i] = (int64_t)vpLocalMapPoints[i]->mnId;
+            b0_[i] = skip(vpLocalMapPoints[i]) ? 1 : 0;
+        }
+        orbgpu_track_scratch trk{b1_.data(), nullptr, nullptr, nullptr, nullptr, nullptr};
+        const int nm = run_local(F, dF, vpLocalMapPoints, table, b0_.data(), nullptr, Tcw(F), F.fx, F.fy, F.cx, F.cy, F.mbf,
+                                 F.mfLogScaleFactor, 0.5f, th, &trk);
+        int seen = 0;
+        for (int i = 0; i < m; i++) {
+            in_view(vpLocalMapPoints[i], b1_[i] != 0);
+            seen += b1_[i] != 0;
+        }
+        if (nToMatch)
+            *nToMatch = seen;
+        return nm;
+    }
+
+    // SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1328-1470) with both frames on the device and
+    // the last frame's map points (world position, descriptor, Observations()) looked up by mnId.
+    template <typename TcwOf>
+    int SearchByProjection(FrameT &CurrentFrame, const DeviceFrameT<FrameT> &dCur, const FrameT &LastFrame,
+                           const DeviceFrameT<FrameT> &dLast, const float th, const bool bMono,
+                           MapPointTableT<MapPointT> &table, TcwOf Tcw)
+    {
+        const int nl = LastFrame.N, n = CurrentFrame.N;
+        ids_.resize(nl), b0_.resize(nl), kid_.resize(n), k2m_.resize(std::max(n, 1));
+        for (int i = 0; i < nl; i++) {
+            const MapPointT *p = LastFrame.mvpMapPoints[i];
+            ids_[i] = p ? (int64_t)p->mnId : -1;
+            b0_[i] = LastFrame.mvbOutlier[i];
+        }
+        for (int j = 0; j < n; j++)
+            kid_[j] = CurrentFrame.mvpMapPoints[j] ? (int64_t)CurrentFrame.mvpMapPoints[j]->mnId : -1;
+        int32_t nmatches = 0;
+        check(orbgpu_search_by_projection_last_table(dCur.handle(), Tcw(CurrentFrame), dLast.handle(), Tcw(LastFrame),
+                                                     table.handle(), ids_.data(), b0_.data(), kid_.data(), CurrentFrame.fx,
+                                                     CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, CurrentFrame.mbf,
+                                                     CurrentFrame.mb, th, bMono, mbCheckOrientation, k2m_.data(), &nmatches),
+              "SearchByProjection(last, table)");
+        for (int j = 0; j < n; j++)
+            if (k2m_[j] >= 0)
+                CurrentFrame.mvpMapPoints[j] = LastFrame.mvpMapPoints[k2m_[j]];  // :1428
         return nmatches;
     }
 
@@ -387,10 +635,8 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
         std::vector<uint8_t> bad(std::max(m, 1)), desc((size_t)std::max(m, 1) * 32);
         std::vector<float> wp((size_t)std::max(m, 1) * 3), nr((size_t)std::max(m, 1) * 3), mind(std::max(m, 1)),
             maxd(std::max(m, 1));
-        std::map<MapPointT *, int> row;  // first row of every distinct point (vpPoints has no duplicates in the reference)
         for (int i = 0; i < m; i++) {
             MapPointT *p = vpPoints[i];
-            row.emplace(p, i);
             bad[i] = p->isBad();
             const float *w = world_pos(p), *nn = normal(p);
             wp[3 * i] = w[0], wp[3 * i + 1] = w[1], wp[3 * i + 2] = w[2];
@@ -400,10 +646,12 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
         }
         orbgpu_points_view pv{m, bad.data(), wp.data(), nr.data(), mind.data(), maxd.data(), desc.data()};
         std::vector<int32_t> k2m(pKF->N, -1);
+        PtrIndex<MapPointT> row(vpMatched.begin(), vpMatched.end());  // first row of every matched point (vpPoints has no duplicates in the reference)
+        row.locate(vpPoints.data(), m);
         for (int j = 0; j < pKF->N; j++)
             if (vpMatched[j]) {
-                auto it = row.find(vpMatched[j]);
-                k2m[j] = it == row.end() ? -2 : it->second;
+                const int r = row.position(vpMatched[j]);
+                k2m[j] = r < 0 ? -2 : r;
             }
         const std::vector<int32_t> before = k2m;
         int32_t nmatches = 0;
@@ -575,9 +823,35 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
     }
 
   protected:
+    // the common tail of the table flavours of SearchByProjection(F, vpMapPoints, th): ids in, list positions out
+    int run_local(FrameT &F, const DeviceFrameT<FrameT> &dF, const std::vector<MapPointT *> &vp,
+                  MapPointTableT<MapPointT> &table, const uint8_t *skip, const orbgpu_mappoint_view *scratch,
+                  const float *Tcw, float fx, float fy, float cx, float cy, float mbf, float log_sf, float cos_limit, float th,
+                  orbgpu_track_scratch *trk)
+    {
+        const int n = F.N, m = (int)vp.size();
+        kid_.resize(n), k2m_.resize(std::max(n, 1));
+        for (int j = 0; j < n; j++)
+            kid_[j] = F.mvpMapPoints[j] ? (int64_t)F.mvpMapPoints[j]->mnId : -1;
+        int32_t nmatches = 0;
+        check(orbgpu_search_local_points_table(dF.handle(), table.handle(), m, ids_.data(), skip, scratch, Tcw, fx, fy, cx, cy,
+                                               mbf, log_sf, cos_limit, th, mfNNratio, kid_.data(), k2m_.data(), &nmatches, trk),
+              "SearchByProjection(table)");
+        for (int j = 0; j < n; j++)
+            if (k2m_[j] >= 0 && F.mvpMapPoints[j] != vp[k2m_[j]])
+                F.mvpMapPoints[j] = vp[k2m_[j]];  // ORBmatcher.cc:123
+        return nmatches;
+    }
+
     float mfNNratio;
     bool mbCheckOrientation;
     int device_;
+    // per-call staging, kept between calls (a matcher that lives on the stack per call site, as in the reference, pays
+    // these allocations every time; Tracking can keep one matcher per thread instead)
+    std::vector<int64_t> ids_, kid_;
+    std::vector<int32_t> k2m_, i0_;
+    std::vector<uint8_t> b0_, b1_;
+    std::vector<float> f0_, f1_, f2_, f3_;
 };
 
 // --------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 // reference's member names (Frame.h / MapPoint.h / KeyFrame.h).  Reads a scenario file written by
 // tests/test_shim.py, runs extractor -> SearchByProjection x2 -> PointCloudMapping through the shim
 // and writes the results for comparison with the oracle.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -21,6 +22,7 @@ struct MapPoint {  // members read by the matcher: MapPoint.h:91-96 + accessors
     float world[3] = {0, 0, 0}, normal[3] = {0, 0, 1}, minDist = 0, maxDist = 0;
     uint8_t desc[32];
     int id = -1;
+    long unsigned int mnId = 0;  // MapPoint.h:84
     bool isBad() const { return bad; }
     int Observations() const { return nObs; }
     // the part of the pointer graph ORBmatcher::Fuse edits (MapPoint.h: AddObservation, Replace, IsInKeyFrame), reduced
@@ -134,8 +136,8 @@ int main(int argc, char **argv)
         int32_t hdr[4];  // w, h, nfeatures, n_map
         rd(in, hdr, 4);
         const int w = hdr[0], h = hdr[1], nfeat = hdr[2], m = hdr[3];
-        float cam[6];  // fx fy cx cy bf th
-        rd(in, cam, 6);
+        float cam[7];  // fx fy cx cy bf th, mfLogScaleFactor as the scenario's isInFrustum used it
+        rd(in, cam, 7);
         std::vector<uint8_t> gray((size_t)w * h), rgb((size_t)w * h * 3);
         std::vector<float> depth((size_t)w * h);
         rd(in, gray.data(), gray.size());
@@ -190,7 +192,17 @@ int main(int argc, char **argv)
             p.mnTrackScaleLevel = lvl, p.mTrackViewCos = f4[0], p.mTrackProjX = f4[1], p.mTrackProjY = f4[2],
             p.mTrackProjXR = f4[3];
             p.id = i;
+            p.mnId = 1000003ul * (unsigned long)((i * 7919) % m) + 17ul;  // sparse, shuffled ids (7919 and m are coprime or not: see below)
             vp[i] = &p;
+        }
+        {  // ids must be distinct: fall back to a plain affine map when 7919 shares a factor with m
+            std::vector<unsigned long> seen;
+            for (int i = 0; i < m; i++)
+                seen.push_back(mps[i].mnId);
+            std::sort(seen.begin(), seen.end());
+            if (std::adjacent_find(seen.begin(), seen.end()) != seen.end())
+                for (int i = 0; i < m; i++)
+                    mps[i].mnId = 1000003ul * (unsigned long)i + 17ul;
         }
         auto desc_row = [](const Frame &fr, int i) { return &fr.mDescriptors[(size_t)i * 32]; };
         auto mp_desc = [](MapPoint *p) { return p->desc; };
@@ -205,6 +217,146 @@ int main(int argc, char **argv)
         const int dist = orbgpu_shim::ORBmatcherT<Frame, MapPoint>::DescriptorDistance(mps[0].desc, mps[m - 1].desc);
         int32_t d32 = dist;
         wr(out, &d32, 1);
+
+        // ---- the same search over the device-resident MapPoint table (ids instead of objects), both flavours, and
+        //      SearchByProjection(Cur, Last) with both frames on the device; host time per call of every flavour
+        {
+            // (a map point seen at exactly its creation distance predicts level l or l + 1 depending on the last bit of
+            //  this value: the scenario's own figure keeps the stand-in and the oracle on the same side)
+            F.mfLogScaleFactor = cam[6];
+            using clk = std::chrono::steady_clock;
+            auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            orbgpu_shim::MapPointTableT<MapPoint> table(0, 256);
+            auto wp_of = [](MapPoint *p) { return p->world; };
+            auto nr_of = [](MapPoint *p) { return p->normal; };
+            auto mn_of = [](MapPoint *p) { return p->minDist; };
+            auto mx_of = [](MapPoint *p) { return p->maxDist; };
+            const auto t_up0 = clk::now();
+            for (int a = 0; a < m; a += 1500) {  // key frame by key frame, as the map grows
+                std::vector<MapPoint *> part(vp.begin() + a, vp.begin() + std::min(a + 1500, m));
+                table.Upsert(part, wp_of, nr_of, mn_of, mx_of, mp_desc);
+            }
+            const double up_us = us(t_up0, clk::now());
+            if (table.rows() != m)
+                throw std::runtime_error("table rows != map points");
+            Frame F2 = F;
+            orbgpu_shim::DeviceFrameT<Frame> dF;
+            const auto t_f0 = clk::now();
+            dF.Upload(F2, desc_row);
+            const double frame_us = us(t_f0, clk::now());
+            const int reps = 20;
+            double t_host = 0, t_tab = 0, t_dev = 0;
+            int nm_tab = 0, nm_dev = 0, nseen = 0;
+            std::vector<int32_t> ids_tab(F.N), ids_dev(F.N);
+            std::vector<uint8_t> seen(m);
+            for (int rep = 0; rep < reps; rep++) {
+                F2.mvpMapPoints.assign(F2.N, nullptr);
+                auto t0 = clk::now();
+                const int nh = matcher.SearchByProjection(F2, vp, cam[5], desc_row, mp_desc);
+                t_host += us(t0, clk::now());
+                if (nh != nm)
+                    throw std::runtime_error("host-pointer SearchByProjection is not repeatable");
+                F2.mvpMapPoints.assign(F2.N, nullptr);
+                t0 = clk::now();
+                nm_tab = matcher.SearchByProjection(F2, dF, vp, cam[5], table);
+                t_tab += us(t0, clk::now());
+                for (int j = 0; j < F2.N; j++)
+                    ids_tab[j] = F2.mvpMapPoints[j] ? F2.mvpMapPoints[j]->id : -1;
+                F2.mvpMapPoints.assign(F2.N, nullptr);
+                t0 = clk::now();
+                nm_dev = matcher.SearchLocalPoints(
+                    F2, dF, vp, cam[5], table, [](MapPoint *) { return false; }, [](const Frame &fr) { return fr.mTcw; },
+                    [&](MapPoint *p, bool v) { seen[p->id] = v; }, &nseen);
+                t_dev += us(t0, clk::now());
+                for (int j = 0; j < F2.N; j++)
+                    ids_dev[j] = F2.mvpMapPoints[j] ? F2.mvpMapPoints[j]->id : -1;
+            }
+            int32_t v32 = nm_tab;
+            wr(out, &v32, 1);
+            wr(out, ids_tab.data(), ids_tab.size());
+            v32 = nm_dev;
+            wr(out, &v32, 1);
+            wr(out, ids_dev.data(), ids_dev.size());
+            v32 = nseen;
+            wr(out, &v32, 1);
+            wr(out, seen.data(), seen.size());
+            std::printf("shim timing (host wall time per call, %d map points, %d key points): table upload %.0f us (once), "
+                        "frame upload %.0f us (per frame), SearchByProjection host-pointer %.0f us, over the table %.0f us, "
+                        "SearchLocalPoints on the device %.0f us\n",
+                        m, F.N, up_us, frame_us, t_host / reps, t_tab / reps, t_dev / reps);
+
+            // last frame = the key points the first n_last map points were made from
+            int32_t n_last = 0;
+            rd(in, &n_last, 1);
+            Frame L;
+            L.N = n_last;
+            L.mvKeys.resize(n_last), L.mvKeysUn.resize(n_last), L.mvuRight.assign(n_last, -1.f);
+            L.mDescriptors.resize((size_t)n_last * 32);
+            L.mvpMapPoints.assign(n_last, nullptr), L.mvbOutlier.assign(n_last, false);
+            for (int i = 0; i < n_last; i++) {
+                float xy[2], ang;
+                int32_t oct;
+                rd(in, xy, 2), rd(in, &oct, 1), rd(in, &ang, 1);
+                L.mvKeys[i] = KeyPoint{{xy[0], xy[1]}, 31.f, ang, 0.f, oct, -1};
+                L.mvKeysUn[i] = L.mvKeys[i];
+                std::memcpy(&L.mDescriptors[(size_t)i * 32], mps[i].desc, 32);
+                L.mvpMapPoints[i] = (i % 5 == 4) ? nullptr : &mps[i];
+                L.mvbOutlier[i] = i % 17 == 0;
+            }
+            L.mvScaleFactors = F.mvScaleFactors;
+            L.mnMinX = F.mnMinX, L.mnMaxX = F.mnMaxX, L.mnMinY = F.mnMinY, L.mnMaxY = F.mnMaxY;
+            L.mfGridElementWidthInv = F.mfGridElementWidthInv, L.mfGridElementHeightInv = F.mfGridElementHeightInv;
+            L.fx = F.fx, L.fy = F.fy, L.cx = F.cx, L.cy = F.cy, L.mbf = F.mbf, L.mb = F.mb;
+            std::memcpy(L.mTcw, Tcw, 64);
+            assign_grid(L);
+            orbgpu_shim::DeviceFrameT<Frame> dL;
+            dL.Upload(L, desc_row);
+            auto tcw_of = [](const Frame &fr) { return fr.mTcw; };
+            double t_lh = 0, t_lt = 0;
+            int nl_host = 0, nl_tab = 0;
+            std::vector<int32_t> idl_host(F.N), idl_tab(F.N);
+            for (int rep = 0; rep < reps; rep++) {
+                F2.mvpMapPoints.assign(F2.N, nullptr);  // Tracking.cc:1166
+                auto t0 = clk::now();
+                nl_host = matcher.SearchByProjection(F2, L, 15.f, false, desc_row, mp_desc, tcw_of, wp_of);
+                t_lh += us(t0, clk::now());
+                for (int j = 0; j < F2.N; j++)
+                    idl_host[j] = F2.mvpMapPoints[j] ? F2.mvpMapPoints[j]->id : -1;
+                F2.mvpMapPoints.assign(F2.N, nullptr);
+                t0 = clk::now();
+                nl_tab = matcher.SearchByProjection(F2, dF, L, dL, 15.f, false, table, tcw_of);
+                t_lt += us(t0, clk::now());
+                for (int j = 0; j < F2.N; j++)
+                    idl_tab[j] = F2.mvpMapPoints[j] ? F2.mvpMapPoints[j]->id : -1;
+            }
+            v32 = nl_host;
+            wr(out, &v32, 1);
+            wr(out, idl_host.data(), idl_host.size());
+            v32 = nl_tab;
+            wr(out, &v32, 1);
+            wr(out, idl_tab.data(), idl_tab.size());
+            std::printf("shim timing: SearchByProjection(Cur, Last) host-pointer %.0f us, over the table %.0f us (%d last-frame key points)\n",
+                        t_lh / reps, t_lt / reps, n_last);
+            // edits reach the table: a point flagged bad is skipped by the next search
+            if (nm_dev > 0) {
+                int victim = -1;
+                for (int j = 0; j < F.N && victim < 0; j++)
+                    victim = ids_dev[j];
+                mps[victim].bad = true;
+                table.SetBad(&mps[victim]);
+                F2.mvpMapPoints.assign(F2.N, nullptr);
+                (void)matcher.SearchLocalPoints(
+                    F2, dF, vp, cam[5], table, [](MapPoint *) { return false; }, tcw_of, [](MapPoint *, bool) {});
+                for (int j = 0; j < F2.N; j++)
+                    if (F2.mvpMapPoints[j] == &mps[victim])
+                        throw std::runtime_error("a map point flagged bad in the table was matched");
+                mps[victim].bad = false;  // the stand-ins go on to the other sections unchanged
+            }
+        }
+        if (argc > 3 && std::string(argv[3]) == "--projection-only") {
+            std::printf("shim ok (projection only): %d key points, %d projection matches\n", n, nm);
+            return 0;
+        }
 
         // ---- loop-closing projection (the stand-in Frame plays the key frame) and distinctive descriptors
         {

@@ -35,6 +35,109 @@ def test_shim_compiles_and_links():
         assert r.returncode == 2 and "usage" in r.stderr
 
 
+def check_table_section(oracle, buf, off, n, of, mp, wp, ko, no, k_last, n_last, Tcw, st):
+    """The shim's MapPoint-table flavours of SearchByProjection(F, vpMapPoints, th), SearchLocalPoints and
+    SearchByProjection(Cur, Last) against the oracle (the stand-in map point i carries id i)."""
+    m = len(wp)
+    nm_tab = struct.unpack_from("<i", buf, off)[0]
+    ids_tab = np.frombuffer(buf, np.int32, n, off + 4)
+    off += 4 + 4 * n
+    assert nm_tab == no and np.array_equal(ids_tab, ko), "table flavour (mTrack* from the host)"
+    nm_dev = struct.unpack_from("<i", buf, off)[0]
+    ids_dev = np.frombuffer(buf, np.int32, n, off + 4)
+    off += 4 + 4 * n
+    assert nm_dev == no and np.array_equal(ids_dev, ko), "table flavour (isInFrustum on the device)"
+    nseen = struct.unpack_from("<i", buf, off)[0]
+    seen = np.frombuffer(buf, np.uint8, m, off + 4)
+    off += 4 + m
+    assert np.array_equal(seen, (mp["bad"] == 0).astype(np.uint8)) and nseen == int((mp["bad"] == 0).sum())
+    last = {"has_mp": (np.arange(n_last) % 5 != 4).astype(np.uint8), "outlier": (np.arange(n_last) % 17 == 0).astype(np.uint8),
+            "obs_pos": mp["obs_pos"][:n_last], "world_pos": wp[:n_last], "desc": mp["desc"][:n_last],
+            "kp_octave": k_last["octave"], "kp_angle": k_last["angle"], "Tcw": Tcw}
+    fx, fy, cx, cy, bf = (float(v) for v in (st.fx, st.fy, st.cx, st.cy, st.bf))
+    nlo, klo = oracle.search_by_projection_last(of, Tcw, fx, fy, cx, cy, bf, bf / fx, last, 15.0, False, True,
+                                                np.full(n, -1, np.int32))
+    assert nlo > 100
+    for what in ("host pointers", "table"):
+        nl = struct.unpack_from("<i", buf, off)[0]
+        idl = np.frombuffer(buf, np.int32, n, off + 4)
+        off += 4 + 4 * n
+        assert nl == nlo and np.array_equal(idl, klo), "SearchByProjection(Cur, Last), %s: %d vs %d" % (what, nl, nlo)
+    return off
+
+
+@pytest.mark.gpu
+def test_shim_projection_c3_size(gpu, oracle, stream1280):
+    """C3's size through the C++ shim (1280x960, 2000 features, ~10 k local map points): the table flavours equal the
+    oracle, and the run prints the host wall time per call of every flavour (the figure INTEGRATION.md quotes)."""
+    st = stream1280
+    rng = np.random.default_rng(12)
+    t_cur = 12
+    g, rgb, depth = st.frame(t_cur)
+    oe = oracle.Extractor(2000)
+    ok, od = oe.extract(g)
+    sf = oe.scale_factors()
+    Tcw = scenario.rigid()
+    wp, dsc, octv, k_last = [], [], [], None
+    ox, oy = st.offset(t_cur)
+    for t in (11, 10, 9, 8, 7):
+        gp, _, dp = st.frame(t)
+        k, d = oracle.Extractor(2000).extract(gp)
+        px, py = st.offset(t)
+        P, _ = scenario.world_points_from_prev(k, dp, (ox - px, oy - py), st, Tcw, rng)
+        wp.append(P), dsc.append(d), octv.append(k["octave"])
+        k_last = k if k_last is None else k_last
+    n_first = len(wp[0])
+    wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
+    mp = scenario.local_map(oracle, st, Tcw, wp, dsc, octv, sf, rng, obs_zero_frac=0.1)
+    mp["bad"] = (mp["bad"] | (mp["in_view"] == 0) | (octv == len(sf) - 1)).astype(np.uint8)
+    th = 3.0
+    with tempfile.TemporaryDirectory() as d:
+        exe = build_exe(d)
+        scen, outp = os.path.join(d, "scen.bin"), os.path.join(d, "out.bin")
+        with open(scen, "wb") as f:
+            f.write(struct.pack("<4i", 1280, 960, 2000, len(wp)))
+            f.write(struct.pack("<7f", float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), th,
+                                float(np.log(np.float32(sf[1])))))  # mfLogScaleFactor as scenario.local_map used it
+            f.write(g.tobytes()), f.write(rgb.tobytes()), f.write(depth.tobytes()), f.write(Tcw.astype("<f4").tobytes())
+            rec = np.zeros(len(wp), np.dtype([("f", "u1", 3), ("lvl", "<i4"), ("s", "<f4", 4), ("wp", "<f4", 3), ("nr", "<f4", 3),
+                                              ("d", "<f4", 2), ("desc", "u1", 32)]))
+            rec["f"] = np.stack([mp["in_view"], mp["bad"], mp["obs_pos"]], 1)
+            rec["lvl"] = mp["level"]
+            rec["s"] = np.stack([mp["view_cos"], mp["proj_x"], mp["proj_y"], mp["proj_xr"]], 1)
+            rec["wp"], rec["nr"] = wp, mp["normal"]
+            rec["d"] = np.stack([mp["min_dist"], mp["max_dist"]], 1)
+            rec["desc"] = mp["desc"]
+            assert rec.dtype.itemsize == 3 + 4 + 16 + 12 + 12 + 8 + 32
+            f.write(rec.tobytes())
+            f.write(struct.pack("<i", n_first))
+            lrec = np.zeros(n_first, np.dtype([("xy", "<f4", 2), ("o", "<i4"), ("a", "<f4")]))
+            lrec["xy"] = np.stack([k_last["x"], k_last["y"]], 1)
+            lrec["o"], lrec["a"] = k_last["octave"], k_last["angle"]
+            f.write(lrec.tobytes())
+        r = subprocess.run([exe, scen, outp, "--projection-only"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        print(r.stdout)
+        buf = open(outp, "rb").read()
+    assert "shim timing" in r.stdout
+    n = struct.unpack_from("<i", buf, 0)[0]
+    off = 4
+    kps = np.frombuffer(buf, oracle.KEYPOINT_DTYPE, n, off)
+    off += 28 * n
+    desc = np.frombuffer(buf, np.uint8, 32 * n, off).reshape(n, 32)
+    off += 32 * n
+    assert n == len(ok) and kps.tobytes() == ok.tobytes() and np.array_equal(desc, od)
+    nm = struct.unpack_from("<i", buf, off)[0]
+    k2m = np.frombuffer(buf, np.int32, n, off + 4)
+    off += 4 + 4 * n
+    of = scenario.make_frame(oracle, ok, od, depth, st, sf)
+    no, ko = oracle.search_by_projection(of, mp, th, 0.8, np.full(n, -1, np.int32))
+    assert len(wp) > 9000 and nm == no and np.array_equal(k2m, ko) and no > 500
+    off += 4  # DescriptorDistance
+    off = check_table_section(oracle, buf, off, n, of, mp, wp, ko, no, k_last, n_first, Tcw, st)
+    assert off == len(buf)
+
+
 @pytest.mark.gpu
 def test_shim_end_to_end(gpu, oracle, stream640):
     st = stream640
@@ -46,7 +149,7 @@ def test_shim_end_to_end(gpu, oracle, stream640):
     sf = oe.scale_factors()
     Tcw = scenario.rigid()
     # local map from two earlier frames (oracle extraction; the shim extracts the current frame itself)
-    wp, dsc, octv = [], [], []
+    wp, dsc, octv, k_last = [], [], [], None
     ox, oy = st.offset(t_cur)
     for t in (11, 10):
         gp, _, dp = st.frame(t)
@@ -54,6 +157,7 @@ def test_shim_end_to_end(gpu, oracle, stream640):
         px, py = st.offset(t)
         P, _ = scenario.world_points_from_prev(k, dp, (ox - px, oy - py), st, Tcw, rng)
         wp.append(P), dsc.append(d), octv.append(k["octave"])
+        k_last = k if k_last is None else k_last
     n_first = len(wp[0])  # the map points made from frame t_cur - 1
     wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
     mp = scenario.local_map(oracle, st, Tcw, wp, dsc, octv, sf, rng, obs_zero_frac=0.1)
@@ -67,7 +171,8 @@ def test_shim_end_to_end(gpu, oracle, stream640):
         scen, outp = os.path.join(d, "scen.bin"), os.path.join(d, "out.bin")
         with open(scen, "wb") as f:
             f.write(struct.pack("<4i", 640, 480, 1000, len(wp)))
-            f.write(struct.pack("<6f", float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), th))
+            f.write(struct.pack("<7f", float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), th,
+                                float(np.log(np.float32(sf[1])))))  # mfLogScaleFactor as scenario.local_map used it
             f.write(g.tobytes()), f.write(rgb.tobytes()), f.write(depth.tobytes()), f.write(Tcw.astype("<f4").tobytes())
             for i in range(len(wp)):
                 f.write(struct.pack("<3B", int(mp["in_view"][i]), int(mp["bad"][i]), int(mp["obs_pos"][i])))
@@ -78,6 +183,11 @@ def test_shim_end_to_end(gpu, oracle, stream640):
                 f.write(mp["normal"][i].astype("<f4").tobytes())
                 f.write(struct.pack("<2f", float(mp["min_dist"][i]), float(mp["max_dist"][i])))
                 f.write(mp["desc"][i].tobytes())
+            # the last frame of SearchByProjection(Cur, Last): the key points the first n_first map points were made from
+            f.write(struct.pack("<i", n_first))
+            for i in range(n_first):
+                f.write(struct.pack("<2fif", float(k_last["x"][i]), float(k_last["y"][i]), int(k_last["octave"][i]),
+                                    float(k_last["angle"][i])))
             # vocabulary for the SearchByBoW part + how many map points play the key frame's features
             voc = scenario.synthetic_vocabulary(10, 3, 99)
             n_kf = n_first
@@ -86,6 +196,7 @@ def test_shim_end_to_end(gpu, oracle, stream640):
             f.write(voc["desc"].tobytes()), f.write(voc["weight"].astype("<f8").tobytes())
         r = subprocess.run([exe, scen, outp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout
+        print(r.stdout)
         buf = open(outp, "rb").read()
     n = struct.unpack_from("<i", buf, 0)[0]
     off = 4
@@ -104,6 +215,7 @@ def test_shim_end_to_end(gpu, oracle, stream640):
     dist = struct.unpack_from("<i", buf, off)[0]
     off += 4
     assert dist == oracle.descriptor_distance(mp["desc"][0], mp["desc"][-1])
+    off = check_table_section(oracle, buf, off, n, of, mp, wp, ko, no, k_last, n_first, Tcw, st)
     # loop-closing projection through the shim (Sim3 = 1.5 x the rigid pose) and distinctive descriptors
     ns = struct.unpack_from("<i", buf, off)[0]
     off += 4
