@@ -73,7 +73,8 @@ def pmc_traffic(stage, frames_per_launch):
             j = json.load(open(path))
             k = j["kernels"]
             per_frame = float(sum(k[kn]["hbm_bytes_per_frame"] for kn in STAGE_KERNELS[stage]))
-            return per_frame * frames_per_launch, "profiles/%s (%s)" % (name, j.get("how", "separate --pmc passes"))
+            return per_frame * frames_per_launch, "SCALED to %d frames per launch from the committed per-frame counters of profiles/%s (%s); not collected in this run" % (
+                frames_per_launch, name, j.get("how", "separate --pmc passes"))
         except Exception:
             continue
     return None, None
@@ -93,6 +94,8 @@ def valu_issue(stage, frames_per_launch, ms_per_launch):
                 "note": "cycles a SIMD has per VALU wave-instruction of this kernel at the live launch time; the kernel's "
                         "instructions are mostly of the half-rate class (packed 16-bit extrema, v_perm), whose measured issue "
                         "cost is 4.3 cycles",
+                "scaled": "instruction count SCALED from the committed B = 256 counter pass to %d frames per launch; the launch "
+                          "duration is live" % frames_per_launch,
                 "source": "profiles/r02_pmc_sq.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE), profiles/r02_valu_rate.txt"}
     except Exception:
         return None
@@ -282,10 +285,18 @@ def main():
                       desc[k].data_ptr() + DS, kps[k].data_ptr() + KP + 12, nout[k].data_ptr() + 4, 28, 50, 0.7,
                       True, match_b.data_ptr(), nmatch.data_ptr(), s_match.cuda_stream)
 
+    match_timing = {"on": False, "pairs": []}  # HIP events around the matcher on ITS stream, on the profiled steps
+
     def flush_match():
         if pending[0] is not None:
             with torch.cuda.stream(s_match):
+                if match_timing["on"]:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(s_match)
                 run_match(pending[0])
+                if match_timing["on"]:
+                    b.record(s_match)
+                    match_timing["pairs"].append((a, b))
                 ev_match[pending[0]].record(s_match)
             pending[0] = None
 
@@ -351,7 +362,9 @@ def main():
     for i in range(args.steps):
         for e in parts:
             e.set_profiling(i % PROF_EVERY == 0)
+        match_timing["on"] = args.overlap_match and i % PROF_EVERY == 0
         step(args.warmup + i)
+    match_timing["on"] = False
     flush_match()  # the last step's matcher belongs to the timed region
     if pl:
         pl.wait(s_ext.cuda_stream)
@@ -371,7 +384,14 @@ def main():
         e.set_profiling(False)
     # serial schedule only: what the step spends outside the extraction stages = the matcher (+ 3 small copies);
     # with the matcher on its own stream the difference is not a duration of anything
-    match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0) if not args.overlap_match else None
+    if not args.overlap_match:
+        match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0)
+        match_how = "step time minus the six extraction stages (serial schedule, one stream)"
+    else:  # k_bf_topk + k_bf_resolve of one step, timed on the matcher's own stream while the next extraction shares the device
+        match_ms = (sum(a.elapsed_time(b) for a, b in match_timing["pairs"]) / len(match_timing["pairs"])
+                    if match_timing["pairs"] else None)
+        match_how = ("HIP events on the matcher's stream around the %d-pair match of a step, every %dth timed step; it runs "
+                     "next to the following extraction, so it is not additive with the extraction stages" % (B, PROF_EVERY))
 
     elapsed_max, total_frames = D.aggregate(elapsed, B * args.steps, world,
                                             device="cuda" if args.backend == "nccl" else "cpu")
@@ -448,7 +468,7 @@ def main():
                          "ms_per_launch": stage_ms[dom], "frames_per_launch": B, "launches": P,
                          "launch_note": None if P == 1 else "ms_per_launch = the %d sub-batch launches of a step, each timed "
                          "with HIP events on its own stream while the other parts' kernels share the device" % P},
-            "stages": per_stage,
+            "stages": dict(per_stage, **({"match": {"ms": round(match_ms, 4), "how": match_how}} if match_ms is not None else {})),
             "valu_issue": valu_issue(dom, B, stage_ms[dom]),
             "extract_ms_per_step": round(ext_ms, 4),
             "extract_roofline": {"achieved": ext_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_ach / HBM_PEAK_GBS,

@@ -131,9 +131,18 @@ def c3(reps=30, device_id=0):
 
     extract_glue()
     k2m.fill_(-1)
+    # one untimed call with the tracking scratch attached: mbTrackInView of every point = the real in-view count
+    in_view = torch.zeros(M, dtype=torch.uint8, device=dev)
+    trk = G.TrackScratch()
+    trk.in_view = in_view.data_ptr()
+    G.search_local_points_device(fv, tb, Tcw, *camv, log_sf, 3.0, 0.8, k2m.data_ptr(), counts.data_ptr(), trk, stream=s,
+                                 device_id=device_id)
+    torch.cuda.synchronize()
+    n_view, n_bad_level = int(in_view.sum()), int(counts[1])
+    k2m.fill_(-1)
     search()
     torch.cuda.synchronize()
-    n_match, n_view = int(counts[0]), int(counts[1])
+    n_match = int(counts[0])
     N = int(nout[0])
     ms_search = timed(search, pre=lambda: k2m.fill_(-1))
     ms_extract = timed(extract_glue)
@@ -146,7 +155,8 @@ def c3(reps=30, device_id=0):
     ach = alg_m2 / (ms_search * 1e-3) / 1e9
     return {"workload": "C3: synthetic 1280x960, 2000 features, extract + isInFrustum + SearchByProjection(th=3) of %d "
                         "local map points (%d in view), device resident, one frame at a time" % (M, n_view),
-            "keypoints": N, "map_points": M, "matches": n_match, "claim_sweeps": sweeps, "rewalked_rows": rewalked,
+            "keypoints": N, "map_points": M, "in_view": n_view, "levels_out_of_range": n_bad_level, "matches": n_match,
+            "claim_sweeps": sweeps, "rewalked_rows": rewalked,
             "search_ms": ms_search, "extract_glue_ms": ms_extract, "extract_glue_search_ms": ms_chain,
             "frames_per_s": 1e3 / ms_chain,
             "roofline": {"bound": "hbm", "kernel": "k_frustum_queries + k_proj_lists + k_proj_resolve", "achieved": ach,

@@ -68,6 +68,20 @@ def main():
     kept, md = O.statistical_outlier_removal(vox5, 50, 1.0)
     np.savez_compressed(os.path.join(HERE, "sor_cloud_640x480_f0.npz"), mean_dist=md,
                         kept_crc=np.array([zlib.crc32(kept.tobytes())], np.uint32), n_kept=np.array([len(kept)], np.int32))
+    # (2) Hamming known-answer test: 4096 descriptor pairs from a xorshift stream (tests/golden_scenarios.py), distances by
+    #     the oracle, cross-checked here with Python integers
+    import golden_scenarios as GS
+    a, b = GS.hamming_kat_inputs()
+    dist = np.array([O.descriptor_distance(x, y) for x, y in zip(a, b)], np.int32)
+    assert np.array_equal(dist, GS.popcount_reference(a, b))
+    np.savez_compressed(os.path.join(HERE, "hamming_kat_4096.npz"), dist=dist.astype(np.int16),
+                        inputs_crc=np.array([zlib.crc32(a.tobytes() + b.tobytes())], np.uint32))
+    # (6b) SearchByProjection assignments of C3's matcher problem (1280x960, 2000 features, ~10 k local map points)
+    sc = GS.c3_projection_scenario(O)
+    n, k2m = O.search_by_projection(sc["frame"], sc["mp"], sc["th"], sc["nnratio"], sc["k0"])
+    np.savez_compressed(os.path.join(HERE, "projection_c3_seed5678.npz"), nmatches=np.array([n], np.int32), kp_to_mp=k2m,
+                        n_map_points=np.array([len(sc["world_pos"])], np.int32),
+                        inputs_crc=np.array([sc["inputs_crc"]], np.uint32))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -74,3 +74,27 @@ def test_outlier_filter(oracle):
     kept, md = oracle.statistical_outlier_removal(g["vox_005"], 50, 1.0)
     assert np.array_equal(md.view(np.uint32), s["mean_dist"].view(np.uint32))
     assert len(kept) == int(s["n_kept"][0]) and zlib.crc32(kept.tobytes()) == int(s["kept_crc"][0])
+
+
+def test_hamming_kat(oracle):
+    """ORBmatcher::DescriptorDistance (ORBmatcher.cc:1647-1663): 4096 pairs, the oracle, Python integers and the committed
+    distances agree."""
+    import golden_scenarios as GS
+    g = np.load(os.path.join(G, "hamming_kat_4096.npz"))
+    a, b = GS.hamming_kat_inputs()
+    assert zlib.crc32(a.tobytes() + b.tobytes()) == int(g["inputs_crc"][0]), "KAT input generator changed"
+    want = g["dist"].astype(np.int32)
+    assert np.array_equal(GS.popcount_reference(a, b), want)
+    assert np.array_equal(np.array([oracle.descriptor_distance(x, y) for x, y in zip(a, b)], np.int32), want)
+    assert want.min() == 0 and want.max() > 150 and len(np.unique(want)) > 50  # near duplicates .. far pairs
+
+
+def test_projection_c3(oracle):
+    """SearchByProjection(F, vpMapPoints, th) on C3's seeded scenario (~10 k map points) against the committed assignments."""
+    import golden_scenarios as GS
+    g = np.load(os.path.join(G, "projection_c3_seed5678.npz"))
+    sc = GS.c3_projection_scenario(oracle)
+    assert sc["inputs_crc"] == int(g["inputs_crc"][0]), "scenario generator changed"
+    assert len(sc["world_pos"]) == int(g["n_map_points"][0]) > 9000
+    n, k2m = oracle.search_by_projection(sc["frame"], sc["mp"], sc["th"], sc["nnratio"], sc["k0"])
+    assert n == int(g["nmatches"][0]) > 1000 and np.array_equal(k2m, g["kp_to_mp"])

@@ -208,3 +208,14 @@ def test_argument_errors_are_statuses_not_crashes(gpu):
     h = C.c_void_p()
     assert L.orbgpu_matcher_create(0, 0, 100, C.byref(h)) == gpu.EINVAL
     assert L.orbgpu_cloud_create(0.0, 0, C.byref(h)) == gpu.EINVAL  # resolution must be positive
+
+
+def test_hamming_kat_on_gpu(gpu):
+    """The committed 4096-pair known-answer test of DescriptorDistance (tests/golden/hamming_kat_4096.npz) on the device."""
+    import os
+    import zlib
+    import golden_scenarios as GS
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hamming_kat_4096.npz"))
+    a, b = GS.hamming_kat_inputs()
+    assert zlib.crc32(a.tobytes() + b.tobytes()) == int(g["inputs_crc"][0])
+    assert np.array_equal(gpu.ORBmatcher.DescriptorDistance(a, b), g["dist"].astype(np.int32))

@@ -571,3 +571,31 @@ def test_search_local_points_batch_of_sequences(gpu, oracle):
         c = counts.cpu().numpy()
         assert c[0] == no and np.array_equal(k2m.cpu().numpy()[:n], ko), (c, no)
     assert expect[0][0] > 50 and expect[3][0] == 0
+
+
+def test_golden_c3_projection_on_gpu(gpu, oracle):
+    """The committed SearchByProjection assignments of C3's seeded scenario (tests/golden/projection_c3_seed5678.npz, ~10 k
+    map points) replayed through the host-pointer entry point and through the MapPoint table on the device."""
+    import os
+    import golden_scenarios as GS
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "projection_c3_seed5678.npz"))
+    sc = GS.c3_projection_scenario(oracle)
+    assert sc["inputs_crc"] == int(g["inputs_crc"][0]), "scenario generator changed"
+    of, mp, st = sc["frame"], sc["mp"], sc["stream"]
+    gf = gpu.Frame(of.kp_x, of.kp_y, of.octave, of.angle, of.u_right, of.desc, float(of.max_x), float(of.max_y), of.scale_factors)
+    n, k2m = gpu.ORBmatcher(sc["nnratio"], True).SearchByProjection(gf, mp, sc["th"], sc["k0"])
+    assert n == int(g["nmatches"][0]) and np.array_equal(k2m, g["kp_to_mp"])
+    m = len(sc["world_pos"])
+    ids = np.arange(m, dtype=np.int64) * 3 + 5
+    tbl = gpu.MapPointTable(m)
+    tbl.upsert(ids, sc["world_pos"], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["obs_pos"].astype(np.int32))
+    tbl.upsert(np.array([1], np.int64), n_obs=np.array([1], np.int32))  # the point outside the list some key points hold
+    tbl.set_bad(ids[mp["bad"] != 0])
+    kp_ids = np.where(sc["k0"] >= 0, ids[np.maximum(sc["k0"], 0)], np.where(sc["k0"] == -2, 1, -1)).astype(np.int64)
+    dfr = gpu.DeviceFrame().upload(gf)
+    fx, fy, cx, cy, bf = (float(v) for v in (st.fx, st.fy, st.cx, st.cy, st.bf))
+    log_sf = float(np.log(np.float32(sc["sf"][1])))
+    for scratch in (mp, None):  # mTrack* from the host, then isInFrustum on the device
+        n2, k2 = gpu.search_local_points_table(dfr, tbl, ids, sc["Tcw"], fx, fy, cx, cy, bf, log_sf, sc["th"], sc["nnratio"],
+                                               scratch=scratch, kp_ids=kp_ids)
+        assert n2 == int(g["nmatches"][0]) and np.array_equal(k2, g["kp_to_mp"])
