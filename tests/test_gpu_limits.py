@@ -22,8 +22,8 @@ def test_image_side_limit_and_too_small_levels(gpu):
     big = np.zeros((64, 4200), np.uint8)
     with pytest.raises(RuntimeError, match="outside the supported range"):
         gpu.ORBextractor(500, 1.2, 1, 20, 7)(big)
-    small = np.zeros((100, 100), np.uint8)  # level 7 of 8 would be 28 px wide
-    with pytest.raises(RuntimeError, match="outside the supported range"):
+    small = np.zeros((100, 100), np.uint8)  # level 3 of 8 is 58 px wide: no room for a 30-px FAST cell inside the 16-px border
+    with pytest.raises(RuntimeError, match="pyramid level 3 too small"):
         gpu.ORBextractor(500)(small)
 
 
