@@ -891,6 +891,96 @@ __device__ __forceinline__ void count_runs(int *cnt, int target, bool valid)
 constexpr int QT_CELL_ILP = 8;  // ... of one cell in the single-frame compaction
 constexpr int QT_ILP = 4;  // keys a thread carries through a sweep side by side (independent LDS / memory chains)
 
+// Single frames only: step 0 of k_quadtree (filter the level's stored keys by the per-cell threshold rule, compact them,
+// count them per initial node) and the child counts of the initial nodes (what step 1's key sweep produced) for ALL
+// levels of a frame, spread over the device -- the level-0 workgroup of k_quadtree<true> spent 31 of its 102 us on that
+// one sweep over ~45 k stored keys of a 1280x960 frame, and 7 us more on step 1's.  Per (frame, level) the kernel
+// leaves in `aux`: [0] the number of kept keys, [1 + 4 b + q] the kept keys of initial node (bin) b that fall into its
+// quadrant q.  k_quadtree<true> reads and re-arms them.  Batches keep the in-kernel step 0 (one workgroup per (frame,
+// level) is already thousands of workgroups there).
+constexpr int QT_INI_MAX = 80;                       // initial nodes of a level this path supports (round(width / height))
+constexpr int QT_AUX_LEVEL = 1 + 4 * QT_INI_MAX;     // ints per (frame, level)
+constexpr int QT_AUX_FRAME = QT_AUX_LEVEL * ORBGPU_MAX_LEVELS;
+constexpr int QT_PRE_KEYS = 256 * QT_ILP;            // stored keys a workgroup of the prefilter takes per trip
+constexpr int QT_PRE_GRID = 48;                      // workgroups per (frame, level): one trip each up to 49 k stored keys
+
+__global__ __launch_bounds__(256) void k_qt_prefilter(const LevelGeom *__restrict__ geom, int ncells_total,
+                                                      const uint32_t *__restrict__ slots, size_t frame_slots,
+                                                      const int *__restrict__ cell_cnt, uint32_t *__restrict__ dense_key,
+                                                      int *__restrict__ aux, int t_ini)
+{
+    __shared__ int s_cnt[4 * QT_INI_MAX];
+    __shared__ int s_w[4 * QT_ILP], s_base;
+    const int level = blockIdx.y, f = blockIdx.z;
+    const LevelGeom g = geom[level];
+    const int *fcnt = cell_cnt + (size_t)f * (ncells_total + ORBGPU_MAX_LEVELS);
+    const int nst = min(fcnt[ncells_total + level], g.slot_cnt);
+    if ((int)blockIdx.x * QT_PRE_KEYS >= nst)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_ini = g.n_ini;
+    for (int i = tid; i < 4 * n_ini; i += 256)
+        s_cnt[i] = 0;
+    __syncthreads();
+    const int *ccounts = fcnt + g.cell_first;
+    const uint32_t *lslots = slots + (size_t)f * frame_slots + g.slot_off;
+    uint32_t *dkey = dense_key + (size_t)f * frame_slots + g.slot_off;
+    int *laux = aux + (size_t)f * QT_AUX_FRAME + level * QT_AUX_LEVEL;
+    // the grid is sized for a typical level (the host cannot know the key counts); a workgroup strides over the tiles
+    for (int i_first = blockIdx.x * QT_PRE_KEYS; i_first < nst; i_first += gridDim.x * QT_PRE_KEYS) {
+    uint32_t key[QT_ILP];
+    int hi[QT_ILP];
+#pragma unroll
+    for (int u = 0; u < QT_ILP; u++)
+        key[u] = lslots[min(i_first + u * 256 + tid, nst - 1)];
+#pragma unroll
+    for (int u = 0; u < QT_ILP; u++) {
+        const uint32_t cj = __umulhi((uint32_t)max(key_x(key[u]) - 3, 0), g.inv_wcell);
+        const uint32_t ci = __umulhi((uint32_t)max(key_y(key[u]) - 3, 0), g.inv_hcell);
+        hi[u] = ccounts[min((int)(ci * (uint32_t)g.ncols_eff + cj), g.ncells - 1)] >> 16;  // the cell's corners above iniThFAST
+    }
+    // one range of the level's dense array per workgroup and trip (a same-address global atomic per WAVE serialised
+    // 700 of them on level 0's counter: 7 of the kernel's 12 us)
+    bool keep[QT_ILP];
+    unsigned long long m[QT_ILP];
+#pragma unroll
+    for (int u = 0; u < QT_ILP; u++) {
+        // cornerScore = s - 1:  s > t  <=>  response >= t
+        keep[u] = i_first + u * 256 + tid < nst && (!hi[u] || key_resp(key[u]) >= t_ini);
+        m[u] = __ballot(keep[u]);
+        if (lane == 0)
+            s_w[u * 4 + (tid >> 6)] = __popcll(m[u]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int k = 0; k < 4 * QT_ILP; k++)
+            tot += s_w[k];
+        s_base = tot ? atomicAdd(&laux[0], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < QT_ILP; u++) {
+        int base = s_base;
+        for (int k = 0; k < u * 4 + (tid >> 6); k++)
+            base += s_w[k];
+        if (keep[u])
+            dkey[base + __popcll(m[u] & ((1ull << lane) - 1ull))] = key[u];
+        int bin = (int)((float)key_x(key[u]) / g.hx);
+        bin = min(max(bin, 0), n_ini - 1);
+        // the initial node of bin b (ORBextractor.cc:548-557) and the child its split point sends the key to
+        const short4 b = make_short4((short)(int)(g.hx * (float)bin), 0, (short)(int)(g.hx * (float)(bin + 1)),
+                                     (short)(g.max_by - BORDER0));
+        count_runs(s_cnt, bin * 4 + quadrant_at(key[u], split_of(b)), keep[u]);
+    }
+    __syncthreads();  // s_w is rewritten by the next trip
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * n_ini; i += 256)
+        if (s_cnt[i])
+            atomicAdd(&laux[1 + i], s_cnt[i]);
+}
+
 template <bool LDS_KEYS>  // keep the level's first kcap keys and node ids in LDS (single frames: see the launch)
 __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__restrict__ geom,
                                                   const CellDesc *__restrict__ cells, int ncells_total,
@@ -900,7 +990,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
                                                   uint16_t *__restrict__ dense_node,
                                                   uint32_t *__restrict__ sel, int sel_cap_total,
                                                   int *__restrict__ nsel, int *__restrict__ ncand, int nlevels,
-                                                  int ncap, int t_ini, int kcap_arg, long long *dbg_t)
+                                                  int ncap, int t_ini, int kcap_arg, long long *dbg_t,
+                                                  int *__restrict__ pre_aux /* k_qt_prefilter's results, or nullptr */)
 {
     // section timestamps of workgroup (frame 0, level 0) for tools/qt_sections.py; compiled in with -DORBGPU_QT_TIMING
 #ifdef ORBGPU_QT_TIMING
@@ -984,6 +1075,29 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     const int n_ini = g.n_ini;
     const float hx = g.hx;
     const uint32_t *lslots = slots + (size_t)f * frame_slots + g.slot_off;
+    __shared__ uint16_t s_bin2node[QT_INI_MAX];  // prefiltered path: list position of the initial node of every bin
+    const bool pre = LDS_KEYS && pre_aux != nullptr;
+    bool labelled = !pre;  // prefiltered path: no key carries a node id until the first pass has re-labelled them
+    if (pre) {
+        // k_qt_prefilter has filtered, compacted and counted: fetch the counts, pull the LDS share of the keys in, re-arm
+        int *laux = pre_aux + (size_t)f * QT_AUX_FRAME + level * QT_AUX_LEVEL;
+        if (tid == 0)
+            s_nk = laux[0];
+        for (int i = tid; i < 4 * n_ini; i += nt)
+            S.ccnt_next[i] = laux[1 + i];  // (bin, quadrant) counts; turned into the initial nodes' child counts below
+        __syncthreads();
+        for (int i = tid; i < 1 + 4 * n_ini; i += nt)
+            laux[i] = 0;
+        for (int c = tid; c < g.ncells; c += nt)
+            ccounts[c] = 0;
+        if (tid == 0)
+            *lcount = 0;
+        for (int b = tid; b < n_ini; b += nt)
+            S.sb[b] = S.ccnt_next[4 * b] + S.ccnt_next[4 * b + 1] + S.ccnt_next[4 * b + 2] + S.ccnt_next[4 * b + 3];
+        const int nk = min(s_nk, kcap);
+        for (int i = tid; i < nk; i += nt)
+            lkey[i] = dkey[i];
+    } else {
     for (int b = tid; b < n_ini; b += nt)
         S.sb[b] = 0;
     for (int c = tid; c < g.ncells; c += nt) {
@@ -1029,6 +1143,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             }
         }
     }
+    }  // !pre
     __syncthreads();  // dkey written by this workgroup only; visible after the barrier (same CU)
     const int nkeys = s_nk;
     if (tid == 0)
@@ -1041,6 +1156,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         for (int b = 0; b < n_ini; b++) {
             int c = S.sb[b];
             S.sa[b] = n;  // bin -> list position
+            if (pre)
+                s_bin2node[b] = (uint16_t)n;
             if (c > 0) {
                 bndA[n] = make_short4((short)(int)(hx * (float)b), 0, (short)(int)(hx * (float)(b + 1)),
                                           (short)(g.max_by - BORDER0));
@@ -1060,6 +1177,20 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     // never read them between the barrier that ends a pass and the barrier behind the next pass's sections.  They are
     // read here (the next write is two barriers away) and after the barrier behind the sections of every pass.
     int n_cur = s_n, phase_cur = s_phase, done_cur = s_done;
+    if (pre) {
+        // the child counts of the initial nodes are the prefilter's (bin, quadrant) counts, moved from bin order to list
+        // order (empty bins have no node); a node with one key is never expanded and counts nothing (as the sweep below)
+        int mine[4] = {0, 0, 0, 0};
+        const int b = tid;
+        const bool have = b < n_ini && S.sb[b] > 0;
+        if (have)
+            for (int q = 0; q < 4; q++)
+                mine[q] = S.sb[b] > 1 ? S.ccnt_next[4 * b + q] : 0;
+        __syncthreads();  // every count read before the array is rewritten in list order (n_ini <= QT_INI_MAX < nt)
+        if (have)
+            for (int q = 0; q < 4; q++)
+                S.ccnt_next[4 * S.sa[b] + q] = mine[q];
+    } else {
     for (int i = tid; i < 4 * n_ini; i += nt)
         S.ccnt_next[i] = 0;
     __syncthreads();
@@ -1085,12 +1216,21 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             }
         }
     }
+    }  // !pre
     __syncthreads();
     {
         int *t = S.ccnt;
         S.ccnt = S.ccnt_next;
         S.ccnt_next = t;
     }
+    // node of key i: its label, or (prefiltered path, before the first re-labelling sweep) the initial node of its bin
+    auto node_of = [&](int i, uint32_t key) -> int {
+        if (labelled)
+            return node_at(i);
+        int b = (int)((float)key_x(key) / hx);
+        b = min(max(b, 0), n_ini - 1);
+        return (int)s_bin2node[b];
+    };
 
     QT_MARK(2)
     // ---- passes
@@ -1271,7 +1411,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             for (int u = 0; u < QT_ILP; u++) {
                 const int i = min(i0 + u * nt, nkeys - 1);
                 key[u] = key_at(i);
-                nd[u] = node_at(i);
+                nd[u] = node_of(i, key[u]);
             }
 #pragma unroll
             for (int u = 0; u < QT_ILP; u++)
@@ -1286,6 +1426,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             }
         }
         __syncthreads();
+        labelled = true;  // every key carries the id of its node in the new list
         {
             int *t = S.ccnt;
             S.ccnt = S.ccnt_next;
@@ -1318,7 +1459,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         for (int u = 0; u < QT_ILP; u++) {
             const int i = min(i0 + u * nt, nkeys - 1);
             key[u] = key_at(i);
-            nd[u] = node_at(i);
+            nd[u] = node_of(i, key[u]);
         }
 #pragma unroll
         for (int u = 0; u < QT_ILP; u++) {
@@ -1823,6 +1964,9 @@ struct orbgpu_extractor {
     // device state
     DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt, d_ctab, d_bcol;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
+    DevBuf d_qtaux;  // k_qt_prefilter -> k_quadtree<true> (single frames): QT_AUX_FRAME ints per frame, < QT_BATCH_MIN frames
+    bool qt_prefilter = false;  // every level has <= QT_INI_MAX initial nodes
+    int max_slots_level = 0;
     DevBuf d_in, d_kps, d_desc, d_nout;  // staging for the host entry points
     DevBuf d_dbg;
     hipStream_t stream = nullptr;
@@ -1841,6 +1985,7 @@ struct orbgpu_extractor {
     hipEvent_t pipe_signal[8] = {};  // the same for an orbgpu_pipeline that owns this handle (stagger of its parts)
     bool counters_dirty = false;  // the cell counters may hold counts no k_quadtree has consumed
     bool force_batch_quadtree = false;  // ORBGPU_DEBUG_QT_BATCH: the batch variant of k_quadtree for any batch size (tests)
+    bool qt_no_prefilter = false;  // ORBGPU_DEBUG_QT_NOPRE: single frames filter their keys inside k_quadtree<true> (tests, A/B)
     int qt_keys_hook = -1;  // ORBGPU_DEBUG_QT_KEYS (read at creation): LDS key share of k_quadtree<true>; -1 = as many as fit
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
@@ -2192,6 +2337,10 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     e->ncap = ncap;
     e->qt_lds = qt_lds;
     e->qt_kcap = qt_kcap;
+    e->max_slots_level = max_slots_level;
+    e->qt_prefilter = !e->qt_no_prefilter;
+    for (int l = 0; l < nl; l++)
+        e->qt_prefilter = e->qt_prefilter && geom[l].n_ini <= QT_INI_MAX;
     int max_kp = 0;
     for (int l = 0; l < nl; l++)
         max_kp += geom[l].sel_cap - 1;
@@ -2219,6 +2368,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_sel, sizeof(uint32_t) * (size_t)sel_off * B);
     RSV(e->d_nsel, sizeof(int) * nl * B);
     RSV(e->d_ncand, sizeof(int) * nl * B);
+    RSV(e->d_qtaux, sizeof(int) * QT_AUX_FRAME * QT_BATCH_MIN);
 #undef RSV
     ORBGPU_HIP_TRY(hipMemcpy(e->d_geom.p, geom.data(), sizeof(LevelGeom) * nl, hipMemcpyHostToDevice));
     ORBGPU_HIP_TRY(hipMemcpy(e->d_cells.p, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
@@ -2254,6 +2404,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
     // cell counters start at zero; k_quadtree re-arms them after reading
     ORBGPU_HIP_TRY(hipMemset(e->d_cellcnt.p, 0, sizeof(int) * (cells.size() + ORBGPU_MAX_LEVELS) * B));
+    ORBGPU_HIP_TRY(hipMemset(e->d_qtaux.p, 0, e->d_qtaux.bytes));  // likewise (k_quadtree<true> re-arms what it reads)
     // The attribute belongs to the function (per device), not to this handle: another handle with a larger geometry may
     // have raised it and still launch, so it is set once to the most the kernel can ever be launched with here
     // (qt_lds <= 159 KB and qt_lds + 6 qt_kcap <= 150 KB are enforced above; the static part is < 200 B).
@@ -2332,8 +2483,10 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->frame_pyr, dg, e->blur_geom);
     END(ST_BLUR, st);
     BEGIN(ST_FAST, st);
-    if (e->counters_dirty)  // a previous call enqueued the FAST pass but not the quadtree that re-arms the counters
+    if (e->counters_dirty) {  // a previous call enqueued the FAST pass but not the quadtree that re-arms the counters
         ORBGPU_HIP_TRY(hipMemsetAsync(e->d_cellcnt.p, 0, e->d_cellcnt.bytes, st));
+        ORBGPU_HIP_TRY(hipMemsetAsync(e->d_qtaux.p, 0, e->d_qtaux.bytes, st));
+    }
     e->counters_dirty = true;
     {
         const int t_ini = std::max(e->prm.ini_th_fast, 1), t_min = std::max(e->prm.min_th_fast, 1);
@@ -2350,13 +2503,20 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                            e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
-                           e->ncap, std::max(e->prm.ini_th_fast, 1), 0, qt_dbg());
-    else
+                           e->ncap, std::max(e->prm.ini_th_fast, 1), 0, qt_dbg(), (int *)nullptr);
+    else {
+        // the filtering / counting sweep over the stored keys of every level first, spread over the device
+        if (e->qt_prefilter)
+            hipLaunchKernelGGL(k_qt_prefilter, dim3(std::min((e->max_slots_level + QT_PRE_KEYS - 1) / QT_PRE_KEYS, QT_PRE_GRID), nl, batch), dim3(256), 0,
+                               st, dg, (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
+                               e->d_dkey.as<uint32_t>(), e->d_qtaux.as<int>(), std::max(e->prm.ini_th_fast, 1));
         hipLaunchKernelGGL(k_quadtree<true>, dim3(batch, nl), dim3(w * h >= QT_LARGE_PIXELS ? QT_THREADS : QT_THREADS_SMALL), e->qt_lds + (size_t)e->qt_kcap * 6, st, dg,
                            e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
-                           e->ncap, std::max(e->prm.ini_th_fast, 1), e->qt_kcap, qt_dbg());
+                           e->ncap, std::max(e->prm.ini_th_fast, 1), e->qt_kcap, qt_dbg(),
+                           e->qt_prefilter ? e->d_qtaux.as<int>() : (int *)nullptr);
+    }
     ORBGPU_HIP_TRY(hipGetLastError());
     e->counters_dirty = false;
     END(ST_QUADTREE, st);
@@ -2412,6 +2572,7 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
     if (e->prm.max_batch < 1)
         e->prm.max_batch = 1;
     e->force_batch_quadtree = getenv("ORBGPU_DEBUG_QT_BATCH") != nullptr;
+    e->qt_no_prefilter = getenv("ORBGPU_DEBUG_QT_NOPRE") != nullptr;
     if (const char *q = getenv("ORBGPU_DEBUG_QT_KEYS"))  // test hook, read here like the others (configure() runs at the first extraction)
         e->qt_keys_hook = std::max(atoi(q), 0);
     if (const char *q = getenv("ORBGPU_DEBUG_FAST_QUEUE"))  // test hook: forces k_fast_detect's queue-full path
@@ -2437,7 +2598,7 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
     DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_rstrip, &e->d_rsel,
                       &e->d_rwt, &e->d_ctab, &e->d_bcol, &e->d_pyr,
                       &e->d_blur, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
-                      &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg};
+                      &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg, &e->d_qtaux};
     for (DevBuf *b : bufs)
         b->release();
     for (auto &x : e->ev)

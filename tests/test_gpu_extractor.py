@@ -355,6 +355,27 @@ def test_quadtree_keys_beyond_lds(gpu, oracle, w, h, nfeat, kcap, monkeypatch):
     assert len(oe.level_candidates(0)) > lds_keys, "level 0 must have keys beyond the LDS share"
 
 
+@pytest.mark.parametrize("w,h,nfeat", [(640, 480, 1000), (1280, 960, 2000), (1000, 200, 600)])
+def test_single_frame_quadtree_with_and_without_prefilter(gpu, oracle, w, h, nfeat, monkeypatch):
+    """Single frames filter / count their FAST keys in a device-wide kernel of its own (k_qt_prefilter) before the
+    quadtree workgroups start; ORBGPU_DEBUG_QT_NOPRE keeps that sweep inside k_quadtree<true>.  Both equal the oracle
+    (the wide image has five initial nodes per level: the bin -> node mapping of the prefiltered path)."""
+    from orb_slam2_map_amd.synth import Stream
+    imgs = [Stream(w, h, 77).frame(t)[0] for t in (0, 3)]
+    oe = oracle.Extractor(nfeat, 1.2, 8 if h >= 480 else 4)
+    for nopre in (False, True):
+        if nopre:
+            monkeypatch.setenv("ORBGPU_DEBUG_QT_NOPRE", "1")
+        ge = gpu.ORBextractor(nfeat, 1.2, 8 if h >= 480 else 4)
+        monkeypatch.delenv("ORBGPU_DEBUG_QT_NOPRE", raising=False)
+        for rep in range(2):
+            for img in imgs:  # alternating frames: the counters a call leaves behind must be clean for the next
+                gk, gd = ge(img)
+                ok, od = oe.extract(img)
+                check_stages(gpu, ge, oe, 0, oe.nlevels if hasattr(oe, "nlevels") else (8 if h >= 480 else 4), "%dx%d nopre %d" % (w, h, nopre))
+                assert_same_keypoints(gk, gd, ok, od, "%dx%d nopre %d rep %d" % (w, h, nopre, rep))
+
+
 def test_two_handles_share_the_quadtree_kernel(gpu, oracle, stream640, stream1280):
     """The dynamic-LDS limit of k_quadtree is a property of the kernel, not of a handle: a handle configured for a
     small geometry must not take away what a handle with a large one launches with."""
