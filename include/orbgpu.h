@@ -146,6 +146,11 @@ int orbgpu_extractor_graph_state(const orbgpu_extractor *h, int32_t *state);
 int orbgpu_extractor_debug_quadtree_config(const orbgpu_extractor *h, int32_t batch, int32_t *lds_keys, int32_t *threads,
                                            int32_t *lds_bytes);
 int orbgpu_extractor_set_profiling(orbgpu_extractor *h, int32_t enable);
+/* Throughput option for resident batches (no counterpart in the reference): the 7x7 blur (ORBextractor.cc:1085-1086;
+ * HBM-bound) runs on a stream owned by the handle next to the FAST pass (VALU-bound) and the quadtree, forked after the
+ * pyramid and joined in front of the descriptor stage.  Results are unchanged; with profiling on, the blur's stage time
+ * is the one measured on its own stream (it overlaps the "fast" / "quadtree" stage times). */
+int orbgpu_extractor_set_concurrent_blur(orbgpu_extractor *h, int32_t enable);
 /* Pipelining aid for callers that run other work next to an extraction (bench.py starts the matcher of the previous
  * batch there): `hip_event` (a hipEvent_t, or NULL to clear) is recorded on the launch stream of every later
  * orbgpu_extract_batch_device call right after stage `stage` (index as in orbgpu_extractor_stage_name). */

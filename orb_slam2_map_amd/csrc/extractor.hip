@@ -1985,6 +1985,10 @@ struct orbgpu_extractor {
     hipEvent_t pipe_signal[8] = {};  // the same for an orbgpu_pipeline that owns this handle (stagger of its parts)
     bool counters_dirty = false;  // the cell counters may hold counts no k_quadtree has consumed
     bool force_batch_quadtree = false;  // ORBGPU_DEBUG_QT_BATCH: the batch variant of k_quadtree for any batch size (tests)
+    // optional: the blur (HBM-bound) on a stream of the handle's own next to the FAST pass (VALU-bound) and the quadtree
+    bool concurrent_blur = false;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool qt_no_prefilter = false;  // ORBGPU_DEBUG_QT_NOPRE: single frames filter their keys inside k_quadtree<true> (tests, A/B)
     int qt_keys_hook = -1;  // ORBGPU_DEBUG_QT_KEYS (read at creation): LDS key share of k_quadtree<true>; -1 = as many as fit
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
@@ -2479,8 +2483,20 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     // follows it pays for the write-back of the blurred planes (k_describe 105 instead of 87 us behind it, k_orient 119
     // instead of 93), and FAST has bandwidth to spare.  (On a side stream next to the quadtree both were slower.)
     BEGIN(ST_BLUR, st);
-    hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
-                       e->frame_pyr, dg, e->blur_geom);
+    if (e->concurrent_blur) {
+        // fork: the side stream waits for the pyramid, blurs, and is joined in front of the descriptor stage
+        ORBGPU_HIP_TRY(hipEventRecord(e->ev_fork, st));
+        ORBGPU_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        if (prof)
+            ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 1], e->side));
+        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, e->side, pyr, blur,
+                           e->frame_pyr, dg, e->blur_geom);
+        if (prof)
+            ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 2], e->side));
+        ORBGPU_HIP_TRY(hipEventRecord(e->ev_join, e->side));
+    } else
+        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
+                           e->frame_pyr, dg, e->blur_geom);
     END(ST_BLUR, st);
     BEGIN(ST_FAST, st);
     if (e->counters_dirty) {  // a previous call enqueued the FAST pass but not the quadtree that re-arms the counters
@@ -2530,6 +2546,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        e->d_aux.as<KpAux>(), d_n_out, cap);
     END(ST_ORIENT, st);
     BEGIN(ST_DESCRIBE, st);
+    if (e->concurrent_blur)
+        ORBGPU_HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));  // join: the descriptors read the blurred planes
     hipLaunchKernelGGL(k_describe, dim3((std::min(cap, e->max_kp) + 7) / 8, batch), dim3(256), 0, st, blur,
                        e->frame_pyr, dg, e->d_aux.as<KpAux>(), d_n_out, cap, e->d_pattern.as<int8_t>(), d_desc);
     END(ST_DESCRIBE, st);
@@ -2610,6 +2628,12 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
         (void)hipGraphDestroy(e->graph);
     if (e->stream)
         (void)hipStreamDestroy(e->stream);
+    if (e->side)
+        (void)hipStreamDestroy(e->side);
+    if (e->ev_fork)
+        (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join)
+        (void)hipEventDestroy(e->ev_join);
     delete e;
     return ORBGPU_OK;
 }
@@ -3029,6 +3053,25 @@ int orbgpu_extractor_set_profiling(orbgpu_extractor *e, int32_t enable)
     e->profiling = enable != 0;  // the averaging window is kept: stage_times() reads and resets it
     return ORBGPU_OK;
 }
+int orbgpu_extractor_set_concurrent_blur(orbgpu_extractor *e, int32_t enable)
+{
+    ORBGPU_REQUIRE(e, "null argument");
+    int rc = select_device(e->prm.device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    if (enable && !e->side) {
+        ORBGPU_HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        ORBGPU_HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        ORBGPU_HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    if ((enable != 0) != e->concurrent_blur) {
+        ORBGPU_HIP_TRY(hipDeviceSynchronize());  // nothing of the other schedule in flight; a captured graph bakes the schedule in
+        e->graph_key = 0;
+        e->prof_calls = 0;
+    }
+    e->concurrent_blur = enable != 0;
+    return ORBGPU_OK;
+}
 int orbgpu_extractor_graph_state(const orbgpu_extractor *e, int32_t *state)
 {
     ORBGPU_REQUIRE(e && state, "null argument");
@@ -3062,7 +3105,11 @@ int orbgpu_extractor_stage_times(orbgpu_extractor *e, float *ms)
         ORBGPU_HIP_TRY(hipEventSynchronize(evs[ST_COUNT]));  // the last boundary event of the profiled call
         for (int i = 0; i < ST_COUNT; i++) {
             float t = 0.f;
-            ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
+            if (i == ST_BLUR && e->concurrent_blur) {  // timed on the side stream it ran on
+                ORBGPU_HIP_TRY(hipEventSynchronize(evs[ST_COUNT + 2]));
+                ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[ST_COUNT + 1], evs[ST_COUNT + 2]));
+            } else
+                ORBGPU_HIP_TRY(hipEventElapsedTime(&t, evs[i], evs[i + 1]));
             ms[i] += t;
         }
     }

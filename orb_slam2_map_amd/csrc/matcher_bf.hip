@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -601,6 +602,7 @@ struct orbgpu_matcher {
     int max_pairs = 0, cap = 0;
     DevBuf d_topk, d_sweeps;
     int last_pairs = 0;
+    int resolve_threads = 1024;  // workgroup size of k_bf_resolve (ORBGPU_DEBUG_BF_RESOLVE_THREADS: 256 / 512 / 1024)
 };
 
 extern "C" {
@@ -620,6 +622,11 @@ int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orb
     m->device_id = device_id;
     m->max_pairs = max_pairs;
     m->cap = cap;
+    if (const char *q = getenv("ORBGPU_DEBUG_BF_RESOLVE_THREADS")) {
+        const int v = atoi(q);
+        if (v == 256 || v == 512 || v == 1024)
+            m->resolve_threads = v;
+    }
     const size_t P = (size_t)max_pairs;
     if ((rc = m->d_topk.reserve(sizeof(uint32_t) * std::max<size_t>(P * BF_MIN_SPLIT, BF_MAX_SPLIT) * cap * BF_TOPK)) != ORBGPU_OK ||
         (rc = m->d_sweeps.reserve(sizeof(int) * P)) != ORBGPU_OK) {
@@ -685,7 +692,7 @@ static int match_batch_device(orbgpu_matcher *m, int32_t pairs, int32_t cap, con
     // claim / match / queue tables (16 B per row) + the B descriptors (32 B per row) when both fit in LDS
     const int stage_b = (size_t)48 * cap <= BF_RESOLVE_MAX_LDS ? 1 : 0;
     const size_t lds = (size_t)(stage_b ? 48 : 16) * cap;
-    hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(1024), lds, st, cap, d_desc_a, d_valid_a, d_na,
+    hipLaunchKernelGGL(k_bf_resolve, dim3(pairs), dim3(m->resolve_threads), lds, st, cap, d_desc_a, d_valid_a, d_na,
                        d_desc_b, d_nb, topk, th_low, nnratio, reinterpret_cast<const uint8_t *>(d_angle_a),
                        reinterpret_cast<const uint8_t *>(d_angle_b), angle_stride, check_orientation, d_match_b,
                        d_nmatches, m->d_sweeps.as<int>(), stage_b, nsplit, d_node_a, d_node_b);

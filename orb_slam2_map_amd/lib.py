@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_get_inv_scale_factors", "orbgpu_extractor_get_sigma2", "orbgpu_extractor_get_inv_sigma2",
     "orbgpu_extractor_get_quotas", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
     "orbgpu_extract_batch_device", "orbgpu_extractor_get_pyramid_level", "orbgpu_extractor_debug_read",
-    "orbgpu_extractor_graph_state", "orbgpu_extractor_debug_quadtree_config", "orbgpu_extractor_set_profiling", "orbgpu_extractor_set_stage_signal", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
+    "orbgpu_extractor_graph_state", "orbgpu_extractor_debug_quadtree_config", "orbgpu_extractor_set_profiling", "orbgpu_extractor_set_concurrent_blur", "orbgpu_extractor_set_stage_signal", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
     "orbgpu_extractor_stage_times",
     "orbgpu_pipeline_create", "orbgpu_pipeline_destroy", "orbgpu_pipeline_parts", "orbgpu_pipeline_part",
     "orbgpu_pipeline_extract_device", "orbgpu_pipeline_wait",
@@ -356,6 +356,9 @@ class ORBextractor:
         self.L.orbgpu_extractor_debug_quadtree_config.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         check(self.L.orbgpu_extractor_debug_quadtree_config(self.h, batch, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def set_concurrent_blur(self, on):
+        check(self.L.orbgpu_extractor_set_concurrent_blur(self.h, int(on)))
 
     def set_profiling(self, on):
         check(self.L.orbgpu_extractor_set_profiling(self.h, int(on)))

@@ -85,3 +85,39 @@ def test_pipeline_wait_event_and_errors():
         pl.extract_batch_device(0, batch, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr())
     with pytest.raises(G.OrbGpuError):
         G.ExtractorPipeline(500, max_batch=4, parts=0)
+
+
+def test_concurrent_blur_gives_the_same_frames(gpu, stream640):
+    """orbgpu_extractor_set_concurrent_blur: the blur on a stream of the handle's own, forked after the pyramid and joined in
+    front of the descriptor stage -- identical key points and descriptors, with and without profiling events, and after
+    switching back."""
+    torch = pytest.importorskip("torch")
+    B, w, h = 8, 640, 480
+    imgs = torch.from_numpy(stream640.gray_batch(20, B)).cuda()
+    ge = gpu.ORBextractor(1000, max_batch=B)
+    cap = ge.max_keypoints(w, h)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        kps = torch.zeros((B, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device="cuda")
+        nout = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ge.extract_batch_device(imgs.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), s)
+        torch.cuda.synchronize()
+        return kps.cpu().numpy(), desc.cpu().numpy(), nout.cpu().numpy()
+    ref = run()
+    assert ref[2].min() > 500
+    ge.set_concurrent_blur(True)
+    for prof in (False, True, False):
+        ge.set_profiling(prof)
+        for _ in range(3):
+            got = run()
+            assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+    ge.set_profiling(True)
+    run()
+    t = ge.stage_times()
+    assert t["blur"] > 0 and t["fast"] > 0
+    ge.set_profiling(False)
+    ge.set_concurrent_blur(False)
+    got = run()
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
