@@ -104,7 +104,7 @@ def test_concurrent_blur_gives_the_same_frames(gpu, stream640):
         nout = torch.zeros(B, dtype=torch.int32, device="cuda")
         ge.extract_batch_device(imgs.data_ptr(), B, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), s)
         torch.cuda.synchronize()
-        return kps.cpu().numpy(), desc.cpu().numpy(), nout.cpu().numpy()
+        return kps.cpu().numpy().view(np.int32), desc.cpu().numpy(), nout.cpu().numpy()  # (class_id = -1 is a NaN as float)
     ref = run()
     assert ref[2].min() > 500
     ge.set_concurrent_blur(True)
