@@ -61,7 +61,7 @@ STAGE_KERNELS = {"pyramid": ["k_border0_fast"] + ["k_resize_fast"] * 7, "fast": 
                  "blur": ["k_blur"], "describe": ["k_describe"]}
 
 
-PMC_FILES = ("r02_pmc_traffic.json",)  # newest first (the round-1 file predates the fused FAST kernel)
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest first (the round-1 file predates the fused FAST kernel)
 
 
 def pmc_traffic(stage, frames_per_launch):
@@ -440,6 +440,12 @@ def main():
         per_stage = {k: {"ms": round(v, 4),
                          "GB/s": round(algorithmic_bytes(k, n_kp, n_cand) * B / (max(v, 1e-6) * 1e-3) / 1e9, 1)}
                      for k, v in stage_ms.items()}
+        # next to the algorithmic rate: what the stage really moved through HBM (committed PMC bytes per frame, scaled to
+        # this launch) over its live duration -- the gather stages read whole planes line by line, far more than N x 1321 B
+        for k in per_stage:
+            tb, _ = pmc_traffic(k, B)
+            if tb:
+                per_stage[k]["hbm_traffic_GB/s_scaled_pmc"] = round(tb / (max(stage_ms[k], 1e-6) * 1e-3) / 1e9, 1)
         traffic, traffic_src = pmc_traffic(dom, B)
         ext_bytes = sum(algorithmic_bytes(k, n_kp, n_cand) for k in ("pyramid", "fast", "blur", "orient", "describe"))
         # one part: the six stages follow each other, their sum is the extraction time of a step.  Several parts: the
