@@ -82,10 +82,10 @@ def pmc_traffic(stage, frames_per_launch):
 
 def valu_issue(stage, frames_per_launch, ms_per_launch):
     """Second bound of the dominant kernel (it is VALU-issue bound, not HBM bound): VALU wave-instructions per launch from
-    the committed SQ counter pass (profiles/r02_pmc_sq.json, rocprofv3 --pmc SQ_INSTS_VALU ... at B = 256), scaled to
+    the committed SQ counter pass (profiles/r03_pmc_sq.json, rocprofv3 --pmc SQ_INSTS_VALU ... at B = 256), scaled to
     this launch, against the live launch duration; the ceiling is tools/ubench/valu_rate (profiles/r02_valu_rate.txt)."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq.json")))
         insts = sum(j["kernels"][kn]["valu_insts_per_launch"] for kn in j["kernels"]
                     if kn.split("<")[0] in STAGE_KERNELS[stage]) / 256.0 * frames_per_launch
         cyc = 1024 * ms_per_launch * 1e-3 * 2.4e9 / insts  # 1024 SIMDs at the nominal 2.4 GHz, as in r02_valu_rate.txt
@@ -96,7 +96,7 @@ def valu_issue(stage, frames_per_launch, ms_per_launch):
                         "cost is 4.3 cycles",
                 "scaled": "instruction count SCALED from the committed B = 256 counter pass to %d frames per launch; the launch "
                           "duration is live" % frames_per_launch,
-                "source": "profiles/r02_pmc_sq.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE), profiles/r02_valu_rate.txt"}
+                "source": "profiles/r03_pmc_sq.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE), profiles/r02_valu_rate.txt"}
     except Exception:
         return None
 
