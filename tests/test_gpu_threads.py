@@ -1,0 +1,94 @@
+"""Threading contract of the boundary: handles are not shared between threads,
+distinct handles are re-entrant (the reference runs two extractors concurrently in stereo, Frame.cc:78-81), and the
+stateless matcher entry points are called concurrently from Tracking, LocalMapping and LoopClosing threads -- each host
+thread gets its own workspace and stream.  Several Python threads (ctypes releases the GIL inside the library) hammer
+their own handles and the stateless entry points at the same time; every result equals the single-threaded one."""
+import threading
+
+import numpy as np
+import pytest
+
+import scenario
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_threads_own_handles_and_stateless_matchers(gpu, oracle, stream640):
+    st = stream640
+    nthreads, rounds = 4, 6
+    frames = [st.frame(t) for t in range(40, 40 + nthreads + 1)]
+    # single-threaded references (GPU path, itself checked against the oracle elsewhere; frame 0 also against the oracle here)
+    ref_ext, ref_bf, ref_proj = [], [], []
+    ge = gpu.ORBextractor(1000)
+    for g, _, _ in frames:
+        ref_ext.append(ge(g))
+    ok, od = oracle.Extractor(1000).extract(frames[0][0])
+    assert ref_ext[0][0].tobytes() == ok.tobytes() and np.array_equal(ref_ext[0][1], od)
+    m = gpu.ORBmatcher(0.7, True)
+    sf = np.asarray(ge.GetScaleFactors(), np.float32)
+    Tcw = scenario.rigid()
+    rng = np.random.default_rng(3)
+    probs = []
+    for i in range(nthreads):
+        (ka, da), (kb, db) = ref_ext[i], ref_ext[i + 1]
+        ref_bf.append(m.MatchBruteForce(da, ka["angle"], db, kb["angle"]))
+        # a projection problem per thread: frame i's key points as map points seen from frame i + 1
+        (px, py), (ox, oy) = st.offset(40 + i), st.offset(41 + i)
+        P, _ = scenario.world_points_from_prev(ka, frames[i][2], (ox - px, oy - py), st, Tcw, rng)
+        mp = scenario.local_map(oracle, st, Tcw, P, da, ka["octave"], sf, rng, obs_zero_frac=0.1)
+        of = scenario.make_frame(oracle, kb, db, frames[i + 1][2], st, sf)
+        gf = gpu.Frame(of.kp_x, of.kp_y, of.octave, of.angle, of.u_right, of.desc, float(of.max_x), float(of.max_y), of.scale_factors)
+        k0 = np.full(of.n, -1, np.int32)
+        want = oracle.search_by_projection(of, mp, 3.0, 0.8, k0)
+        got = gpu.ORBmatcher(0.8, True).SearchByProjection(gf, mp, 3.0, k0)
+        assert got[0] == want[0] and np.array_equal(got[1], want[1])
+        probs.append((gf, mp, k0))
+        ref_proj.append(want)
+    errors = []
+    barrier = threading.Barrier(nthreads)
+
+    def worker(i):
+        try:
+            ext = gpu.ORBextractor(1000)          # a handle of this thread's own
+            mine = gpu.ORBmatcher(0.7, True)
+            proj = gpu.ORBmatcher(0.8, True)
+            tbl = gpu.MapPointTable()
+            gf, mp, k0 = probs[i]
+            ids = np.arange(len(mp["level"]), dtype=np.int64) * 5 + i
+            tbl.upsert(ids, mp_world[i], mp["normal"], mp["min_dist"], mp["max_dist"], mp["desc"], mp["obs_pos"].astype(np.int32))
+            tbl.set_bad(ids[mp["bad"] != 0])
+            dfr = gpu.DeviceFrame().upload(gf)
+            barrier.wait()
+            for r in range(rounds):
+                k, d = ext(frames[i][0] if r % 2 == 0 else frames[i + 1][0])
+                want = ref_ext[i] if r % 2 == 0 else ref_ext[i + 1]
+                assert k.tobytes() == want[0].tobytes() and np.array_equal(d, want[1]), "extraction differs (thread %d round %d)" % (i, r)
+                (ka, da), (kb, db) = ref_ext[i], ref_ext[i + 1]
+                n, mb = mine.MatchBruteForce(da, ka["angle"], db, kb["angle"])
+                assert n == ref_bf[i][0] and np.array_equal(mb, ref_bf[i][1]), "BF match differs (thread %d round %d)" % (i, r)
+                n, k2 = proj.SearchByProjection(gf, mp, 3.0, k0)
+                assert n == ref_proj[i][0] and np.array_equal(k2, ref_proj[i][1]), "projection differs (thread %d round %d)" % (i, r)
+                n, k3 = gpu.search_local_points_table(dfr, tbl, ids, None, 0, 0, 0, 0, 0, 0, 3.0, 0.8, scratch=mp)
+                assert n == ref_proj[i][0] and np.array_equal(k3, ref_proj[i][1]), "table search differs (thread %d round %d)" % (i, r)
+        except Exception as ex:  # noqa: BLE001 -- reported by the main thread
+            errors.append("thread %d: %r" % (i, ex))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    mp_world = []
+    rng = np.random.default_rng(3)
+    for i in range(nthreads):  # the same world points as above (same generator sequence)
+        ka = ref_ext[i][0]
+        (px, py), (ox, oy) = st.offset(40 + i), st.offset(41 + i)
+        P, _ = scenario.world_points_from_prev(ka, frames[i][2], (ox - px, oy - py), st, Tcw, rng)
+        scenario.local_map(oracle, st, Tcw, P, ref_ext[i][1], ka["octave"], sf, rng, obs_zero_frac=0.1)  # advance the generator alike
+        mp_world.append(P)
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in ts)
