@@ -262,6 +262,7 @@ struct orbgpu_mappoint_table {
     DevBuf d_stage;     // its device twin
     DevBuf g_block;     // the call's gathered local map + translation tables + results
     DevBuf pos_of_row;  // [cap] list position of every table row in the current call
+    ProjWorkspace *pws = nullptr;  // the matchers' scratch for calls over this table (they run on `stream`)
     TableDev dev() const
     {
         return TableDev{world_pos.as<float>(), normal.as<float>(), min_dist.as<float>(), max_dist.as<float>(),
@@ -393,6 +394,12 @@ int orbgpu_mappoint_table_create(int32_t device_id, int32_t initial_rows, orbgpu
         return ORBGPU_ENOMEM;
     }
     t->device_id = device_id;
+    t->pws = proj_workspace_new();
+    if (!t->pws) {
+        set_error("out of host memory");
+        delete t;
+        return ORBGPU_ENOMEM;
+    }
     hipError_t he = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
         set_error("hipStreamCreate: %s", hipGetErrorString(he));
@@ -421,6 +428,7 @@ int orbgpu_mappoint_table_destroy(orbgpu_mappoint_table *t)
     for (DevBuf *b : bufs)
         b->release();
     t->stage.release();
+    proj_workspace_delete(t->pws);
     delete t;
     return ORBGPU_OK;
 }
@@ -783,6 +791,7 @@ int orbgpu_search_local_points_table(const orbgpu_frame *fr, orbgpu_mappoint_tab
     // counts layout: [0] matches, [1] bad levels, [2] unknown list ids, [3] unknown key-point ids
     int32_t *d_counts2 = d_cnt;  // the matcher zeroes and fills [0], [1]; [2], [3] were written before it runs ...
     // ... so they must survive its memset of the first two words only (it clears exactly 2 ints)
+    ProjWorkspaceScope own_workspace(t->pws);
     if ((rc = search_local_points_device_impl(&fv, &tv, scratch ? &sd : nullptr, Tcw, fx, fy, cx, cy, mbf, log_scale_factor,
                                               cos_limit, th, nnratio, (int32_t *)(g + r_k2m), d_counts2,
                                               want_track ? &trk : nullptr, t->device_id, st)) != ORBGPU_OK)
@@ -875,6 +884,7 @@ int orbgpu_search_by_projection_last_table(const orbgpu_frame *cur, const float 
     frame_dev_view(last, &lv_);
     orbgpu_device_lastframe_view lv{last->cap, lv_.n, lv_.kps, g + g_has, last_outlier ? d + i_out : nullptr, g + g_ob,
                                     (const float *)(g + g_wp), g + g_ds};
+    ProjWorkspaceScope own_workspace(t->pws);
     if ((rc = orbgpu_search_by_projection_last_device(&cv_, cur_Tcw, &lv, last_Tcw, fx, fy, cx, cy, mbf, mb, th, mono,
                                                       check_orientation, (int32_t *)(g + r_k2m), d_cnt, t->device_id, st)) !=
         ORBGPU_OK)

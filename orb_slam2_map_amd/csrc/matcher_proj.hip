@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <new>
 #include <cstring>
 #include <cmath>
 #include <vector>
@@ -624,9 +625,29 @@ struct ProjWorkspace {
     }
 };
 
+// A caller that brings its own workspace (the MapPoint table: its calls run on the table's stream and must not share
+// buffers with asynchronous calls the same thread has in flight on another stream) installs it for the duration of a call.
+static thread_local ProjWorkspace *t_ws_override = nullptr;
+ProjWorkspace *proj_workspace_new() { return new (std::nothrow) ProjWorkspace(); }
+void proj_workspace_delete(ProjWorkspace *ws)
+{
+    if (!ws)
+        return;
+    DevBuf *bufs[] = {&ws->kp_x,  &ws->kp_y,     &ws->kp_octave, &ws->u_right,    &ws->desc,  &ws->cell_start, &ws->cell_items,
+                      &ws->kp_angle, &ws->queries, &ws->row_desc, &ws->row_angle, &ws->claim_init, &ws->topk, &ws->match,
+                      &ws->slow,  &ws->k2m,      &ws->out,       &ws->inv_sigma2, &ws->tri,   &ws->problems,   &ws->sweeps};
+    for (DevBuf *b : bufs)
+        b->release();
+    if (ws->stream)
+        (void)hipStreamDestroy(ws->stream);
+    delete ws;
+}
+ProjWorkspaceScope::ProjWorkspaceScope(ProjWorkspace *ws) : prev_(t_ws_override) { t_ws_override = ws; }
+ProjWorkspaceScope::~ProjWorkspaceScope() { t_ws_override = prev_; }
+
 static int workspace(int device_id, ProjWorkspace **out)
 {
-    ProjWorkspace &ws = per_device_workspace<ProjWorkspace>(device_id);  // (the caller has selected device_id)
+    ProjWorkspace &ws = t_ws_override ? *t_ws_override : per_device_workspace<ProjWorkspace>(device_id);  // (the caller has selected device_id)
     if (ws.device != device_id) {  // first use of this device by this thread
         ws.device = device_id;
         hipError_t e = hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking);

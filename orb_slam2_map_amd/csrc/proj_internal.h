@@ -12,6 +12,21 @@ struct ScratchDev {  // device arrays [m]: MapPoint.h:91-96 as filled by Frame::
     const float *view_cos, *proj_x, *proj_y, *proj_xr;
 };
 
+// a projection-matcher workspace owned by the caller instead of the calling thread (see matcher_proj.hip)
+struct ProjWorkspace;
+ProjWorkspace *proj_workspace_new();
+void proj_workspace_delete(ProjWorkspace *ws);
+class ProjWorkspaceScope {
+  public:
+    explicit ProjWorkspaceScope(ProjWorkspace *ws);
+    ~ProjWorkspaceScope();
+    ProjWorkspaceScope(const ProjWorkspaceScope &) = delete;
+    ProjWorkspaceScope &operator=(const ProjWorkspaceScope &) = delete;
+
+  private:
+    ProjWorkspace *prev_;
+};
+
 int validate_frame(const orbgpu_frame_view *f);  // consistency of a host frame view (counts, grid CSR)
 
 int search_local_points_device_impl(const orbgpu_device_frame_view *f, const orbgpu_device_mappoint_table *mp,
