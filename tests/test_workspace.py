@@ -19,5 +19,5 @@ def test_stateless_entry_points_use_the_lookup():
     for name in ("matcher_bf.hip", "matcher_proj.hip"):
         src = open(os.path.join(ROOT, "orb_slam2_map_amd", "csrc", name)).read()
         assert "per_device_workspace<" in src
-        assert "static thread_local Ws" not in src and "static thread_local ProjWorkspace" not in src
+        assert "static thread_local Ws ws" not in src and "static thread_local ProjWorkspace ws" not in src
         assert "static thread_local bool attr_set" not in src  # function attributes are per device as well
