@@ -9,7 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SWEEPS = ["fuzz_extract", "fuzz_projection", "fuzz_proj_variants", "fuzz_bf", "fuzz_bow", "fuzz_m6", "fuzz_cloud"]
+SWEEPS = ["fuzz_extract", "fuzz_projection", "fuzz_proj_variants", "fuzz_table", "fuzz_bf", "fuzz_bow", "fuzz_m6", "fuzz_cloud"]
 
 
 @pytest.mark.gpu

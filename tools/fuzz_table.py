@@ -1,0 +1,163 @@
+"""Randomised parity sweep of the MapPoint-table flavours of the per-frame matchers against the oracle: random local maps
+(1..6 earlier frames, shuffled visiting order), sparse random ids in a table that holds more points than a call lists and
+grows while the sweep runs, host-side skips, existing associations to list / observed / unobserved outside points, both
+flavours (mTrack* from the host, isInFrustum on the device), later edits (set_bad, set_observations, descriptor updates),
+and SearchByProjection(Cur, Last) with random poses, outliers and missing map points.
+    python tools/fuzz_table.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from orb_slam2_map_amd import lib as G
+from oracle import oracle_py as O
+import scenario
+import test_gpu_matcher_proj as T
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def gframe(of):
+    return G.Frame(of.kp_x, of.kp_y, of.octave, of.angle, of.u_right, of.desc, float(of.max_x), float(of.max_y), of.scale_factors)
+
+
+def fail(what, cfg, a, b):
+    print("FAIL", what, cfg, a, b)
+    sys.exit(1)
+
+
+t0, n_local, n_last = time.time(), 0, 0
+tbl = G.MapPointTable(initial_rows=int(rng.choice([0, 64, 5000])))  # one table for the whole sweep: it keeps growing
+next_id = 0
+while time.time() - t0 < budget:
+    w, h, nfeat = [(640, 480, 1000), (1280, 960, 2000), (640, 480, 500), (752, 480, 1500)][int(rng.integers(0, 4))]
+    nprev = int(rng.integers(1, 7))
+    seed = int(rng.integers(0, 1 << 30))
+    obs0 = float(rng.choice([0.0, 0.1, 0.5]))
+    st, Tcw, gf, of, mp, wp, dsc, octv, ang, cur_k = T.build_c3(G, O, w, h, nfeat, nprev, seed, obs_zero_frac=obs0)
+    m = len(wp)
+    if rng.integers(0, 2):
+        perm = rng.permutation(m)
+        mp = {k: (np.ascontiguousarray(v[perm]) if isinstance(v, np.ndarray) and len(v) == m else v) for k, v in mp.items()}
+        wp = np.ascontiguousarray(wp[perm])
+    # ids: fresh sparse numbers; the scenario's points + some outside points go into the (shared, growing) table
+    extra = int(rng.integers(2, 200))
+    stride = int(rng.choice([1, 7, 7919, 1 << 33]))
+    ids_all = next_id + rng.permutation(3 * (m + extra))[:m + extra].astype(np.int64) * stride + int(rng.integers(0, 5))
+    next_id = int(ids_all.max()) + 10  # ids never repeat across the scenarios of a sweep
+    ids = ids_all[:m]
+    x_obs = rng.integers(0, 2, extra).astype(np.int32)
+    order = rng.permutation(m + extra)
+    A = {"world_pos": np.concatenate([wp, rng.normal(0, 2, (extra, 3)).astype(np.float32)]),
+         "normal": np.concatenate([mp["normal"], np.zeros((extra, 3), np.float32)]),
+         "min_dist": np.concatenate([mp["min_dist"], np.zeros(extra, np.float32)]),
+         "max_dist": np.concatenate([mp["max_dist"], np.zeros(extra, np.float32)]),
+         "desc": np.concatenate([mp["desc"], rng.integers(0, 256, (extra, 32), dtype=np.uint8)]),
+         "n_obs": np.concatenate([mp["obs_pos"].astype(np.int32) * int(rng.integers(1, 5)), x_obs])}
+    chunk = int(rng.choice([300, 3000, 100000]))
+    for a in range(0, m + extra, chunk):
+        sel = order[a:a + chunk]
+        tbl.upsert(ids_all[sel], A["world_pos"][sel], A["normal"][sel], A["min_dist"][sel], A["max_dist"][sel], A["desc"][sel],
+                   A["n_obs"][sel])
+    tbl.set_bad(ids[mp["bad"] != 0])
+    cfg = dict(w=w, h=h, nfeat=nfeat, nprev=nprev, seed=seed, obs0=obs0, m=m, extra=extra, stride=stride, rows=tbl.rows())
+    fx, fy, cx, cy, bf = (float(v) for v in (st.fx, st.fy, st.cx, st.cy, st.bf))
+    log_sf = float(np.log(np.float32(np.asarray(of.scale_factors, np.float32)[1])))
+    dfr = G.DeviceFrame().upload(gframe(of))
+    for rep in range(2):
+        k0 = np.full(of.n, -1, np.int32)
+        kp_ids = np.full(of.n, -1, np.int64)
+        if rng.integers(0, 3):
+            pre = rng.choice(of.n, int(rng.integers(1, of.n // 2)), replace=False)
+            kind = rng.integers(0, 3, len(pre))
+            to_list = pre[kind == 0]
+            k0[to_list] = rng.integers(0, m, len(to_list))
+            kp_ids[to_list] = ids[k0[to_list]]
+            for j in pre[kind != 0]:
+                x = int(rng.integers(0, extra))
+                kp_ids[j] = ids_all[m + x]
+                k0[j] = -2 if x_obs[x] else -1
+        skip = (rng.random(m) < rng.choice([0.0, 0.05, 0.5])).astype(np.uint8) if rng.integers(0, 2) else None
+        mpo = dict(mp)
+        if skip is not None:
+            mpo["bad"] = (mp["bad"] | skip).astype(np.uint8)
+        th, ratio = float(rng.choice([1.0, 3.0, 5.0, 8.0])), float(rng.choice([0.6, 0.7, 0.8, 0.9]))
+        no, ko = O.search_by_projection(of, mpo, th, ratio, k0)
+        for flavour in ("scratch", "device"):
+            sc = mp if flavour == "scratch" else None
+            ng, kg = G.search_local_points_table(dfr, tbl, ids, Tcw, fx, fy, cx, cy, bf, log_sf, th, ratio, skip=skip, scratch=sc,
+                                                 kp_ids=kp_ids if (kp_ids >= 0).any() or rng.integers(0, 2) else None)
+            if ng != no or not np.array_equal(kg, ko):
+                fail("local " + flavour, dict(cfg, th=th, ratio=ratio), ng, no)
+            n_local += 1
+        # edits between the repetitions: some points go bad, some lose / gain observations, some get a new descriptor
+        if rep == 0:
+            e = rng.choice(m, int(rng.integers(1, max(2, m // 20))), replace=False)
+            mp = dict(mp)
+            mp["bad"] = mp["bad"].copy()
+            mp["bad"][e[:len(e) // 3]] = 1
+            tbl.set_bad(ids[e[:len(e) // 3]])
+            o = e[len(e) // 3:2 * len(e) // 3]
+            mp["obs_pos"] = mp["obs_pos"].copy()
+            mp["obs_pos"][o] ^= 1
+            tbl.set_observations(ids[o], mp["obs_pos"][o].astype(np.int32) * 2)
+            d = e[2 * len(e) // 3:]
+            mp["desc"] = mp["desc"].copy()
+            mp["desc"][d] = rng.integers(0, 256, (len(d), 32), dtype=np.uint8)
+            tbl.upsert(ids[d], desc=mp["desc"][d])
+    # SearchByProjection(Cur, Last): the scenario's first earlier frame as the last frame
+    if time.time() - t0 < budget:
+        from orb_slam2_map_amd.synth import Stream
+        n0 = int((octv.shape[0]) // nprev) if nprev else 0
+        ge = G.ORBextractor(nfeat, max_batch=2)
+        fr = [Stream(w, h, 1234).frame(11), Stream(w, h, 1234).frame(12)]
+        ks, ds = ge.extract_batch(np.stack([f[0] for f in fr]))
+        sf = np.asarray(ge.GetScaleFactors(), np.float32)
+        olast = scenario.make_frame(O, ks[0], ds[0], fr[0][2], st, sf)
+        ocur = scenario.make_frame(O, ks[1], ds[1], fr[1][2], st, sf)
+        nl, nc = olast.n, ocur.n
+        (px, py), (ox, oy) = st.offset(11), st.offset(12)
+        P, _ = scenario.world_points_from_prev(ks[0], fr[0][2], (ox - px, oy - py), st, Tcw, rng)
+        Tl = Tcw.copy()
+        Tl[2, 3] += float(rng.choice([0.0, 0.5, -0.5]))
+        mpd = ds[0].copy()
+        far = rng.random(nl) < 0.1
+        mpd[far] = rng.integers(0, 256, (int(far.sum()), 32), dtype=np.uint8)
+        last = {"has_mp": (rng.random(nl) < rng.choice([0.3, 0.8, 1.0])).astype(np.uint8),
+                "outlier": (rng.random(nl) < 0.05).astype(np.uint8),
+                "obs_pos": (rng.random(nl) >= obs0).astype(np.uint8), "world_pos": P, "desc": mpd,
+                "kp_octave": ks[0]["octave"], "kp_angle": ks[0]["angle"], "Tcw": Tl}
+        lids = next_id + rng.permutation(2 * nl + 4)[:nl + 2].astype(np.int64) * stride + 1
+        next_id = int(lids.max()) + 10
+        has = last["has_mp"] != 0
+        if has.any():
+            tbl.upsert(lids[:nl][has], world_pos=P[has], desc=mpd[has], n_obs=last["obs_pos"][has].astype(np.int32))
+        tbl.upsert(lids[nl:], n_obs=np.array([3, 0], np.int32))
+        k0 = np.full(nc, -1, np.int32)
+        cur_ids = np.full(nc, -1, np.int64)
+        if rng.integers(0, 2):
+            pre = rng.choice(nc, int(rng.integers(1, 100)), replace=False)
+            half = len(pre) // 2
+            k0[pre[:half]] = -2
+            cur_ids[pre[:half]] = lids[nl]
+            cur_ids[pre[half:]] = lids[nl + 1]
+        th, mono, ori = float(rng.choice([7.0, 15.0, 30.0])), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        no, ko = O.search_by_projection_last(ocur, Tcw, fx, fy, cx, cy, bf, bf / fx, last, th, mono, ori, k0)
+        dl, dc = G.DeviceFrame().upload(gframe(olast)), G.DeviceFrame().upload(gframe(ocur))
+        ng, kg = G.search_by_projection_last_table(dc, Tcw, dl, Tl, tbl, np.where(has, lids[:nl], -1), fx, fy, cx, cy, bf, bf / fx, th,
+                                                   mono, ori, last_outlier=last["outlier"] if rng.integers(0, 2) else None,
+                                                   cur_kp_ids=cur_ids)
+        if last["outlier"].any() and ng != no:  # (the outlier array is optional: without it the oracle must be asked again)
+            last2 = dict(last)
+            last2["outlier"] = np.zeros(nl, np.uint8)
+            no2, ko2 = O.search_by_projection_last(ocur, Tcw, fx, fy, cx, cy, bf, bf / fx, last2, th, mono, ori, k0)
+            if ng == no2 and np.array_equal(kg, ko2):
+                no, ko = no2, ko2
+        if ng != no or not np.array_equal(kg, ko):
+            fail("last", dict(cfg, th=th, mono=mono, ori=ori), ng, no)
+        n_last += 1
+print("fuzz ok: %d local-map searches, %d last-frame searches, %d table rows in %.0f s" % (n_local, n_last, tbl.rows(), time.time() - t0))
