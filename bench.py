@@ -428,6 +428,28 @@ def main():
 
     n_kp = float(n_host[1:].mean())
 
+    # What the opt-in schedule is worth on this box (informational, after the contract's timed region): the same loop with
+    # the blur of every extraction on a stream of the handle's own (orbgpu_extractor_set_concurrent_blur).
+    upside = None
+    if world == 1 and not args.no_secondary and P == 1 and not args.concurrent_blur and args.overlap_match and args.steps >= 10:
+        ext.set_concurrent_blur(True)
+        i0, nup = args.warmup + args.steps, 30
+        for i in range(3):
+            step(i0 + i)
+        flush_match()
+        torch.cuda.synchronize()
+        tu = time.perf_counter()
+        for i in range(nup):
+            step(i0 + 3 + i)
+        flush_match()
+        s_ext.wait_stream(s_match)
+        torch.cuda.synchronize()
+        tu = time.perf_counter() - tu
+        ext.set_concurrent_blur(False)
+        upside = {"concurrent_blur": {"frames_per_s": B * nup / tu, "ms_per_step": tu / nup * 1e3, "steps": nup,
+                                      "note": "bench.py --concurrent-blur makes it the timed schedule; not the default because "
+                                              "the dominant kernel's stage time then contains the blur running next to it"}}
+
     if rank == 0:
         # dominant kernel of the extraction pipeline + its roofline fraction
         # FAST survivors handed to the quadtree (first frame of the self-check batch); prices the NMS / quadtree rows
@@ -505,6 +527,8 @@ def main():
             out["roofline"]["practical_peak"] = {"copy_kernel_GB/s": copy_gbs, "frac_of_practical": ach / copy_gbs,
                                                  "what": "16 B/lane device-to-device copy, 1 GiB, read + write bytes"}
             out["secondary"] = {}
+            if upside:
+                out["secondary"]["c2_schedules"] = upside
             for name, fn in (("c3", workloads.c3), ("c3_batch", workloads.c3_batch), ("c4", workloads.c4)):
                 try:
                     r = fn(device_id=local_rank)
