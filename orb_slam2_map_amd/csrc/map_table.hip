@@ -14,6 +14,7 @@
 // rows when points are inserted, the device copy (patched slot by slot after every insert) serves the per-frame lookups.
 #include "common.h"
 #include "proj_internal.h"
+#include "id_hash.h"
 
 #include <algorithm>
 #include <climits>
@@ -23,12 +24,8 @@
 
 namespace orbgpu {
 
-constexpr int64_t MT_EMPTY = -1;
-
-__host__ __device__ __forceinline__ uint32_t mt_hash(int64_t id, int log2cap)
-{
-    return (uint32_t)(((uint64_t)id * 0x9E3779B97F4A7C15ull) >> (64 - log2cap));
-}
+constexpr int64_t MT_EMPTY = ID_HASH_EMPTY;
+__host__ __device__ __forceinline__ uint32_t mt_hash(int64_t id, int log2cap) { return id_hash_slot(id, log2cap); }
 
 __device__ __forceinline__ int mt_lookup(const int64_t *__restrict__ hkeys, const int32_t *__restrict__ hvals, int log2cap,
                                          int64_t id)
@@ -253,10 +250,9 @@ struct orbgpu_mappoint_table {
     hipStream_t stream = nullptr;
     int rows = 0, cap = 0;
     DevBuf world_pos, normal, min_dist, max_dist, desc, bad, obs, id;
-    std::vector<int64_t> hkeys;  // host copy of the id -> row hash
-    std::vector<int32_t> hvals;
+    IdHash hash;                 // host copy of the id -> row hash (id_hash.h)
     std::vector<int32_t> stamp;  // per row: last upsert call that touched it (duplicate ids inside one call are refused)
-    int log2cap = 0, call_no = 0;
+    int call_no = 0;
     DevBuf d_hkeys, d_hvals;
     Pinned stage;       // host staging of a call's inputs / outputs
     DevBuf d_stage;     // its device twin
@@ -283,29 +279,8 @@ struct orbgpu_frame {
 
 namespace orbgpu {
 
-static int host_find(const orbgpu_mappoint_table *t, int64_t id)
-{
-    if (t->log2cap == 0 || id < 0)
-        return -1;
-    const uint32_t mask = (1u << t->log2cap) - 1u;
-    for (uint32_t s = mt_hash(id, t->log2cap);; s = (s + 1) & mask) {
-        if (t->hkeys[s] == id)
-            return t->hvals[s];
-        if (t->hkeys[s] == MT_EMPTY)
-            return -1;
-    }
-}
-
-static uint32_t host_insert(orbgpu_mappoint_table *t, int64_t id, int row)
-{
-    const uint32_t mask = (1u << t->log2cap) - 1u;
-    uint32_t s = mt_hash(id, t->log2cap);
-    while (t->hkeys[s] != MT_EMPTY)
-        s = (s + 1) & mask;
-    t->hkeys[s] = id;
-    t->hvals[s] = row;
-    return s;
-}
+static int host_find(const orbgpu_mappoint_table *t, int64_t id) { return t->hash.find(id); }
+static uint32_t host_insert(orbgpu_mappoint_table *t, int64_t id, int row) { return t->hash.insert(id, row); }
 
 // row capacity `want`, hash capacity >= 2 * want; existing rows are carried over on the device
 static int table_grow(orbgpu_mappoint_table *t, int want)
@@ -342,20 +317,11 @@ static int table_grow(orbgpu_mappoint_table *t, int want)
     int l2 = 1;
     while ((1 << l2) < 2 * ncap)
         l2++;
-    std::vector<int64_t> old_keys;
-    std::vector<int32_t> old_vals;
-    old_keys.swap(t->hkeys);
-    old_vals.swap(t->hvals);
-    t->log2cap = l2;
-    t->hkeys.assign((size_t)1 << l2, MT_EMPTY);
-    t->hvals.assign((size_t)1 << l2, -1);
-    for (size_t s = 0; s < old_keys.size(); s++)
-        if (old_keys[s] != MT_EMPTY)
-            host_insert(t, old_keys[s], old_vals[s]);
+    t->hash.rebuild(l2);
     if ((rc = t->d_hkeys.reserve(sizeof(int64_t) << l2)) != ORBGPU_OK || (rc = t->d_hvals.reserve(sizeof(int32_t) << l2)) != ORBGPU_OK)
         return rc;
-    ORBGPU_HIP_TRY(hipMemcpyAsync(t->d_hkeys.p, t->hkeys.data(), sizeof(int64_t) << l2, hipMemcpyHostToDevice, t->stream));
-    ORBGPU_HIP_TRY(hipMemcpyAsync(t->d_hvals.p, t->hvals.data(), sizeof(int32_t) << l2, hipMemcpyHostToDevice, t->stream));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(t->d_hkeys.p, t->hash.keys.data(), sizeof(int64_t) << l2, hipMemcpyHostToDevice, t->stream));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(t->d_hvals.p, t->hash.vals.data(), sizeof(int32_t) << l2, hipMemcpyHostToDevice, t->stream));
     ORBGPU_HIP_TRY(hipStreamSynchronize(t->stream));
     return ORBGPU_OK;
 }
@@ -483,10 +449,7 @@ int orbgpu_mappoint_table_upsert(orbgpu_mappoint_table *t, int32_t n, const int6
         if (t->stamp[r] == t->call_no) {  // undo nothing: rows handed out stay valid, but the call is refused
             set_error("map point id %lld appears twice in one upsert call", (long long)ids[i]);
             // the new rows of this call were inserted into the host hash only; drop them again
-            for (int k = 0; k < nnew; k++) {
-                t->hkeys[h_hs[k]] = MT_EMPTY;
-                t->hvals[h_hs[k]] = -1;
-            }
+            t->hash.rollback(h_hs, nnew);
             // (linear probing: removing the most recent insertions in reverse order leaves no broken chains, because
             //  nothing was inserted after them)
             t->rows = rows_before;
@@ -770,11 +733,11 @@ int orbgpu_search_local_points_table(const orbgpu_frame *fr, orbgpu_mappoint_tab
     GatherOut go{(float *)(g + g_wp), (float *)(g + g_nr), (float *)(g + g_mn), (float *)(g + g_mx), g + g_ds, g + g_sk,
                  g + g_ob,            nullptr,             t->pos_of_row.as<int32_t>(), d_cnt + 2};
     hipLaunchKernelGGL(k_table_gather, dim3((m + 255) / 256), dim3(256), 0, st, m, (const int64_t *)(d + i_ids),
-                       skip ? d + i_skip : nullptr, t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->log2cap, t->dev(),
+                       skip ? d + i_skip : nullptr, t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->hash.log2cap, t->dev(),
                        go);
     if (kp_ids)
         hipLaunchKernelGGL(k_table_kp, dim3((cap + 255) / 256), dim3(256), 0, st, n, cap, m, (const int64_t *)(d + i_kp),
-                           t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->log2cap, t->obs.as<uint8_t>(),
+                           t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->hash.log2cap, t->obs.as<uint8_t>(),
                            t->pos_of_row.as<int32_t>(), (int32_t *)(g + r_k2m), d_cnt + 3);
     else
         ORBGPU_HIP_TRY(hipMemsetAsync(g + r_k2m, 0xFF, 4 * (size_t)cap, st));  // every key point free
@@ -872,10 +835,10 @@ int orbgpu_search_by_projection_last_table(const orbgpu_frame *cur, const float 
     // outliers itself; bad points stay in (the reference does not test isBad() here, ORBmatcher.cc:1351-1357).
     GatherOut go{(float *)(g + g_wp), nullptr, nullptr, nullptr, g + g_ds, g + g_sk, g + g_ob, g + g_has, nullptr, d_cnt + 2};
     hipLaunchKernelGGL(k_table_gather, dim3((nl + 255) / 256), dim3(256), 0, st, nl, (const int64_t *)(d + i_ids),
-                       (const uint8_t *)nullptr, t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->log2cap, t->dev(), go);
+                       (const uint8_t *)nullptr, t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->hash.log2cap, t->dev(), go);
     if (cur_kp_ids)  // the current frame's own associations never point into the last frame's rows: held or free
         hipLaunchKernelGGL(k_table_kp, dim3((cap + 255) / 256), dim3(256), 0, st, n, cap, 0, (const int64_t *)(d + i_kp),
-                           t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->log2cap, t->obs.as<uint8_t>(),
+                           t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->hash.log2cap, t->obs.as<uint8_t>(),
                            (const int32_t *)nullptr, (int32_t *)(g + r_k2m), d_cnt + 3);
     else
         ORBGPU_HIP_TRY(hipMemsetAsync(g + r_k2m, 0xFF, 4 * (size_t)cap, st));
