@@ -80,3 +80,22 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle_py" not in src and "orb_oracle" not in src and "liborb_oracle" not in src, f
     out = os.popen("ldd %s" % os.path.join(pkg, "liborbgpu.so")).read()
     assert "oracle" not in out
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/orbgpu.h compiles as C99 with -pedantic -Werror, and a C program links against the
+    library and calls it (no device needed for the version query)."""
+    import subprocess
+    src = tmp_path / "abi_c99.c"
+    src.write_text('#include "orbgpu.h"\n#include <stdio.h>\n'
+                   'int main(void) {\n'
+                   '    orbgpu_extractor_params p = {1000, 1.2f, 8, 20, 7, 0, 1};\n'
+                   '    orbgpu_keypoint k; orbgpu_point_xyzrgba q; (void)p; (void)k; (void)q;\n'
+                   '    printf("%d %d %d\\n", orbgpu_abi_version(), (int)sizeof(orbgpu_keypoint), (int)sizeof(orbgpu_point_xyzrgba));\n'
+                   '    return orbgpu_abi_version() == ORBGPU_ABI_VERSION ? 0 : 1;\n}\n')
+    pkg = os.path.join(ROOT, "orb_slam2_map_amd")
+    exe = str(tmp_path / "abi_c99")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src),
+                    "-o", exe, "-L" + pkg, "-lorbgpu", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and r.stdout.split()[1:] == ["28", "16"], r.stdout
