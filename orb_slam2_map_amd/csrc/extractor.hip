@@ -1232,6 +1232,21 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
         return (int)s_bin2node[b];
     };
 
+    // step 3's reduction key of a candidate (see there): response + 1 in bits 40.., then the inverted vToDistributeKeys order
+    const float inv_w = 1.0f / (float)g.wcell, inv_h = 1.0f / (float)g.hcell;
+    auto best_of = [&](uint32_t key) -> unsigned long long {
+        const int x = key_x(key), y = key_y(key);  // relative to (minBorderX, minBorderY): cell interiors start at 3
+        // exact floor((v - 3) / cell) for v < 4096, cell >= 1: the float quotient is off by less than one ulp
+        int cj = (int)((float)(x - 3) * inv_w), ci = (int)((float)(y - 3) * inv_h);
+        cj += ((cj + 1) * g.wcell <= x - 3) ? 1 : 0;
+        cj -= (cj * g.wcell > x - 3) ? 1 : 0;
+        ci += ((ci + 1) * g.hcell <= y - 3) ? 1 : 0;
+        ci -= (ci * g.hcell > y - 3) ? 1 : 0;
+        const unsigned long long ord = ((unsigned long long)ci << 32) | ((unsigned long long)cj << 24) | (key >> 8);
+        return ((unsigned long long)(key_resp(key) + 1) << 40) | (0xFFFFFFFFFFull - ord);
+    };
+    bool best_done = false;  // the last pass's sweep has already reduced the keys per final node (below)
+
     QT_MARK(2)
     // ---- passes
     for (int iter = 0; iter < 64; iter++) {
@@ -1401,6 +1416,12 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             S.ccnt_next[i] = 0;
         __syncthreads();
         const bool count_next = done_cur == 0;
+        // The last pass (the list is final): nobody reads the labels again except step 3, so the sweep feeds step 3's
+        // per-node maximum directly instead of writing them -- one sweep over the keys less.  The maxima accumulate in the
+        // child-count array of the list being built, which the loop above has just zeroed for n_cur nodes (4 ints = two
+        // 64-bit words each) and which is S.ccnt after the swap below, where step 3 expects it.
+        const bool last_pass = done_cur == 1;
+        unsigned long long *best_next = reinterpret_cast<unsigned long long *>(S.ccnt_next);
 
         QT_MARK(15)
         // (7) re-label the keys and, in the same sweep, count the children of the NEW list's nodes
@@ -1419,6 +1440,11 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
 #pragma unroll
             for (int u = 0; u < QT_ILP; u++) {
                 const bool have = i0 + u * nt < nkeys;
+                if (last_pass) {
+                    if (have)
+                        atomicMax(&best_next[nn[u]], best_of(key[u]));
+                    continue;
+                }
                 if (have)
                     set_node(i0 + u * nt, nn[u]);
                 if (count_next)
@@ -1426,7 +1452,8 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
             }
         }
         __syncthreads();
-        labelled = true;  // every key carries the id of its node in the new list
+        best_done = last_pass;
+        labelled = labelled || !last_pass;  // every key carries the id of its node in the new list (not after the last pass)
         {
             int *t = S.ccnt;
             S.ccnt = S.ccnt_next;
@@ -1448,31 +1475,23 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
     //      row 32..39, cell column 24..31, y 12..23, x 0..11), which is also enough to rebuild the winning key.
     const int n = n_cur;
     unsigned long long *best = reinterpret_cast<unsigned long long *>(S.ccnt);  // [ncap*4] ints >= n 64-bit words
-    for (int p = tid; p < n; p += nt)
-        best[p] = 0ull;
-    __syncthreads();
-    const float inv_w = 1.0f / (float)g.wcell, inv_h = 1.0f / (float)g.hcell;
-    for (int i0 = tid; i0 < nkeys; i0 += QT_ILP * nt) {
-        uint32_t key[QT_ILP];
-        int nd[QT_ILP];
+    if (!best_done) {  // (no last pass ran: the initial list was final, or the pass limit was hit)
+        for (int p = tid; p < n; p += nt)
+            best[p] = 0ull;
+        __syncthreads();
+        for (int i0 = tid; i0 < nkeys; i0 += QT_ILP * nt) {
+            uint32_t key[QT_ILP];
+            int nd[QT_ILP];
 #pragma unroll
-        for (int u = 0; u < QT_ILP; u++) {
-            const int i = min(i0 + u * nt, nkeys - 1);
-            key[u] = key_at(i);
-            nd[u] = node_of(i, key[u]);
-        }
+            for (int u = 0; u < QT_ILP; u++) {
+                const int i = min(i0 + u * nt, nkeys - 1);
+                key[u] = key_at(i);
+                nd[u] = node_of(i, key[u]);
+            }
 #pragma unroll
-        for (int u = 0; u < QT_ILP; u++) {
-            const int x = key_x(key[u]), y = key_y(key[u]);  // relative to (minBorderX, minBorderY): cell interiors start at 3
-            // exact floor((v - 3) / cell) for v < 4096, cell >= 1: the float quotient is off by less than one ulp
-            int cj = (int)((float)(x - 3) * inv_w), ci = (int)((float)(y - 3) * inv_h);
-            cj += ((cj + 1) * g.wcell <= x - 3) ? 1 : 0;
-            cj -= (cj * g.wcell > x - 3) ? 1 : 0;
-            ci += ((ci + 1) * g.hcell <= y - 3) ? 1 : 0;
-            ci -= (ci * g.hcell > y - 3) ? 1 : 0;
-            const unsigned long long ord = ((unsigned long long)ci << 32) | ((unsigned long long)cj << 24) | (key[u] >> 8);
-            if (i0 + u * nt < nkeys)
-                atomicMax(&best[nd[u]], ((unsigned long long)(key_resp(key[u]) + 1) << 40) | (0xFFFFFFFFFFull - ord));
+            for (int u = 0; u < QT_ILP; u++)
+                if (i0 + u * nt < nkeys)
+                    atomicMax(&best[nd[u]], best_of(key[u]));
         }
     }
     __syncthreads();
