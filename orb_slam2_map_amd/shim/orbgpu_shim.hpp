@@ -298,8 +298,13 @@ template <typename MapPointT> class MapPointTableT {
     MapPointTableT(const MapPointTableT &) = delete;
     MapPointTableT &operator=(const MapPointTableT &) = delete;
     orbgpu_mappoint_table *handle() const { return h_; }
+    // One caller at a time (the C ABI's rule for a table).  In the reference LocalMapping creates and culls map points
+    // while Tracking searches, and only some of those edits happen under Map::mMutexMapUpdate, so the wrapper serialises
+    // its own calls and the matcher overloads that search the table take the same lock.
+    std::mutex &mutex() const { return mu_; }
     int rows() const
     {
+        std::lock_guard<std::mutex> g(mu_);
         int32_t r = 0;
         check(orbgpu_mappoint_table_rows(h_, &r), "MapPointTable::rows");
         return r;
@@ -311,6 +316,7 @@ template <typename MapPointT> class MapPointTableT {
     void Upsert(const std::vector<MapPointT *> &pts, WorldPos world_pos, Normal normal, MinDist min_dist, MaxDist max_dist,
                 MpDesc mp_desc)
     {
+        std::lock_guard<std::mutex> g(mu_);
         const size_t n = pts.size();
         ids_.resize(n), wp_.resize(3 * n), nr_.resize(3 * n), mn_.resize(n), mx_.resize(n), ds_.resize(32 * n), ob_.resize(n);
         for (size_t i = 0; i < n; i++) {
@@ -337,18 +343,21 @@ template <typename MapPointT> class MapPointTableT {
     // MapPoint::SetWorldPos (MapPoint.cc:73-78)
     void SetWorldPos(MapPointT *p, const float *w)
     {
+        std::lock_guard<std::mutex> g(mu_);
         const int64_t id = (int64_t)p->mnId;
         check(orbgpu_mappoint_table_upsert(h_, 1, &id, w, nullptr, nullptr, nullptr, nullptr, nullptr), "SetWorldPos");
     }
     // MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:242-307): the chosen descriptor
     void SetDescriptor(MapPointT *p, const uint8_t *d)
     {
+        std::lock_guard<std::mutex> g(mu_);
         const int64_t id = (int64_t)p->mnId;
         check(orbgpu_mappoint_table_upsert(h_, 1, &id, nullptr, nullptr, nullptr, nullptr, d, nullptr), "SetDescriptor");
     }
     // MapPoint::AddObservation / EraseObservation (MapPoint.cc:98-149)
     void SetObservations(MapPointT *p)
     {
+        std::lock_guard<std::mutex> g(mu_);
         const int64_t id = (int64_t)p->mnId;
         const int32_t n = p->Observations();
         check(orbgpu_mappoint_table_set_observations(h_, 1, &id, &n, nullptr), "SetObservations");
@@ -356,11 +365,13 @@ template <typename MapPointT> class MapPointTableT {
     // MapPoint::SetBadFlag (MapPoint.cc:151-175), MapPoint::Replace (:177-228)
     void SetBad(MapPointT *p)
     {
+        std::lock_guard<std::mutex> g(mu_);
         const int64_t id = (int64_t)p->mnId;
         check(orbgpu_mappoint_table_set_bad(h_, 1, &id, nullptr), "SetBad");
     }
 
   private:
+    mutable std::mutex mu_;
     orbgpu_mappoint_table *h_ = nullptr;
     std::vector<int64_t> ids_, bad_;
     std::vector<float> wp_, nr_, mn_, mx_;
@@ -562,6 +573,7 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
         for (int j = 0; j < n; j++)
             kid_[j] = CurrentFrame.mvpMapPoints[j] ? (int64_t)CurrentFrame.mvpMapPoints[j]->mnId : -1;
         int32_t nmatches = 0;
+        std::lock_guard<std::mutex> table_lock(table.mutex());
         check(orbgpu_search_by_projection_last_table(dCur.handle(), Tcw(CurrentFrame), dLast.handle(), Tcw(LastFrame),
                                                      table.handle(), ids_.data(), b0_.data(), kid_.data(), CurrentFrame.fx,
                                                      CurrentFrame.fy, CurrentFrame.cx, CurrentFrame.cy, CurrentFrame.mbf,
@@ -834,6 +846,7 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
         for (int j = 0; j < n; j++)
             kid_[j] = F.mvpMapPoints[j] ? (int64_t)F.mvpMapPoints[j]->mnId : -1;
         int32_t nmatches = 0;
+        std::lock_guard<std::mutex> table_lock(table.mutex());
         check(orbgpu_search_local_points_table(dF.handle(), table.handle(), m, ids_.data(), skip, scratch, Tcw, fx, fy, cx, cy,
                                                mbf, log_sf, cos_limit, th, mfNNratio, kid_.data(), k2m_.data(), &nmatches, trk),
               "SearchByProjection(table)");

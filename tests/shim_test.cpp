@@ -2,6 +2,7 @@
 // reference's member names (Frame.h / MapPoint.h / KeyFrame.h).  Reads a scenario file written by
 // tests/test_shim.py, runs extractor -> SearchByProjection x2 -> PointCloudMapping through the shim
 // and writes the results for comparison with the oracle.
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -338,6 +339,59 @@ int main(int argc, char **argv)
             wr(out, idl_tab.data(), idl_tab.size());
             std::printf("shim timing: SearchByProjection(Cur, Last) host-pointer %.0f us, over the table %.0f us (%d last-frame key points)\n",
                         t_lh / reps, t_lt / reps, n_last);
+            // LocalMapping edits the map while Tracking searches: a second thread inserts points (the table grows under the
+            // searches), changes their observation counts and flags some bad -- none of them is in the list, so every search
+            // must give the same matches; the wrapper's lock makes the two threads take turns
+            {
+                std::vector<MapPoint> extra(6000);
+                for (size_t i = 0; i < extra.size(); i++) {
+                    extra[i].mnId = 4000000007ul + 13ul * i;
+                    extra[i].world[2] = 1.f + (float)i;
+                    std::memset(extra[i].desc, (int)(i & 255), 32);
+                }
+                std::atomic<bool> stop{false};
+                std::atomic<int> edits{0};
+                std::string edit_error;
+                std::thread editor([&] {
+                    try {
+                        size_t next = 0;
+                        while (!stop.load()) {
+                            std::vector<MapPoint *> part;
+                            for (int k = 0; k < 500 && next < extra.size(); k++)
+                                part.push_back(&extra[next++]);
+                            if (!part.empty())
+                                table.Upsert(part, wp_of, nr_of, mn_of, mx_of, mp_desc);
+                            MapPoint &p = extra[(size_t)edits.load() % extra.size()];
+                            p.nObs = edits.load() % 3;
+                            if (p.mnId < 4000000007ul + 13ul * next) {  // only points the table has been told about
+                                table.SetObservations(&p);
+                                if (edits.load() % 7 == 0)
+                                    table.SetBad(&p);
+                            }
+                            edits++;
+                        }
+                    } catch (const std::exception &e) {
+                        edit_error = e.what();
+                    }
+                });
+                for (int rep = 0; rep < 40 || (edits.load() < 3 && rep < 4000); rep++) {  // (at least 40; until the editor had turns)
+                    F2.mvpMapPoints.assign(F2.N, nullptr);
+                    const int nmt = matcher.SearchLocalPoints(
+                        F2, dF, vp, cam[5], table, [](MapPoint *) { return false; }, tcw_of, [](MapPoint *, bool) {});
+                    if (nmt != nm_dev) {
+                        stop = true;
+                        editor.join();
+                        throw std::runtime_error("a search gave other matches while another thread edited the table");
+                    }
+                }
+                stop = true;
+                editor.join();
+                if (!edit_error.empty())
+                    throw std::runtime_error("editor thread: " + edit_error);
+                if (edits.load() < 3 || table.rows() <= m)
+                    throw std::runtime_error("the editor thread did not get its turn");
+                std::printf("table edited %d times by a second thread during the searches (%d rows)\n", edits.load(), table.rows());
+            }
             // edits reach the table: a point flagged bad is skipped by the next search
             if (nm_dev > 0) {
                 int victim = -1;
