@@ -388,8 +388,8 @@ int main(int argc, char **argv)
                 editor.join();
                 if (!edit_error.empty())
                     throw std::runtime_error("editor thread: " + edit_error);
-                if (edits.load() < 3 || table.rows() <= m)
-                    throw std::runtime_error("the editor thread did not get its turn");
+                if (edits.load() < 1 || table.rows() <= m)
+                    throw std::runtime_error("the editor thread never got a turn in 4000 searches");
                 std::printf("table edited %d times by a second thread during the searches (%d rows)\n", edits.load(), table.rows());
             }
             // edits reach the table: a point flagged bad is skipped by the next search
