@@ -881,9 +881,14 @@ template <typename FrameT, typename MapPointT> class ORBmatcherT {
 //     by shutdown() with no new key frame, indexes keyframes[N] (:246);
 //   * loop closure (:217-243): when the hook reports LoopClosing::loop_detected (and clears it, :219), the map is
 //     rebuilt from all non-bad key frames of the Map sorted by id;
-//   * otherwise (:244-267) the new key frames are inserted.  The reference transforms only the LAST new cloud with
-//     the pose of the FIRST new key frame (:246-247) and, in the loop branch, does not advance lastKeyframeSize:
-//     setReferenceQuirks(true) reproduces both; by default every new key frame is inserted with its own pose;
+//   * otherwise (:244-267) the new key frames are inserted.  The reference transforms only the LAST new cloud
+//     (keyFrameCloud.back(), :247) with the pose of the FIRST new key frame (keyframes[lastKeyframeSize], :246) and,
+//     in the loop branch, does not advance lastKeyframeSize (so the next insert takes the pose of the first key frame
+//     that arrived with the loop closure).  That IS the default here -- the drop-in's map equals the reference's for the
+//     same grouping of key frames into wake-ups.  setReferenceQuirks(false) is the corrected opt-in: every new key
+//     frame is inserted with its own pose and the loop branch consumes its key frames.  After a loop branch the
+//     reference only runs again on the next notify, i.e. the next insertKeyFrame: the wait predicate therefore
+//     compares against the number of key frames SEEN (seenSize), not against the stale lastKeyframeSize;
 //   * after the loop (:270-288): clear, per key frame generatePointCloud + voxel.filter + `+=`, then sor.filter
 //     (meanK 50, stddev factor 1.0: the constructor's settings, :46-47) and, if an output path is set,
 //     savePCDFileBinary.  A map of meanK points or fewer is left unfiltered (PCL reads past its neighbour list there).
@@ -916,7 +921,13 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
         orbgpu_cloud_destroy(cloud_);
     }
 
-    void setReferenceQuirks(bool on) { quirks = on; }
+    // true (default): PointCloudMap.cc:217-262 statement by statement; false: the corrected insert (own pose per key
+    // frame, loop branch advances lastKeyframeSize).  Set before the first insertKeyFrame.
+    void setReferenceQuirks(bool on)
+    {
+        std::unique_lock<std::mutex> lck(keyframeMutex);
+        quirks = on;
+    }
     // "optimized_pointcloud.pcd" in the reference (:287); empty (default) = do not write a file
     void setOutputPath(const std::string &path) { outputPath = path; }
     // the reference fixes these in its constructor (:46-47); meanK <= 0 skips the filter
@@ -934,7 +945,7 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
     void waitProcessed()
     {
         std::unique_lock<std::mutex> lck(keyframeMutex);
-        processed.wait(lck, [&] { return finished || (!busy && !loopPending && keyframes.size() <= lastKeyframeSize); });
+        processed.wait(lck, [&] { return finished || (!busy && !loopPending && keyframes.size() <= seenSize); });
     }
 
     // a detected loop must wake the viewer too (the reference relies on the next key frame's notify)
@@ -968,13 +979,16 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
             if (shutDownFlagLocked())  // :186-192
                 break;
             size_t N, first;
+            bool ref;
             {
                 std::unique_lock<std::mutex> lck(keyframeMutex);  // :195-198
-                keyFrameUpdated.wait(lck, [&] { return shutDownFlagLocked() || loopPending || keyframes.size() > lastKeyframeSize; });
+                keyFrameUpdated.wait(lck, [&] { return shutDownFlagLocked() || loopPending || keyframes.size() > seenSize; });
                 loopPending = false;
                 busy = true;
                 N = keyframes.size();  // :202-205
                 first = lastKeyframeSize;
+                seenSize = N;
+                ref = quirks;
             }
             size_t done = first;
             if (hooks.take_loop_detected && hooks.all_keyframes && hooks.take_loop_detected()) {  // :217-243
@@ -985,11 +999,11 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
                     if (!adapt.isBad(kf))
                         good.push_back(kf);
                 rebuild(good);
-                if (!quirks)
-                    done = N;  // the reference leaves it (the next pass re-inserts these key frames)
+                if (!ref)
+                    done = N;  // the reference leaves it (:243 falls out of the branch without `lastKeyframeSize = N`)
             } else if (N > first) {  // :244-267
-                if (quirks)
-                    insertOne(keyframeAt(N - 1), keyframeAt(first));  // last cloud, first pose (:246-247)
+                if (ref)
+                    insertOne(keyframeAt(N - 1), keyframeAt(first));  // keyFrameCloud.back() with keyframes[lastKeyframeSize]'s pose (:246-247)
                 else
                     for (size_t i = first; i < N; i++)
                         insertOne(keyframeAt(i), keyframeAt(i));
@@ -1096,11 +1110,12 @@ template <typename KeyFrameT, typename Adapter> class PointCloudMappingT {
 
     orbgpu_cloud *cloud_ = nullptr;
     std::shared_ptr<std::thread> viewerThread;
-    bool shutDownFlag = false, loopPending = false, quirks = false, busy = false, finished = false;
+    bool shutDownFlag = false, loopPending = false, quirks = true, busy = false, finished = false;
     std::mutex shutDownMutex, keyframeMutex, cloudMutex;
     std::condition_variable keyFrameUpdated, processed;
     std::vector<KeyFrameT *> keyframes;
-    size_t lastKeyframeSize = 0;
+    size_t lastKeyframeSize = 0;  // the reference's member (:207, :265)
+    size_t seenSize = 0;          // keyframes.size() at the last wake-up (what a bare wait() + notify per insert amounts to)
     double resolution = 0.01;
     int sorMeanK = 50;          // sor.setMeanK(50), PointCloudMap.cc:46
     double sorStddevMul = 1.0;  // sor.setStddevMulThresh(1.0), :47

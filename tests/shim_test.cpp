@@ -580,6 +580,65 @@ int main(int argc, char **argv)
             nc = (int64_t)fin.size();
             dump(fin);
         }
+        // ---- the reference's insert semantics (PointCloudMap.cc:244-262, the shim's default) and the corrected opt-in:
+        //      five key frames with DIFFERENT depth images and poses; (1) one alone, (2) two in ONE wake-up (the
+        //      reference inserts the last cloud with the first pose), (3) a loop closure detected at a wake-up that
+        //      brings a key frame (rebuild; the reference leaves lastKeyframeSize stale), (4) one more insert (the
+        //      reference takes the pose of the key frame that arrived with the loop closure)
+        struct TwoAtOnce : orbgpu_shim::PointCloudMappingT<KeyFrame, KFAdapter> {
+            using PointCloudMappingT::PointCloudMappingT;
+            void insertTwo(KeyFrame *a, KeyFrame *b)  // both visible to the viewer's next look at keyframes.size()
+            {
+                std::unique_lock<std::mutex> lck(keyframeMutex);
+                keyframes.push_back(a);
+                keyframes.push_back(b);
+                keyFrameUpdated.notify_one();
+            }
+        };
+        for (int mode = 0; mode < 2; mode++) {
+            std::vector<KeyFrame> q(5);
+            for (int i = 0; i < 5; i++) {
+                KeyFrame &kf = q[i];
+                kf.mImDep = depth, kf.mImRGB = rgb, kf.rows = h, kf.cols = w;
+                for (float &d : kf.mImDep)
+                    d += 0.125f * (float)i;
+                kf.fx = cam[0], kf.fy = cam[1], kf.cx = cam[2], kf.cy = cam[3];
+                std::memcpy(kf.pose, Tcw, 64);
+                kf.pose[3] += 0.25f * (float)i;
+                kf.pose[11] -= 0.0625f * (float)i;
+                kf.mnId = 20 + i;
+            }
+            bool flag2 = false;
+            int nmap = 0;
+            orbgpu_shim::PointCloudMappingT<KeyFrame, KFAdapter>::LoopHooks hooks2;
+            hooks2.take_loop_detected = [&] { const bool v = flag2; flag2 = false; return v; };
+            hooks2.all_keyframes = [&] {
+                std::vector<KeyFrame *> all;
+                for (int i = 0; i < nmap; i++)
+                    all.push_back(&q[i]);
+                return all;
+            };
+            TwoAtOnce mapping(0.05, KFAdapter(), 0, hooks2);
+            if (mode == 1)
+                mapping.setReferenceQuirks(false);
+            mapping.setOutlierFilter(0, 1.0);  // the shutdown pass is covered above
+            mapping.insertKeyFrame(&q[0]);
+            mapping.waitProcessed();
+            mapping.insertTwo(&q[1], &q[2]);
+            mapping.waitProcessed();
+            dump(mapping.globalMap());
+            for (int i = 0; i < 5; i++)
+                q[i].pose[7] -= 0.125f;  // the loop closure corrected the poses
+            nmap = 4;
+            flag2 = true;
+            mapping.insertKeyFrame(&q[3]);
+            mapping.waitProcessed();
+            dump(mapping.globalMap());
+            mapping.insertKeyFrame(&q[4]);
+            mapping.waitProcessed();
+            dump(mapping.globalMap());
+            mapping.shutdown();
+        }
         std::printf("shim ok: %d key points, %d projection matches, %lld map points\n", n, nm, (long long)nc);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "shim_test failed: %s\n", e.what());

@@ -359,4 +359,47 @@ def test_shim_end_to_end(gpu, oracle, stream640):
     assert 0 < len(ofin) < len(ocat)
     cloud_c, off = read_cloud(off)
     assert cloud_c.tobytes() == ofin.tobytes(), "shutdown pass: per-key-frame filtered clouds, concatenated, sor.filter"
+
+    # the reference's insert semantics (default) and the corrected opt-in, composed from the oracle's pieces:
+    # PointCloudMap.cc:244-262 inserts keyFrameCloud.back() with keyframes[lastKeyframeSize]'s pose and leaves
+    # lastKeyframeSize alone in the loop branch (:217-243)
+    def kf_cloud_of(i, T):
+        R, t = oracle.pose_inverse(T)
+        d_i = (depth + np.float32(0.125) * np.float32(i)).astype(np.float32)
+        return oracle.transform_points(oracle.backproject(d_i, rgb, *camv), R, t)
+
+    def add(omap, cloud):
+        return oracle.voxel_filter(np.concatenate([omap, cloud]), 0.05)[0]
+
+    def qposes(moved):
+        out = []
+        for i in range(5):
+            T = Tcw.astype(np.float32).copy()
+            T[0, 3] = np.float32(T[0, 3] + np.float32(0.25) * np.float32(i))
+            T[2, 3] = np.float32(T[2, 3] - np.float32(0.0625) * np.float32(i))
+            if moved:
+                T[1, 3] = np.float32(T[1, 3] - np.float32(0.125))
+            out.append(T)
+        return out
+    P0, P1 = qposes(False), qposes(True)
+    empty = np.zeros(0, oracle.POINT_DTYPE)
+    for mode, what in ((0, "reference semantics (default)"), (1, "corrected insert (setReferenceQuirks(false))")):
+        m1 = add(empty, kf_cloud_of(0, P0[0]))
+        if mode == 0:
+            m1 = add(m1, kf_cloud_of(2, P0[1]))  # last cloud, first pose: ONE insert for the two key frames
+        else:
+            m1 = add(add(m1, kf_cloud_of(1, P0[1])), kf_cloud_of(2, P0[2]))
+        got, off = read_cloud(off)
+        assert got.tobytes() == m1.tobytes(), "two key frames in one wake-up, " + what
+        m2 = add(empty, np.concatenate([kf_cloud_of(i, P1[i]) for i in range(4)]))  # rebuild: ids ascending
+        got, off = read_cloud(off)
+        assert got.tobytes() == m2.tobytes(), "loop closure at a wake-up with a new key frame, " + what
+        m3 = add(m2, kf_cloud_of(4, P1[3] if mode == 0 else P1[4]))  # stale lastKeyframeSize = 3 in the reference
+        got, off = read_cloud(off)
+        assert got.tobytes() == m3.tobytes(), "insert after the loop closure, " + what
+        if mode == 0:
+            ref_maps = (m1, m3)
+        else:
+            assert m1.tobytes() != ref_maps[0].tobytes() and m3.tobytes() != ref_maps[1].tobytes(), \
+                "the two modes must be told apart by this scenario"
     assert off == len(buf)
