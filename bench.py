@@ -170,6 +170,130 @@ def cpu_baseline(frames, seconds_budget=9.0):
                                     % (n_all, nthreads, dt_all)}}
 
 
+def cpu_baseline_c3(wl, seconds_budget=12.0):
+    """Oracle (kind 'port') on the C3 frame: extraction at 1280x960 / 2000 features, ComputeStereoFromRGBD + the grid, then
+    Tracking::SearchLocalPoints (isInFrustum per point + SearchByProjection) against the sequence's local map, one core."""
+    from oracle import oracle_py as O
+    libpath = None
+    try:
+        tmp = os.path.join(tempfile.gettempdir(), "liborb_oracle_native_%d.so" % os.getpid())
+        O.build(out=tmp, extra_cflags="-O3 -march=native -fPIC -std=c11 -ffp-contract=off -fno-fast-math")
+        libpath = tmp
+    except Exception:
+        O.build()
+    st = wl.st
+    e = O.Extractor(wl.NF, libpath=libpath)
+    sf = e.scale_factors()
+    log_sf = float(np.log(np.float32(sf[1])))
+    cam = (float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf))
+    depth = wl.depth[0].cpu().numpy()
+    n, t_ext, t_search, nm = 0, 0.0, 0.0, 0
+    t0 = time.perf_counter()
+    while True:
+        img = wl.host_frames[-1] if n % 2 == 0 else wl.host_frames[n % (len(wl.host_frames) - 1)]
+        ta = time.perf_counter()
+        k, d = e.extract(img)
+        tb = time.perf_counter()
+        ur, _ = O.compute_stereo_from_rgbd(k["x"], k["y"], k["x"], depth, cam[4])
+        fr = O.Frame(k["x"], k["y"], k["octave"], k["angle"], ur, d, wl.W, wl.H, sf)
+        nm, _, _, _ = O.search_local_points(fr, wl.Tcw, *cam, wl.table, log_sf, libpath=libpath)
+        tc = time.perf_counter()
+        t_ext += tb - ta
+        t_search += tc - tb
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic 1280x960 frames, 2000 features: extract, ComputeStereoFromRGBD + grid, isInFrustum + "
+                      "SearchByProjection(th=3) of %d map points (%d matches on the last frame); oracle built -O3 "
+                      "-march=native -ffp-contract=off; host has %d cores" % (n, wl.M, nm, os.cpu_count()),
+            "stage_ms_per_frame": {"extract": round(t_ext / n * 1e3, 3), "glue_search_local_points": round(t_search / n * 1e3, 3)}}
+
+
+def main_c3_batch(args, rank, local_rank, world):
+    """--workload c3_batch: north_star's 1280x960 line under --gpus N.  One set of --batch independent sequences per rank
+    (frames shard by sequence: no data-path collective), the same barrier + max-time / frame-count reductions as C2."""
+    import torch
+    from orb_slam2_map_amd import dist as D
+    from orb_slam2_map_amd import lib as G
+    from orb_slam2_map_amd import workloads
+    B = args.batch if args.batch != 512 else 128  # 512 is C2's default; 128 sequences x 1280x960 is the C3 batch (2.3 GB of state)
+    wl = workloads.C3Batch(B, local_rank, D.sequence_seed(1234, rank))
+    s_ext = wl.stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            D.barrier(world)
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        wl.step()
+    barrier()
+    cnt = wl.counts.cpu().numpy()
+    n_host = wl.nout.cpu().numpy()
+    assert n_host.min() > 0 and cnt[:, 0].min() > 0, "benchmark produced empty frames"
+    # the timed region three times (VERDICT r3: one 41-ms sample has no spread): the contract's K steps each, barrier on
+    # both sides of every repetition; `value` comes from the median repetition
+    PROF_EVERY = 4
+    reps = []
+    for r in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            wl.ext.set_profiling(r == 1 and i % PROF_EVERY == 0)
+            wl.step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            D.barrier(world)
+        torch.cuda.synchronize()
+        e_max, total = D.aggregate(elapsed, B * args.steps, world, device="cuda" if args.backend == "nccl" else "cpu")
+        reps.append((e_max, total))
+    stage_ms = wl.ext.stage_times()
+    wl.ext.set_profiling(False)
+    order = sorted(range(3), key=lambda r: reps[r][0])
+    e_med, total = reps[order[1]]
+    if rank == 0:
+        N = float(n_host.mean())
+        n_cand = float(sum(len(wl.ext.debug_read(G.DBG_CANDIDATES, 0, lvl)[0]) for lvl in range(8)))
+        launches = {k: len(v) for k, v in STAGE_KERNELS.items()}
+        dom = max(stage_ms, key=lambda k: stage_ms[k] / launches[k])
+        dom_bytes = wl.stage_bytes(dom, N, n_cand) * B
+        ach = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        alg_m2, alg_ext = wl.algorithmic_bytes(N)
+        ext_ms = sum(stage_ms.values())
+        out = {"metric": "frames/sec ORB extract + SearchByProjection (1280x960, 2000 feat, ~10 k local MapPoints)",
+               "value": total / e_med, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+               "ms_per_step": e_med / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u8", "data": "synthetic",
+               "timed_region_repeats": {"frames_per_s": [round(t / e, 1) for e, t in reps],
+                                        "spread_pct": round(100 * (max(e for e, _ in reps) - min(e for e, _ in reps)) / e_med, 2),
+                                        "value_is": "median of 3 repetitions of the K-step region"},
+               "config": {"workload": "C3 (BASELINE.json configs[2]) in throughput mode: synthetic 1280x960 RGB-D, 2000 features, 8 "
+                                      "levels; per step and sequence one frame: extract + frame glue (ComputeStereoFromRGBD, grid) "
+                                      "+ Tracking::SearchLocalPoints (isInFrustum + SearchByProjection th=3) against the sequence's "
+                                      "%d local map points" % wl.M,
+                          "sequences_per_gpu": B, "frames_per_step_per_gpu": B, "sequences": B * world,
+                          "parallelism": "%d sequences per GPU, sequences never cross GPUs" % B, "schedule": "serial, 1 stream"},
+               "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                            "traffic_source": "no PMC pass at 1280x960 (the C2 passes under profiles/ are per 640x480 frame)",
+                            "algorithmic_bytes": dom_bytes, "ms_per_launch": stage_ms[dom], "frames_per_launch": B},
+               "stages": {k: {"ms": round(v, 4), "GB/s": round(wl.stage_bytes(k, N, n_cand) * B / (max(v, 1e-6) * 1e-3) / 1e9, 1)}
+                          for k, v in stage_ms.items()},
+               "extract_ms_per_step": round(ext_ms, 4),
+               "extract_roofline": {"achieved": alg_ext / (ext_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": alg_ext / (ext_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg_ext},
+               "search_algorithmic_bytes_per_step": alg_m2,
+               "keypoints_per_frame": N, "matches_per_frame": float(cnt[:, 0].mean()), "map_points": wl.M}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_c3(wl)
+        print(json.dumps(out), flush=True)
+    D.finalize(world)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +324,10 @@ def main():
     ap.add_argument("--concurrent-blur", action="store_true",
                     help="run the blur of every extraction on a stream of the handle's own next to FAST / quadtree "
                          "(orbgpu_extractor_set_concurrent_blur)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3_batch"],
+                    help="c2 (default, the contract line): 640x480 / 1000 features, extract + BF match.  c3_batch: the 1280x960 "
+                         "stream of BASELINE.json configs[2] in throughput mode -- --batch independent sequences per GPU, one "
+                         "frame each per step: extract + frame glue + SearchLocalPoints against ~10 k map points per sequence")
     ap.add_argument("--force-group", action="store_true",
                     help="build the process group for a single rank too: barrier and reductions then run through the "
                          "backend (RCCL) exactly as on the multi-GPU node -- what a one-GPU box can execute of that path")
@@ -234,6 +362,9 @@ def main():
     torch.cuda.set_device(local_rank)
     # RCCL; carries the barrier and two scalar reductions only (--force-group: through the backend even for one rank)
     D.init(args.backend, rank, world, force_group=args.force_group)
+
+    if args.workload == "c3_batch":
+        return main_c3_batch(args, rank, local_rank, world)
 
     W, H, NFEAT = 640, 480, 1000
     B, POOL = args.batch, max(args.pool, args.batch)

@@ -80,6 +80,28 @@ typedef struct orbgpu_extractor orbgpu_extractor;
 int orbgpu_extractor_create(const orbgpu_extractor_params *params, orbgpu_extractor **out);
 int orbgpu_extractor_destroy(orbgpu_extractor *h);
 
+/* computeOrbDescriptor's  a = (float)cos(angle), b = (float)sin(angle)  (ORBextractor.cc:112-113).  With
+ * `using namespace std;` in force (:66-67) the calls resolve to std::cos(float) / std::sin(float) = libm's cosf / sinf,
+ * which are not correctly rounded: their last bit is a property of the host's libm.  Process-wide, read by
+ * orbgpu_extractor_create:
+ *   ORBGPU_TRIG_HOST_LIBM (default)  the values THIS host's cosf / sinf return, bit for bit: the device evaluates a fixed
+ *       IEEE-double sequence and corrects it from a table of the arguments where the host differs, built by scanning
+ *       every float of [0, 2 pi] once per process at the first extractor creation (about 15 core-seconds, spread over
+ *       the CPUs the process may use; 18 MB on the device);
+ *   ORBGPU_TRIG_ROUNDED_DOUBLE       (float)cos((double)angle): the correctly rounded value, no table, no start-up scan
+ *       (differs from glibc 2.35's cosf / sinf in 1.3e-3 of the arguments, from a descriptor bit far more rarely:
+ *       DESIGN.md section 2). */
+enum { ORBGPU_TRIG_HOST_LIBM = 0, ORBGPU_TRIG_ROUNDED_DOUBLE = 1 };
+int orbgpu_set_trig_mode(int32_t mode);
+int orbgpu_get_trig_mode(void);
+/* entries of the exception table (-1: not built yet) and the time its scan took */
+int orbgpu_trig_table_info(int64_t *entries, double *build_ms);
+/* Test aid, needs no device: cos / sin of x as ORBGPU_TRIG_HOST_LIBM delivers them (builds the table if necessary);
+ * *from_table = 1 if the table corrected the base value. */
+int orbgpu_trig_host_eval(float x, float *c, float *s, int32_t *from_table);
+/* Test aid: the DEVICE's values (the function the descriptor stage calls) for n host floats, current mode. */
+int orbgpu_trig_eval(const float *x, int32_t n, float *c, float *s, int32_t device_id);
+
 /* GetLevels / GetScaleFactor / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (ORBextractor.h:63-83). Arrays receive nlevels floats. */
 int orbgpu_extractor_get_levels(const orbgpu_extractor *h, int32_t *nlevels);
@@ -421,8 +443,13 @@ int orbgpu_search_by_projection(const orbgpu_frame_view *f, const orbgpu_mappoin
  *   set_observations  AddObservation / EraseObservation (:98-149)
  *   set_bad           SetBadFlag (:151-175), Replace (:177-228)
  * Per frame the caller passes ids; id -> row lookup, the gather of the call's local map and the translation of the
- * frame's existing associations run on the device.  A table is used by one host thread at a time (the reference's
- * callers hold Map::mMutexMapUpdate around these edits); every call returns synchronised. */
+ * frame's existing associations run on the device.  A table is used by ONE host thread at a time and the CALLER must
+ * serialise: most of the reference's edit sites run WITHOUT Map::mMutexMapUpdate (`new MapPoint` at LocalMapping.cc:434,
+ * SetBadFlag in MapPointCulling and at Tracking.cc:806 / 937 / 1416; only Tracking.cc:463, Optimizer.cc:746 / 989 and
+ * the LoopClosing sites hold it), while Tracking searches the table concurrently -- an unserialised edit mutates the
+ * host-side id hash under a running lookup.  The C++ wrapper MapPointTableT serialises its own calls and the matcher
+ * overloads that search it through MapPointTableT::mutex().  Every call returns synchronised.
+ * Limits: at most 2^26 ids per call, 2^27 rows per table. */
 typedef struct orbgpu_mappoint_table orbgpu_mappoint_table;
 int orbgpu_mappoint_table_create(int32_t device_id, int32_t initial_rows, orbgpu_mappoint_table **out);
 int orbgpu_mappoint_table_destroy(orbgpu_mappoint_table *t);
@@ -438,6 +465,9 @@ int orbgpu_mappoint_table_upsert(orbgpu_mappoint_table *t, int32_t n, const int6
 int orbgpu_mappoint_table_set_bad(orbgpu_mappoint_table *t, int32_t n, const int64_t *ids, int32_t *known);
 int orbgpu_mappoint_table_set_observations(orbgpu_mappoint_table *t, int32_t n, const int64_t *ids, const int32_t *n_obs,
                                            int32_t *known);
+/* Ids of the most recent orbgpu_search_local_points_table / orbgpu_search_by_projection_last_table call that the table
+ * had never been told about: list rows (skipped) and key-point associations (treated as held).  Either may be NULL. */
+int orbgpu_mappoint_table_last_unknown(const orbgpu_mappoint_table *t, int32_t *list_ids, int32_t *kp_ids);
 /* One row back to the host (tests, debugging); any output may be NULL. */
 int orbgpu_mappoint_table_read(orbgpu_mappoint_table *t, int64_t id, float *world_pos, float *normal, float *min_dist,
                                float *max_dist, uint8_t *desc, int32_t *has_observations, int32_t *bad);
@@ -463,7 +493,12 @@ int orbgpu_frame_device_view(const orbgpu_frame *fr, orbgpu_device_frame_view *v
  *                    mbTrackInView etc. so that the caller can IncreaseVisible() (Tracking.cc:1479-1483).
  * kp_ids [n] or NULL (host): mnId of F.mvpMapPoints[j], -1 = none.  kp_to_mp [n] (host, out): position in ids[] of the
  * point key point j holds after the call, -1 none, -2 a point outside the list that has observations (untouched).
- * An id the table does not know is an error (ORBGPU_EINVAL): the table must mirror the map. */
+ * An id the table does not know yet is NOT an error: LocalMapping publishes a new point to the key frames
+ * (LocalMapping.cc:434-440, AddMapPoint) before ComputeDistinctiveDescriptors / UpdateNormalAndDepth have run, and
+ * Tracking::UpdateLocalPoints may list it in that window; the reference tolerates the window, so does this call: an
+ * unknown list id is a skipped row, an unknown key-point id counts as "held" (-2).  orbgpu_mappoint_table_last_unknown
+ * reports how many of each the most recent search call over the table met.
+ * With m == 0 (or an empty frame) nothing is searched; kp_to_mp is still translated through the table. */
 int orbgpu_search_local_points_table(const orbgpu_frame *fr, orbgpu_mappoint_table *t, int32_t m, const int64_t *ids,
                                      const uint8_t *skip, const orbgpu_mappoint_view *scratch, const float *Tcw, float fx,
                                      float fy, float cx, float cy, float mbf, float log_scale_factor, float cos_limit,

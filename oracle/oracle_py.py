@@ -98,6 +98,12 @@ def lib(path=None):
     L.ora_fast_atan2.restype = cf
     L.ora_fast_atan2.argtypes = [cf, cf]
     L.ora_orb_descriptor.argtypes = [vp, ci, cf, vp]
+    L.ora_set_trig_mode.argtypes = [ci]
+    L.ora_set_trig_mode.restype = None
+    L.ora_descriptor_trig.argtypes = [cf, vp, vp]
+    L.ora_descriptor_trig.restype = None
+    L.ora_descriptor_trig_array.argtypes = [vp, ci, vp, vp]
+    L.ora_descriptor_trig_array.restype = None
     L.ora_descriptor_distance.argtypes = [vp, vp]
     L.ora_match_bf.argtypes = [vp, vp, vp, ci, vp, vp, ci, ci, cf, ci, vp]
     L.ora_assign_features_to_grid.argtypes = [ci, vp, vp, cf, cf, cf, cf, vp, vp]
@@ -214,6 +220,36 @@ class Extractor:
 
 def pattern():
     return _arr(lib().ora_get_pattern(), 1024, np.int8)
+
+
+TRIG_LIBM_FLOAT, TRIG_ROUNDED_DOUBLE = 0, 1
+
+
+def set_trig_mode(mode):
+    """ORBextractor.cc:112-113: TRIG_LIBM_FLOAT (default) = this host's cosf / sinf, what `using namespace std` makes the
+    reference call; TRIG_ROUNDED_DOUBLE = (float)cos((double)angle)."""
+    lib().ora_set_trig_mode(int(mode))
+
+
+def descriptor_trig(angle_rad):
+    a, b = C.c_float(), C.c_float()
+    lib().ora_descriptor_trig(float(angle_rad), C.byref(a), C.byref(b))
+    return np.float32(a.value), np.float32(b.value)
+
+
+def descriptor_trig_array(angle_rad):
+    x = np.ascontiguousarray(angle_rad, np.float32)
+    a, b = np.zeros(len(x), np.float32), np.zeros(len(x), np.float32)
+    lib().ora_descriptor_trig_array(_p(x), len(x), _p(a), _p(b))
+    return a, b
+
+
+def orb_descriptor(plane, x, y, angle_deg):
+    """computeOrbDescriptor on the pixel (x, y) of a 2-D uint8 array (the caller guarantees the 18-px margin)."""
+    plane = np.ascontiguousarray(plane, np.uint8)
+    out = np.zeros(32, np.uint8)
+    lib().ora_orb_descriptor(plane.ctypes.data + int(y) * plane.strides[0] + int(x), plane.strides[0], float(angle_deg), _p(out))
+    return out
 
 
 def resize_linear(src, dw, dh):
@@ -338,6 +374,31 @@ def search_by_projection(frame, mp, th, nnratio, kp_to_mp):
     out = np.ascontiguousarray(kp_to_mp, np.int32).copy()
     n = lib().ora_search_by_projection(C.byref(fv), C.byref(v), th, nnratio, _p(out))
     return n, out
+
+
+def search_local_points(frame, Tcw, fx, fy, cx, cy, mbf, table, log_sf, th=3.0, nnratio=0.8, cos_limit=0.5, kp_to_mp=None,
+                        libpath=None):
+    """Tracking::SearchLocalPoints for a fresh frame (Tracking.cc:1447-1497).  table: dict with world_pos, normal, min_dist,
+    max_dist, desc, skip, obs_pos.  Returns (nmatches, kp_to_mp, in_view, levels_out_of_range)."""
+    L = lib(libpath)
+    L.ora_search_local_points.argtypes = [C.c_void_p] * 2 + [C.c_float] * 5 + [C.c_int] + [C.c_void_p] * 7 + \
+        [C.c_float] * 4 + [C.c_void_p] * 8
+    keep = {k: np.ascontiguousarray(table[k], dt) for k, dt in
+            (("world_pos", np.float32), ("normal", np.float32), ("min_dist", np.float32), ("max_dist", np.float32),
+             ("skip", np.uint8), ("obs_pos", np.uint8), ("desc", np.uint8))}
+    m = len(keep["min_dist"])
+    in_view = np.zeros(m, np.uint8)
+    px, py, pxr, vc = (np.zeros(m, np.float32) for _ in range(4))
+    lvl = np.zeros(m, np.int32)
+    out = np.full(frame.n, -1, np.int32) if kp_to_mp is None else np.ascontiguousarray(kp_to_mp, np.int32).copy()
+    fv = frame.view()
+    T = np.ascontiguousarray(Tcw, np.float32)
+    nlo = C.c_int()
+    n = L.ora_search_local_points(C.addressof(fv), _p(T), fx, fy, cx, cy, mbf, m, _p(keep["world_pos"]), _p(keep["normal"]),
+                                  _p(keep["min_dist"]), _p(keep["max_dist"]), _p(keep["skip"]), _p(keep["obs_pos"]),
+                                  _p(keep["desc"]), log_sf, cos_limit, th, nnratio, _p(in_view), _p(px), _p(py), _p(pxr),
+                                  _p(lvl), _p(vc), _p(out), C.addressof(nlo))
+    return n, out, in_view, nlo.value
 
 
 def search_by_projection_last(cur, cur_Tcw, fx, fy, cx, cy, mbf, mb, last, th, mono, check_ori, kp_to_mp):

@@ -96,6 +96,13 @@ float ora_ic_angle(const uint8_t *center, int step, const int *umax);
 float ora_fast_atan2(float y, float x);
 /* E7: computeOrbDescriptor, ORBextractor.cc:108-147. */
 void ora_orb_descriptor(const uint8_t *center, int step, float angle_deg, uint8_t desc[32]);
+/* :112-113 resolve to std::cos(float) / std::sin(float) (`using namespace std`, :66-67) = this host's cosf / sinf:
+ * ORA_TRIG_LIBM_FLOAT (default).  ORA_TRIG_ROUNDED_DOUBLE = (float)cos((double)angle), the correctly rounded value. */
+enum { ORA_TRIG_LIBM_FLOAT = 0, ORA_TRIG_ROUNDED_DOUBLE = 1 };
+void ora_set_trig_mode(int mode);
+int ora_get_trig_mode(void);
+void ora_descriptor_trig(float angle_rad, float *a, float *b);
+void ora_descriptor_trig_array(const float *angle_rad, int n, float *a, float *b);
 
 /* ---- M0: ORBmatcher::DescriptorDistance, ORBmatcher.cc:1647-1663 ---- */
 int ora_descriptor_distance(const uint8_t *a, const uint8_t *b);
@@ -160,6 +167,16 @@ typedef struct {
  * Returns nmatches, or -1 if a predicted level is outside [0,nlevels) (H5). */
 int ora_search_by_projection(const ora_frame_view *f, const ora_mappoint_view *mp, float th, float nnratio,
                              int32_t *kp_to_mp);
+
+/* Tracking::SearchLocalPoints (Tracking.cc:1447-1497) for a fresh frame: isInFrustum (cos_limit 0.5) over the listed
+ * points that are not skipped, then SearchByProjection(F, vpMapPoints, th) with nnratio.  The m-entry scratch arrays
+ * receive the mTrack* members; *n_level_out counts predicted levels outside [0, nlevels) (left out of the view). */
+int ora_search_local_points(const ora_frame_view *f, const float *Tcw, float fx, float fy, float cx, float cy, float mbf,
+                            int m, const float *world_pos, const float *normal, const float *min_dist,
+                            const float *max_dist, const uint8_t *skip, const uint8_t *obs_pos, const uint8_t *desc,
+                            float log_scale_factor, float cos_limit, float th, float nnratio, uint8_t *in_view,
+                            float *proj_x, float *proj_y, float *proj_xr, int32_t *level, float *view_cos,
+                            int32_t *kp_to_mp, int *n_level_out);
 
 /* ---- M3: SearchByProjection(CurrentFrame, LastFrame, th, bMono), ORBmatcher.cc:1328-1470 ---- */
 typedef struct {

@@ -727,12 +727,40 @@ float ora_ic_angle(const uint8_t *center, int step, const int *umax)
 }
 
 /* ------------------------------------------------------------------ E7 descriptor */
+/* ORBextractor.cc:112-113:  float a = (float)cos(angle), b = (float)sin(angle);  with a float `angle`.  The file has
+ * `using namespace cv; using namespace std;` (:66-67), so overload resolution takes std::cos(float) / std::sin(float),
+ * which are libm's cosf / sinf -- NOT the double functions.  cosf / sinf are not correctly rounded, so their last bit
+ * belongs to the libm (and CPU variant) of the host the reference runs on.  ORA_TRIG_LIBM_FLOAT (default) calls this
+ * host's cosf / sinf, i.e. what the reference computes on this machine; ORA_TRIG_ROUNDED_DOUBLE is the correctly rounded
+ * value (float)cos((double)angle) -- the restatement rounds 1 to 3 had -- kept so that the residual between the two
+ * can be counted (tests/test_trig.py) and liborbgpu's ORBGPU_TRIG_ROUNDED_DOUBLE mode checked. */
+static int g_trig_mode = ORA_TRIG_LIBM_FLOAT;
+void ora_set_trig_mode(int mode) { g_trig_mode = mode == ORA_TRIG_ROUNDED_DOUBLE ? ORA_TRIG_ROUNDED_DOUBLE : ORA_TRIG_LIBM_FLOAT; }
+int ora_get_trig_mode(void) { return g_trig_mode; }
+void ora_descriptor_trig(float angle_rad, float *a, float *b)
+{
+    if (g_trig_mode == ORA_TRIG_ROUNDED_DOUBLE) {
+        *a = (float)cos((double)angle_rad);
+        *b = (float)sin((double)angle_rad);
+    } else {
+        *a = cosf(angle_rad);
+        *b = sinf(angle_rad);
+    }
+}
+
+void ora_descriptor_trig_array(const float *angle_rad, int n, float *a, float *b)
+{
+    for (int i = 0; i < n; i++)
+        ora_descriptor_trig(angle_rad[i], a + i, b + i);
+}
+
 /* computeOrbDescriptor, ORBextractor.cc:108-147 */
 void ora_orb_descriptor(const uint8_t *center, int step, float angle_deg, uint8_t desc[32])
 {
     const float factorPI = (float)(3.14159265358979323846 / 180.f); /* :107 */
     float angle = angle_deg * factorPI;
-    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    float a, b;
+    ora_descriptor_trig(angle, &a, &b);
     const int8_t *p = k_pattern;
     for (int i = 0; i < 32; ++i, p += 32) {
         int val = 0;

@@ -643,6 +643,45 @@ int ora_is_in_frustum(const float *Tcw, float fx, float fy, float cx, float cy, 
     return 1;
 }
 
+/* Tracking::SearchLocalPoints, Tracking.cc:1447-1497, for a fresh frame: every listed point that is not skipped (bad,
+ * or already seen by the frame: the caller's `skip`) goes through Frame::isInFrustum(pMP, 0.5) (:1473), then
+ * ORBmatcher(0.8).SearchByProjection(F, vpMapPoints, th) (:1488-1496) runs over the ones in view.  A predicted level
+ * outside [0, nlevels) is counted in *n_level_out and the point left out (the reference reads past mvScaleFactors, H5).
+ * Scratch arrays (m entries each) are the MapPoint members isInFrustum fills (MapPoint.h:91-96). */
+int ora_search_local_points(const ora_frame_view *f, const float *Tcw, float fx, float fy, float cx, float cy, float mbf,
+                            int m, const float *world_pos, const float *normal, const float *min_dist,
+                            const float *max_dist, const uint8_t *skip, const uint8_t *obs_pos, const uint8_t *desc,
+                            float log_scale_factor, float cos_limit, float th, float nnratio, uint8_t *in_view,
+                            float *proj_x, float *proj_y, float *proj_xr, int32_t *level, float *view_cos,
+                            int32_t *kp_to_mp, int *n_level_out)
+{
+    int nout = 0;
+    for (int i = 0; i < m; i++) {
+        in_view[i] = 0;
+        proj_x[i] = proj_y[i] = proj_xr[i] = view_cos[i] = 0.f;
+        level[i] = 0;
+        if (skip && skip[i])
+            continue;
+        float px, py, pxr, vc;
+        int32_t lv;
+        if (!ora_is_in_frustum(Tcw, fx, fy, cx, cy, mbf, f->min_x, f->max_x, f->min_y, f->max_y, world_pos + 3 * i,
+                               normal + 3 * i, min_dist[i], max_dist[i], log_scale_factor, f->nlevels, cos_limit, &px, &py,
+                               &pxr, &lv, &vc))
+            continue;
+        if (lv < 0 || lv >= f->nlevels) {
+            nout++;
+            continue;
+        }
+        in_view[i] = 1, proj_x[i] = px, proj_y[i] = py, proj_xr[i] = pxr, level[i] = lv, view_cos[i] = vc;
+    }
+    if (n_level_out)
+        *n_level_out = nout;
+    ora_mappoint_view mp;
+    mp.m = m, mp.in_view = in_view, mp.bad = skip, mp.obs_pos = obs_pos, mp.level = level, mp.view_cos = view_cos;
+    mp.proj_x = proj_x, mp.proj_y = proj_y, mp.proj_xr = proj_xr, mp.desc = desc;
+    return ora_search_by_projection(f, &mp, th, nnratio, kp_to_mp);
+}
+
 /* cv::undistortPoints(src, dst, K, distCoef, Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call it
  * (Frame.cc:404-468), OpenCV 2.4 cvUndistortPoints: everything in double, five fixed-point iterations, the
  * rational terms k4..k6 zero, R = identity, P = K.  dist = k1 k2 p1 p2 k3 (k3 = 0 for a 4-entry mDistCoef).

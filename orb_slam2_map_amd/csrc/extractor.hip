@@ -6,6 +6,7 @@
 // OpenCV 2.4 calls it makes.  Integer stages are bit-exact by
 // construction; float stages are written without contraction (see common.h).
 #include "common.h"
+#include "trig_base.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -1514,7 +1515,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
 struct KpAux {
     int x, y, level;
     float angle;
-    float ca, sb;  // (float)cos / (float)sin of the angle in radians, evaluated in double (k_trig)
+    float ca, sb;  // cosf / sinf of the angle in radians as the handle's trig mode defines them (k_trig)
     int plane_off, pitch;  // of the key point's level: k_describe's patch loads then depend on this record only
 };
 
@@ -1683,10 +1684,11 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     }
     }
 }
-// computeOrbDescriptor's  a = (float)cos(angle), b = (float)sin(angle)  (ORBextractor.cc:112-113): the
-// float angle in radians is promoted to double for libm's cos/sin and the result rounded to float.
-// One thread per key point so the double-precision evaluation is amortised over 64 key points per wave.
-__global__ __launch_bounds__(256) void k_trig(KpAux *__restrict__ aux, const int *__restrict__ n_out, int cap)
+// computeOrbDescriptor's  a = (float)cos(angle), b = (float)sin(angle)  (ORBextractor.cc:112-113): std::cos(float) /
+// std::sin(float) of the reference's host, i.e. its libm's cosf / sinf (trig_base.h).  The fixed double-precision
+// sequence gives the correctly rounded value; the table (if the handle has one) replaces it where the host's libm
+// returns something else.  One thread per key point: 64 key points per wave share the double-precision evaluation.
+__global__ __launch_bounds__(256) void k_trig(KpAux *__restrict__ aux, const int *__restrict__ n_out, int cap, TrigTable tt)
 {
     const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1695,8 +1697,10 @@ __global__ __launch_bounds__(256) void k_trig(KpAux *__restrict__ aux, const int
     KpAux *a = aux + (size_t)f * cap + i;
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float angle = a->angle * factorPI;
-    a->ca = (float)cos((double)angle);
-    a->sb = (float)sin((double)angle);
+    float c, s;
+    orbgpu_trig_device(angle, tt, &c, &s);
+    a->ca = c;
+    a->sb = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2012,10 +2016,13 @@ struct orbgpu_extractor {
     int qt_keys_hook = -1;  // ORBGPU_DEBUG_QT_KEYS (read at creation): LDS key share of k_quadtree<true>; -1 = as many as fit
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
+    TrigTable trig = {nullptr, nullptr, nullptr, 0u};  // the host libm's cosf / sinf exceptions (trig.hip); none in ORBGPU_TRIG_ROUNDED_DOUBLE mode
 
 };
 
 namespace orbgpu {
+
+int trig_table_for_device(int device_id, TrigTable *out);  // trig.hip
 
 // E0: constructor tables, ORBextractor.cc:410-470
 static void build_tables(orbgpu_extractor *e)
@@ -2562,7 +2569,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                        reinterpret_cast<const uint32_t *>(e->d_pattern.as<uint8_t>() + 1024), d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out, or_iters);
     hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
-                       e->d_aux.as<KpAux>(), d_n_out, cap);
+                       e->d_aux.as<KpAux>(), d_n_out, cap, e->trig);
     END(ST_ORIENT, st);
     BEGIN(ST_DESCRIBE, st);
     if (e->concurrent_blur)
@@ -2621,6 +2628,12 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
         set_error("hipStreamCreate: %s", hipGetErrorString(he));
         delete e;
         return ORBGPU_EHIP;
+    }
+    rc = trig_table_for_device(p->device_id, &e->trig);
+    if (rc != ORBGPU_OK) {
+        (void)hipStreamDestroy(e->stream);
+        delete e;
+        return rc;
     }
     *out = e;
     return ORBGPU_OK;

@@ -25,6 +25,8 @@
 namespace orbgpu {
 
 constexpr int64_t MT_EMPTY = ID_HASH_EMPTY;
+constexpr int MT_MAX_CALL = 1 << 26;  // ids per call
+constexpr int MT_MAX_ROWS = 1 << 27;  // rows of a table (82 B each)
 __host__ __device__ __forceinline__ uint32_t mt_hash(int64_t id, int log2cap) { return id_hash_slot(id, log2cap); }
 
 __device__ __forceinline__ int mt_lookup(const int64_t *__restrict__ hkeys, const int32_t *__restrict__ hvals, int log2cap,
@@ -259,6 +261,7 @@ struct orbgpu_mappoint_table {
     DevBuf g_block;     // the call's gathered local map + translation tables + results
     DevBuf pos_of_row;  // [cap] list position of every table row in the current call
     ProjWorkspace *pws = nullptr;  // the matchers' scratch for calls over this table (they run on `stream`)
+    int32_t last_unknown_list = 0, last_unknown_kp = 0;  // ids of the last search call the table had never been told about
     TableDev dev() const
     {
         return TableDev{world_pos.as<float>(), normal.as<float>(), min_dist.as<float>(), max_dist.as<float>(),
@@ -301,10 +304,16 @@ static int table_grow(orbgpu_mappoint_table *t, int want)
         int rc = nb.reserve(it.elt * (size_t)ncap);
         if (rc != ORBGPU_OK)
             return rc;
-        ORBGPU_HIP_TRY(hipMemsetAsync(nb.p, 0, it.elt * (size_t)ncap, t->stream));
-        if (t->rows > 0)
-            ORBGPU_HIP_TRY(hipMemcpyAsync(nb.p, it.b->p, it.elt * (size_t)t->rows, hipMemcpyDeviceToDevice, t->stream));
-        ORBGPU_HIP_TRY(hipStreamSynchronize(t->stream));
+        hipError_t he = hipMemsetAsync(nb.p, 0, it.elt * (size_t)ncap, t->stream);
+        if (he == hipSuccess && t->rows > 0)
+            he = hipMemcpyAsync(nb.p, it.b->p, it.elt * (size_t)t->rows, hipMemcpyDeviceToDevice, t->stream);
+        if (he == hipSuccess)
+            he = hipStreamSynchronize(t->stream);
+        if (he != hipSuccess) {  // the array being replaced stays as it was; the fresh one must not leak
+            nb.release();
+            set_error("MapPoint table growth to %d rows: %s", ncap, hipGetErrorString(he));
+            return ORBGPU_EHIP;
+        }
         it.b->release();
         *it.b = nb;
     }
@@ -341,9 +350,51 @@ static void frame_dev_view(const orbgpu_frame *fr, orbgpu_device_frame_view *v)
     v->min_x = fr->min_x, v->max_x = fr->max_x, v->min_y = fr->min_y, v->max_y = fr->max_y;
 }
 
+// A search call with an empty list (or an empty frame): kp_to_mp still follows the output contract -- a key point holding
+// a point WITH observations is -2, one holding a point without (or nothing) is -1 -- so the table is consulted.
+static int translate_kp_only(orbgpu_mappoint_table *t, int n, int cap, const int64_t *kp_ids, int32_t *kp_to_mp)
+{
+    if (n == 0)
+        return ORBGPU_OK;
+    if (!kp_ids) {
+        for (int j = 0; j < n; j++)
+            kp_to_mp[j] = -1;
+        return ORBGPU_OK;
+    }
+    Carver c;
+    const size_t o_kp = c.take(8 * (size_t)n), o_k2m = c.take(4 * (size_t)cap), o_cnt = c.take(16);
+    int rc;
+    if ((rc = t->stage.reserve(c.off)) != ORBGPU_OK || (rc = t->d_stage.reserve(c.off)) != ORBGPU_OK)
+        return rc;
+    uint8_t *h = (uint8_t *)t->stage.p, *d = t->d_stage.as<uint8_t>();
+    std::memcpy(h + o_kp, kp_ids, 8 * (size_t)n);
+    hipStream_t st = t->stream;
+    ORBGPU_HIP_TRY(hipMemcpyAsync(d + o_kp, h + o_kp, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    ORBGPU_HIP_TRY(hipMemsetAsync(d + o_cnt, 0, 16, st));
+    hipLaunchKernelGGL(k_table_kp, dim3((cap + 255) / 256), dim3(256), 0, st, n, cap, 0, (const int64_t *)(d + o_kp),
+                       t->d_hkeys.as<int64_t>(), t->d_hvals.as<int32_t>(), t->hash.log2cap, t->obs.as<uint8_t>(),
+                       (const int32_t *)nullptr, (int32_t *)(d + o_k2m), (int32_t *)(d + o_cnt) + 3);
+    ORBGPU_HIP_TRY(hipGetLastError());
+    ORBGPU_HIP_TRY(hipMemcpyAsync(h + o_k2m, d + o_k2m, (o_cnt + 16) - o_k2m, hipMemcpyDeviceToHost, st));
+    ORBGPU_HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(kp_to_mp, h + o_k2m, 4 * (size_t)n);
+    t->last_unknown_kp = ((const int32_t *)(h + o_cnt))[3];
+    return ORBGPU_OK;
+}
+
 } // namespace orbgpu
 
 extern "C" {
+
+int orbgpu_mappoint_table_last_unknown(const orbgpu_mappoint_table *t, int32_t *list_ids, int32_t *kp_ids)
+{
+    ORBGPU_REQUIRE(t, "null table");
+    if (list_ids)
+        *list_ids = t->last_unknown_list;
+    if (kp_ids)
+        *kp_ids = t->last_unknown_kp;
+    return ORBGPU_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // table
@@ -416,9 +467,14 @@ int orbgpu_mappoint_table_upsert(orbgpu_mappoint_table *t, int32_t n, const int6
     int rc = select_device(t->device_id);
     if (rc != ORBGPU_OK)
         return rc;
-    for (int i = 0; i < n; i++)
+    ORBGPU_REQUIRE(n <= MT_MAX_CALL, "at most %d map points per upsert call", MT_MAX_CALL);
+    int64_t unknown = 0;  // ids that need a row (an id listed twice counts twice: the call is refused below anyway)
+    for (int i = 0; i < n; i++) {
         ORBGPU_REQUIRE(ids[i] >= 0, "map point id %lld is negative", (long long)ids[i]);
-    if ((rc = table_grow(t, t->rows + n)) != ORBGPU_OK)  // room for n new rows, whatever the ids turn out to be
+        unknown += host_find(t, ids[i]) < 0;
+    }
+    ORBGPU_REQUIRE((int64_t)t->rows + unknown <= MT_MAX_ROWS, "the MapPoint table is limited to %d rows", MT_MAX_ROWS);
+    if (unknown && (rc = table_grow(t, t->rows + (int)unknown)) != ORBGPU_OK)  // an update of known points never grows the table
         return rc;
     // staging layout
     Carver cv;
@@ -471,7 +527,16 @@ int orbgpu_mappoint_table_upsert(orbgpu_mappoint_table *t, int32_t n, const int6
         std::memcpy(h + o_ds, desc, 32 * (size_t)n);
     if (n_obs)
         std::memcpy(h + o_ob, n_obs, 4 * (size_t)n);
-    ORBGPU_HIP_TRY(hipMemcpyAsync(t->d_stage.p, h, cv.off, hipMemcpyHostToDevice, t->stream));
+    // from here on a HIP failure must take the rows this call handed out back again: the device hash never got them
+    auto undo = [&](hipError_t he, const char *what) {
+        set_error("%s: %s (MapPoint table upsert)", what, hipGetErrorString(he));
+        t->hash.rollback(h_hs, nnew);
+        t->rows = rows_before;
+        return ORBGPU_EHIP;
+    };
+    hipError_t he = hipMemcpyAsync(t->d_stage.p, h, cv.off, hipMemcpyHostToDevice, t->stream);
+    if (he != hipSuccess)
+        return undo(he, "hipMemcpyAsync");
     const uint8_t *d = t->d_stage.as<uint8_t>();
     UpsertDev u{(const int32_t *)(d + o_row),
                 d + o_new,
@@ -487,8 +552,10 @@ int orbgpu_mappoint_table_upsert(orbgpu_mappoint_table *t, int32_t n, const int6
         hipLaunchKernelGGL(k_hash_apply, dim3((nnew + 255) / 256), dim3(256), 0, t->stream, nnew, (const int32_t *)(d + o_hs),
                            (const int64_t *)(d + o_hk), (const int32_t *)(d + o_hv), t->d_hkeys.as<int64_t>(),
                            t->d_hvals.as<int32_t>());
-    ORBGPU_HIP_TRY(hipGetLastError());
-    ORBGPU_HIP_TRY(hipStreamSynchronize(t->stream));  // the staging block is reused by the next call
+    if ((he = hipGetLastError()) != hipSuccess)
+        return undo(he, "kernel launch");
+    if ((he = hipStreamSynchronize(t->stream)) != hipSuccess)  // the staging block is reused by the next call
+        return undo(he, "hipStreamSynchronize");
     return ORBGPU_OK;
 }
 
@@ -679,11 +746,9 @@ int orbgpu_search_local_points_table(const orbgpu_frame *fr, orbgpu_mappoint_tab
         return rc;
     const int n = fr->n, cap = fr->cap;
     *nmatches = 0;
-    if (m == 0 || n == 0) {
-        for (int j = 0; j < n; j++)
-            kp_to_mp[j] = (kp_ids && kp_ids[j] >= 0) ? -2 : -1;
-        return ORBGPU_OK;
-    }
+    t->last_unknown_list = t->last_unknown_kp = 0;
+    if (m == 0 || n == 0)  // nothing to search; the frame's own associations are still translated through the table
+        return translate_kp_only(t, n, cap, kp_ids, kp_to_mp);
     const size_t M = (size_t)m;
     // inputs: one staged block
     Carver ci;
@@ -762,10 +827,11 @@ int orbgpu_search_local_points_table(const orbgpu_frame *fr, orbgpu_mappoint_tab
     ORBGPU_HIP_TRY(hipMemcpyAsync(h, g + r_beg, r_end - r_beg, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipStreamSynchronize(st));
     const int32_t *cnt = (const int32_t *)(h + (r_cnt - r_beg));
-    if (cnt[2] || cnt[3]) {
-        set_error("%d local map point id(s) and %d key-point association id(s) are not in the MapPoint table", cnt[2], cnt[3]);
-        return ORBGPU_EINVAL;
-    }
+    // ids the table has not been told about yet are not an error: LocalMapping publishes a new point to the key frames
+    // (LocalMapping.cc:434-440) before its attributes are final, and Tracking::UpdateLocalPoints may list it in that
+    // window.  Such a list row is skipped, such a key-point association counts as held; the counts are reported by
+    // orbgpu_mappoint_table_last_unknown.
+    t->last_unknown_list = cnt[2], t->last_unknown_kp = cnt[3];
     if (scratch && cnt[1]) {
         set_error("%d map point(s) with a predicted level outside [0,%d)", cnt[1], fr->nlevels);
         return ORBGPU_ELEVEL;  // as orbgpu_search_by_projection (H5)
@@ -804,11 +870,9 @@ int orbgpu_search_by_projection_last_table(const orbgpu_frame *cur, const float 
         return rc;
     const int n = cur->n, cap = cur->cap, nl = last->n;
     *nmatches = 0;
-    if (nl == 0 || n == 0) {
-        for (int j = 0; j < n; j++)
-            kp_to_mp[j] = (cur_kp_ids && cur_kp_ids[j] >= 0) ? -2 : -1;
-        return ORBGPU_OK;
-    }
+    t->last_unknown_list = t->last_unknown_kp = 0;
+    if (nl == 0 || n == 0)
+        return translate_kp_only(t, n, cap, cur_kp_ids, kp_to_mp);
     const size_t M = (size_t)nl;
     Carver ci;
     const size_t i_ids = ci.take(8 * M), i_out = last_outlier ? ci.take(M) : 0, i_kp = cur_kp_ids ? ci.take(8 * (size_t)n) : 0;
@@ -855,10 +919,7 @@ int orbgpu_search_by_projection_last_table(const orbgpu_frame *cur, const float 
     ORBGPU_HIP_TRY(hipMemcpyAsync(h, g + r_beg, r_end - r_beg, hipMemcpyDeviceToHost, st));
     ORBGPU_HIP_TRY(hipStreamSynchronize(st));
     const int32_t *cnt = (const int32_t *)(h + (r_cnt - r_beg));
-    if (cnt[2] || cnt[3]) {
-        set_error("%d last-frame map point id(s) and %d key-point association id(s) are not in the MapPoint table", cnt[2], cnt[3]);
-        return ORBGPU_EINVAL;
-    }
+    t->last_unknown_list = cnt[2], t->last_unknown_kp = cnt[3];  // skipped rows / held key points, not an error (see above)
     std::memcpy(kp_to_mp, h + (r_k2m - r_beg), 4 * (size_t)n);
     *nmatches = cnt[0];
     return ORBGPU_OK;

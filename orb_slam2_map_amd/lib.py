@@ -107,6 +107,7 @@ _LIB = None
 # every symbol include/orbgpu.h declares (checked by tests/test_abi.py against the header text)
 ABI_SYMBOLS = [
     "orbgpu_last_error_string", "orbgpu_abi_version", "orbgpu_device_count", "orbgpu_measure_copy_bandwidth",
+    "orbgpu_set_trig_mode", "orbgpu_get_trig_mode", "orbgpu_trig_table_info", "orbgpu_trig_host_eval", "orbgpu_trig_eval",
     "orbgpu_extractor_create", "orbgpu_extractor_destroy", "orbgpu_extractor_get_levels",
     "orbgpu_extractor_get_scale_factor", "orbgpu_extractor_get_scale_factors",
     "orbgpu_extractor_get_inv_scale_factors", "orbgpu_extractor_get_sigma2", "orbgpu_extractor_get_inv_sigma2",
@@ -122,7 +123,7 @@ ABI_SYMBOLS = [
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_mappoint_table_create", "orbgpu_mappoint_table_destroy", "orbgpu_mappoint_table_rows",
     "orbgpu_mappoint_table_upsert", "orbgpu_mappoint_table_set_bad", "orbgpu_mappoint_table_set_observations",
-    "orbgpu_mappoint_table_read", "orbgpu_frame_create", "orbgpu_frame_destroy", "orbgpu_frame_upload",
+    "orbgpu_mappoint_table_read", "orbgpu_mappoint_table_last_unknown", "orbgpu_frame_create", "orbgpu_frame_destroy", "orbgpu_frame_upload",
     "orbgpu_frame_device_view", "orbgpu_search_local_points_table", "orbgpu_search_by_projection_last_table",
     "orbgpu_vocabulary_create", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_size", "orbgpu_bow_transform",
     "orbgpu_bow_transform_batch_device", "orbgpu_search_by_bow", "orbgpu_search_by_bow_batch_device",
@@ -160,6 +161,8 @@ def lib():
     L.orbgpu_extractor_stage_name.argtypes = [i32]
     sigs = {
         "orbgpu_extractor_create": [vp, vp],
+        "orbgpu_set_trig_mode": [i32],
+        "orbgpu_trig_table_info": [vp, vp],
         "orbgpu_extractor_destroy": [vp],
         "orbgpu_extractor_get_levels": [vp, vp],
         "orbgpu_extractor_get_scale_factor": [vp, vp],
@@ -244,6 +247,45 @@ def measure_copy_bandwidth(nbytes=1 << 30, reps=10, device_id=0):
     v = C.c_float()
     check(L.orbgpu_measure_copy_bandwidth(nbytes, reps, device_id, C.byref(v)))
     return v.value
+
+
+TRIG_HOST_LIBM, TRIG_ROUNDED_DOUBLE = 0, 1
+
+
+def set_trig_mode(mode):
+    """cos / sin of computeOrbDescriptor (ORBextractor.cc:112-113) for extractors created from now on: TRIG_HOST_LIBM
+    (default: this host's cosf / sinf, bit for bit) or TRIG_ROUNDED_DOUBLE ((float)cos((double)angle))."""
+    check(lib().orbgpu_set_trig_mode(int(mode)))
+
+
+def get_trig_mode():
+    return lib().orbgpu_get_trig_mode()
+
+
+def trig_table_info():
+    """(entries of the host-libm exception table or -1 if it has not been built, milliseconds its scan took)."""
+    n, ms = C.c_int64(), C.c_double()
+    check(lib().orbgpu_trig_table_info(C.byref(n), C.byref(ms)))
+    return n.value, ms.value
+
+
+def trig_host_eval(x):
+    """(cos, sin, from_table) of the float x as TRIG_HOST_LIBM delivers them; needs no device."""
+    L = lib()
+    L.orbgpu_trig_host_eval.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    c, s, t = C.c_float(), C.c_float(), C.c_int32()
+    check(L.orbgpu_trig_host_eval(float(x), C.byref(c), C.byref(s), C.byref(t)))
+    return np.float32(c.value), np.float32(s.value), t.value
+
+
+def trig_eval(x, device_id=0):
+    """cos / sin of the float32 array x as the DEVICE computes them for the descriptor stage (current trig mode)."""
+    L = lib()
+    L.orbgpu_trig_eval.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    x = np.ascontiguousarray(x, np.float32)
+    c, s = np.zeros(len(x), np.float32), np.zeros(len(x), np.float32)
+    check(L.orbgpu_trig_eval(_p(x), len(x), _p(c), _p(s), device_id))
+    return c, s
 
 
 # --------------------------------------------------------------------------------------------
@@ -570,6 +612,13 @@ class MapPointTable:
         self.L.orbgpu_mappoint_table_set_observations.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         check(self.L.orbgpu_mappoint_table_set_observations(self.h, len(ids), _p(ids), _p(n_obs), C.byref(k)))
         return k.value
+
+    def last_unknown(self):
+        """(list ids, key-point ids) of the last search call over the table that the table did not know."""
+        a, b = C.c_int32(), C.c_int32()
+        self.L.orbgpu_mappoint_table_last_unknown.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        check(self.L.orbgpu_mappoint_table_last_unknown(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def read(self, id_):
         wp, nr, ds = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(32, np.uint8)

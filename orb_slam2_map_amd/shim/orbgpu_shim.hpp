@@ -369,6 +369,62 @@ template <typename MapPointT> class MapPointTableT {
         const int64_t id = (int64_t)p->mnId;
         check(orbgpu_mappoint_table_set_bad(h_, 1, &id, nullptr), "SetBad");
     }
+    // Batch forms: ONE staged copy, launch and synchronisation for the whole set, under one hold of the mutex Tracking's
+    // searches take.  These are what the bulk writers call: the write-back loops of bundle adjustment
+    // (Optimizer.cc:775 / 1040: SetWorldPos + UpdateNormalAndDepth per point, thousands per local BA), loop correction
+    // (LoopClosing.cc:520-560) and MapPointCulling.  The one-id forms above cost a full host <-> device round trip each.
+    template <typename WorldPos, typename Normal, typename MinDist, typename MaxDist>
+    void SetWorldPos(const std::vector<MapPointT *> &pts, WorldPos world_pos, Normal normal, MinDist min_dist, MaxDist max_dist)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        const size_t n = pts.size();
+        ids_.resize(n), wp_.resize(3 * n), nr_.resize(3 * n), mn_.resize(n), mx_.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            MapPointT *p = pts[i];
+            ids_[i] = (int64_t)p->mnId;
+            const float *w = world_pos(p), *nn = normal(p);
+            for (int c = 0; c < 3; c++)
+                wp_[3 * i + c] = w[c], nr_[3 * i + c] = nn[c];
+            mn_[i] = min_dist(p), mx_[i] = max_dist(p);
+        }
+        check(orbgpu_mappoint_table_upsert(h_, (int32_t)n, ids_.data(), wp_.data(), nr_.data(), mn_.data(), mx_.data(), nullptr,
+                                           nullptr),
+              "SetWorldPos (batch)");
+    }
+    void SetObservations(const std::vector<MapPointT *> &pts)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        const size_t n = pts.size();
+        ids_.resize(n), ob_.resize(n);
+        for (size_t i = 0; i < n; i++)
+            ids_[i] = (int64_t)pts[i]->mnId, ob_[i] = pts[i]->Observations();
+        check(orbgpu_mappoint_table_set_observations(h_, (int32_t)n, ids_.data(), ob_.data(), nullptr), "SetObservations (batch)");
+    }
+    // the count taken by the caller: for a hook that runs where MapPoint::mMutexFeatures is held (Observations() would
+    // lock it again)
+    void SetObservations(MapPointT *p, int nObs)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        const int64_t id = (int64_t)p->mnId;
+        const int32_t n = nObs;
+        check(orbgpu_mappoint_table_set_observations(h_, 1, &id, &n, nullptr), "SetObservations");
+    }
+    void SetBad(const std::vector<MapPointT *> &pts)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        ids_.resize(pts.size());
+        for (size_t i = 0; i < pts.size(); i++)
+            ids_[i] = (int64_t)pts[i]->mnId;
+        check(orbgpu_mappoint_table_set_bad(h_, (int32_t)ids_.size(), ids_.data(), nullptr), "SetBad (batch)");
+    }
+    // ids of the last table search that the table had not been told about yet (skipped rows, held key points)
+    std::pair<int, int> LastUnknown() const
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        int32_t a = 0, b = 0;
+        check(orbgpu_mappoint_table_last_unknown(h_, &a, &b), "LastUnknown");
+        return {a, b};
+    }
 
   private:
     mutable std::mutex mu_;

@@ -168,73 +168,115 @@ def c3(reps=30, device_id=0):
                                  "algorithmic_bytes": alg_ext, "note": "single frame: 14 dependent launches"}}
 
 
-def c3_batch(n_seq=128, reps=10, device_id=0):
+class C3Batch:
     """C3 in throughput mode: n_seq independent sequences (frames shard by sequence), one 1280x960 frame each per step:
-    batched extraction + frame glue + orbgpu_search_local_points_batch_device.  Every sequence has its own copy of the
-    frame, of the ~10 k-point map table and of all outputs (distinct addresses); the content is the C3 scenario."""
-    import torch
+    batched extraction + frame glue + orbgpu_search_local_points_batch_device (= per frame Tracking::SearchLocalPoints,
+    Tracking.cc:1447-1497 -> ORBmatcher::SearchByProjection(F, vpMapPoints, th), ORBmatcher.cc:45-129).  Every sequence
+    has its own copy of the frame, of the ~10 k-point map table and of all outputs (distinct addresses); the content is
+    the C3 scenario of the stream with seed `seed` (one seed per rank in bench.py --workload c3_batch)."""
+
     W, H, NF = 1280, 960, 2000
-    rng = np.random.default_rng(5678)
-    st = Stream(W, H, 1234)
-    nprev, t_cur = 5, 12
-    ts = [t_cur - 1 - i for i in range(nprev)] + [t_cur]
-    frames = [st.frame(t) for t in ts]
-    ext = G.ORBextractor(NF, max_batch=n_seq, device_id=device_id)
-    ks, ds = ext.extract_batch(np.stack([f[0] for f in frames]))
-    sf = ext.GetScaleFactors()
-    Tcw = rigid()
-    ox, oy = st.offset(t_cur)
-    wp, dsc, octv = [], [], []
-    for i, t in enumerate(ts[:-1]):
-        px, py = st.offset(t)
-        wp.append(_world_points(ks[i], frames[i][2], (ox - px, oy - py), st, Tcw, rng))
-        dsc.append(ds[i]), octv.append(ks[i]["octave"])
-    wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
-    tab = local_map_table(wp, dsc, octv, sf, Tcw, rng)
-    M = len(wp)
-    dev = "cuda:%d" % device_id
-    B = n_seq
-    img = torch.from_numpy(frames[-1][0]).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
-    depth = torch.from_numpy(frames[-1][2]).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
-    cap = ext.max_keypoints(W, H)
-    kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
-    desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
-    nout = torch.zeros(B, dtype=torch.int32, device=dev)
-    ur, dz = (torch.zeros((B, cap), dtype=torch.float32, device=dev) for _ in range(2))
-    cs = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device=dev)
-    items = torch.zeros((B, cap), dtype=torch.int32, device=dev)
-    dtab = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev).unsqueeze(0).repeat(*([B] + [1] * v.ndim)).contiguous()
-            for k, v in tab.items()}
-    k2m = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
-    counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
-    sfa = np.asarray(sf, np.float32)
-    log_sf = float(np.log(np.float32(sfa[1])))
-    cam = G.make_camera(float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), W, H)
-    problems, keep = [], []
-    for b in range(B):
-        fv = G.DeviceFrameView()
-        fv.cap, fv.n, fv.kps, fv.desc = cap, nout[b:].data_ptr(), kps[b].data_ptr(), desc[b].data_ptr()
-        fv.u_right, fv.cell_start, fv.cell_items = ur[b].data_ptr(), cs[b].data_ptr(), items[b].data_ptr()
-        fv.nlevels, fv.scale_factors = len(sfa), sfa.ctypes.data
-        fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(W), 0.0, float(H)
-        tb = G.DeviceMapPointTable()
-        tb.m = M
-        for k in dtab:
-            setattr(tb, k, dtab[k][b].data_ptr())
-        keep.append((fv, tb))
-        problems.append({"frame": fv, "table": tb, "Tcw": Tcw, "fx": float(st.fx), "fy": float(st.fy), "cx": float(st.cx),
-                         "cy": float(st.cy), "mbf": float(st.bf), "log_sf": log_sf, "d_kp_to_mp": k2m[b].data_ptr(),
-                         "d_counts": counts[b].data_ptr()})
-    stream = torch.cuda.current_stream()
-    s = stream.cuda_stream
+    PX = [1228800, 853600, 592963, 411996, 285671, 198404, 138138, 95676]
 
-    def extract_glue():
-        ext.extract_batch_device(img.data_ptr(), B, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), cap, nout.data_ptr(), s)
-        G.frame_glue_batch_device(B, cap, kps.data_ptr(), nout.data_ptr(), depth.data_ptr(), W, W * H, cam, None,
-                                  ur.data_ptr(), dz.data_ptr(), cs.data_ptr(), items.data_ptr(), s, device_id)
+    def __init__(self, n_seq=128, device_id=0, seed=1234):
+        import torch
+        W, H, NF = self.W, self.H, self.NF
+        rng = np.random.default_rng(5678)
+        st = Stream(W, H, seed)
+        nprev, t_cur = 5, 12
+        ts = [t_cur - 1 - i for i in range(nprev)] + [t_cur]
+        frames = [st.frame(t) for t in ts]
+        self.host_frames = [f[0] for f in frames]
+        self.ext = ext = G.ORBextractor(NF, max_batch=n_seq, device_id=device_id)
+        ks, ds = ext.extract_batch(np.stack([f[0] for f in frames]))
+        sf = ext.GetScaleFactors()
+        self.Tcw = Tcw = rigid()
+        ox, oy = st.offset(t_cur)
+        wp, dsc, octv = [], [], []
+        for i, t in enumerate(ts[:-1]):
+            px, py = st.offset(t)
+            wp.append(_world_points(ks[i], frames[i][2], (ox - px, oy - py), st, Tcw, rng))
+            dsc.append(ds[i]), octv.append(ks[i]["octave"])
+        wp, dsc, octv = np.concatenate(wp), np.concatenate(dsc), np.concatenate(octv)
+        self.table = tab = local_map_table(wp, dsc, octv, sf, Tcw, rng)
+        self.M = M = len(wp)
+        self.st = st
+        dev = "cuda:%d" % device_id
+        self.B = B = n_seq
+        self.device_id = device_id
+        self.img = torch.from_numpy(frames[-1][0]).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+        self.depth = torch.from_numpy(frames[-1][2]).to(dev).unsqueeze(0).repeat(B, 1, 1).contiguous()
+        self.cap = cap = ext.max_keypoints(W, H)
+        self.kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+        self.desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        self.nout = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.ur, self.dz = (torch.zeros((B, cap), dtype=torch.float32, device=dev) for _ in range(2))
+        self.cs = torch.zeros((B, 64 * 48 + 1), dtype=torch.int32, device=dev)
+        self.items = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+        self.dtab = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev).unsqueeze(0).repeat(*([B] + [1] * v.ndim)).contiguous()
+                     for k, v in tab.items()}
+        self.k2m = torch.full((B, cap), -1, dtype=torch.int32, device=dev)
+        self.counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        self.sfa = sfa = np.asarray(sf, np.float32)
+        self.log_sf = log_sf = float(np.log(np.float32(sfa[1])))
+        self.cam = G.make_camera(float(st.fx), float(st.fy), float(st.cx), float(st.cy), float(st.bf), W, H)
+        self.problems, self.keep = [], []
+        for b in range(B):
+            fv = G.DeviceFrameView()
+            fv.cap, fv.n, fv.kps, fv.desc = cap, self.nout[b:].data_ptr(), self.kps[b].data_ptr(), self.desc[b].data_ptr()
+            fv.u_right, fv.cell_start, fv.cell_items = self.ur[b].data_ptr(), self.cs[b].data_ptr(), self.items[b].data_ptr()
+            fv.nlevels, fv.scale_factors = len(sfa), sfa.ctypes.data
+            fv.min_x, fv.max_x, fv.min_y, fv.max_y = 0.0, float(W), 0.0, float(H)
+            tb = G.DeviceMapPointTable()
+            tb.m = M
+            for k in self.dtab:
+                setattr(tb, k, self.dtab[k][b].data_ptr())
+            self.keep.append((fv, tb))
+            self.problems.append({"frame": fv, "table": tb, "Tcw": Tcw, "fx": float(st.fx), "fy": float(st.fy),
+                                  "cx": float(st.cx), "cy": float(st.cy), "mbf": float(st.bf), "log_sf": log_sf,
+                                  "d_kp_to_mp": self.k2m[b].data_ptr(), "d_counts": self.counts[b].data_ptr()})
+        self.stream = torch.cuda.current_stream()
+        self.s = self.stream.cuda_stream
 
-    def search():
-        G.search_local_points_batch_device(problems, 0.5, 3.0, 0.8, stream=s, device_id=device_id)
+    def extract_glue(self):
+        B, W, H, cap, s = self.B, self.W, self.H, self.cap, self.s
+        self.ext.extract_batch_device(self.img.data_ptr(), B, W, H, W, W * H, self.kps.data_ptr(), self.desc.data_ptr(), cap,
+                                      self.nout.data_ptr(), s)
+        G.frame_glue_batch_device(B, cap, self.kps.data_ptr(), self.nout.data_ptr(), self.depth.data_ptr(), W, W * H, self.cam,
+                                  None, self.ur.data_ptr(), self.dz.data_ptr(), self.cs.data_ptr(), self.items.data_ptr(), s,
+                                  self.device_id)
+
+    def search(self):
+        G.search_local_points_batch_device(self.problems, 0.5, 3.0, 0.8, stream=self.s, device_id=self.device_id)
+
+    def step(self):
+        """One frame of every sequence: nothing is associated yet (a fresh Frame), extract + glue, then the search."""
+        self.k2m.fill_(-1)
+        self.extract_glue()
+        self.search()
+
+    def algorithmic_bytes(self, n_kp):
+        """(search, extraction) bytes per step, SURVEY.md 8d: M2 reads M*60 + N*48 + the grid (20 292 B), writes (M + N)*4;
+        extraction 20 343 764 B per frame at N = 2000."""
+        px = self.PX
+        alg_m2 = (self.M * 60 + n_kp * 48 + 20292 + (self.M + n_kp) * 4) * self.B
+        alg_ext = (sum(px[:-1]) + sum(px[1:]) + sum(px) + 2 * sum(px) + n_kp * 1321) * self.B
+        return alg_m2, alg_ext
+
+    def stage_bytes(self, stage, n_kp, n_cand):
+        """SURVEY.md 8d per stage for one 1280x960 frame."""
+        px = self.PX
+        tot = sum(px)
+        return {"pyramid": sum(px[:-1]) + sum(px[1:]), "fast": tot + 4 * n_cand, "blur": 2 * tot,
+                "orient": n_kp * (749 + 28 + 16), "describe": n_kp * (512 + 32),
+                "quadtree": 4 * n_cand * 2 + 4 * n_kp}[stage]
+
+
+def c3_batch(n_seq=128, reps=10, device_id=0):
+    """bench.py `secondary.c3_batch`: the C3Batch step timed piecewise with HIP events on one GPU."""
+    import torch
+    wl = C3Batch(n_seq, device_id)
+    B, M, stream = wl.B, wl.M, wl.stream
 
     def timed(fn, pre=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -249,22 +291,18 @@ def c3_batch(n_seq=128, reps=10, device_id=0):
             ts.append(e0.elapsed_time(e1))
         return float(np.median(ts))  # a single stalled repetition (seen once: 38 ms among 30 of 0.33 ms) must not set the figure
 
-    extract_glue()
-    k2m.fill_(-1)
-    search()
+    wl.step()
     torch.cuda.synchronize()
-    cnt = counts.cpu().numpy()
+    cnt = wl.counts.cpu().numpy()
     assert (cnt[:, 0] == cnt[0, 0]).all() and cnt[0, 0] > 0, "identical problems must give identical match counts"
-    N = int(nout[0])
-    ms_search = timed(search, pre=lambda: k2m.fill_(-1))
-    ext.set_profiling(True)
-    ms_extract = timed(extract_glue)
-    stages = ext.stage_times()
-    ext.set_profiling(False)
-    ms_chain = timed(lambda: (extract_glue(), search()), pre=lambda: k2m.fill_(-1))
-    alg_m2 = (M * 60 + N * 48 + 20292 + (M + N) * 4) * B
-    px = [1228800, 853600, 592963, 411996, 285671, 198404, 138138, 95676]
-    alg_ext = (sum(px[:-1]) + sum(px[1:]) + sum(px) + 2 * sum(px) + N * 1321) * B
+    N = int(wl.nout[0])
+    ms_search = timed(wl.search, pre=lambda: wl.k2m.fill_(-1))
+    wl.ext.set_profiling(True)
+    ms_extract = timed(wl.extract_glue)
+    stages = wl.ext.stage_times()
+    wl.ext.set_profiling(False)
+    ms_chain = timed(lambda: (wl.extract_glue(), wl.search()), pre=lambda: wl.k2m.fill_(-1))
+    alg_m2, alg_ext = wl.algorithmic_bytes(N)
     ach_s = alg_m2 / (ms_search * 1e-3) / 1e9
     ach_e = alg_ext / (ms_extract * 1e-3) / 1e9
     return {"workload": "C3 throughput mode: %d independent sequences, one synthetic 1280x960 frame each per step, 2000 "

@@ -392,6 +392,55 @@ int main(int argc, char **argv)
                     throw std::runtime_error("the editor thread never got a turn in 4000 searches");
                 std::printf("table edited %d times by a second thread during the searches (%d rows)\n", edits.load(), table.rows());
             }
+            // LocalMapping publishes a new point to the key frames (LocalMapping.cc:434-440) before it reaches the table:
+            // Tracking::UpdateLocalPoints may list it in that window.  The search must go through (the row is skipped)
+            // and say how many ids it did not know; after the upsert the count is back to zero.
+            {
+                std::vector<MapPoint> late(30);
+                std::vector<MapPoint *> vp2 = vp, latep;
+                for (size_t i = 0; i < late.size(); i++) {
+                    late[i].mnId = 9000000001ul + 3ul * i;
+                    late[i].world[2] = -5.f - (float)i;  // behind the camera: never in view once the table knows them
+                    std::memset(late[i].desc, 0x5a, 32);
+                    vp2.insert(vp2.begin() + (long)(7 * i), &late[i]);
+                    latep.push_back(&late[i]);
+                }
+                F2.mvpMapPoints.assign(F2.N, nullptr);
+                int nmt = matcher.SearchLocalPoints(F2, dF, vp2, cam[5], table, [](MapPoint *) { return false; }, tcw_of,
+                                                    [](MapPoint *, bool) {});
+                if (nmt != nm_dev || table.LastUnknown() != std::make_pair(30, 0))
+                    throw std::runtime_error("ids published before their upsert must be skipped rows, counted");
+                for (int j = 0; j < F2.N; j++)
+                    if ((F2.mvpMapPoints[j] ? F2.mvpMapPoints[j]->id : -1) != ids_dev[j])
+                        throw std::runtime_error("unknown ids in the list changed the matches");
+                table.Upsert(latep, wp_of, nr_of, mn_of, mx_of, mp_desc);
+                F2.mvpMapPoints.assign(F2.N, nullptr);
+                nmt = matcher.SearchLocalPoints(F2, dF, vp2, cam[5], table, [](MapPoint *) { return false; }, tcw_of,
+                                                [](MapPoint *, bool) {});
+                if (nmt != nm_dev || table.LastUnknown() != std::make_pair(0, 0))
+                    throw std::runtime_error("after the upsert no id is unknown");
+                // the batch setters (bundle-adjustment write-back, culling) against the one-id forms: same table contents,
+                // and what a one-id call costs on the host
+                auto t0 = clk::now();
+                for (MapPoint *p : latep)
+                    table.SetWorldPos(p, p->world);
+                const double one_us = us(t0, clk::now()) / (double)latep.size();
+                for (MapPoint *p : latep)
+                    p->world[0] += 1.f, p->nObs = 0;
+                t0 = clk::now();
+                table.SetWorldPos(latep, wp_of, nr_of, mn_of, mx_of);
+                table.SetObservations(latep);
+                table.SetBad(latep);
+                const double batch_us = us(t0, clk::now());
+                float wpos[3];
+                int32_t hobs = -1, hbad = -1;
+                orbgpu_shim::check(orbgpu_mappoint_table_read(table.handle(), (int64_t)late[7].mnId, wpos, nullptr, nullptr, nullptr, nullptr,
+                                                 &hobs, &hbad), "read");
+                if (wpos[0] != late[7].world[0] || hobs != 0 || hbad != 1)
+                    throw std::runtime_error("batch setters did not reach the table");
+                std::printf("table edits: %.0f us per one-id SetWorldPos call, %.0f us for three batch calls over %zu points\n",
+                            one_us, batch_us, latep.size());
+            }
             // edits reach the table: a point flagged bad is skipped by the next search
             if (nm_dev > 0) {
                 int victim = -1;

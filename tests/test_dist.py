@@ -84,6 +84,36 @@ def test_bench_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in out
 
 
+@pytest.mark.gpu
+def test_bench_c3_batch_two_ranks_on_one_gpu():
+    """north_star's 1280x960 line under --gpus N (`--workload c3_batch`, Tracking.cc:1447-1497 per frame): two ranks rehearsed
+    on device 0, 4 sequences each; the contract fields, the workload name and the frame count over both ranks."""
+    import json
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--rehearse-on-device0", "--workload", "c3_batch", "--steps", "2",
+                    "--warmup", "1", "--batch", "4", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["sequences"] == 8 and out["config"]["workload"].startswith("C3")
+    assert "1280x960" in out["metric"] and out["scaling"] == "weak" and out["steps"] == 2
+    frames = out["value"] * out["ms_per_step"] * 1e-3 * out["steps"]
+    assert abs(frames - 2 * 2 * 4) < 1e-6 * frames + 1e-3
+    assert out["matches_per_frame"] > 500 and out["keypoints_per_frame"] > 1900
+    assert len(out["timed_region_repeats"]["frames_per_s"]) == 3 and out["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_c3_batch_single_rank_with_cpu_baseline():
+    import json
+    r = _run_bench(["--workload", "c3_batch", "--steps", "2", "--warmup", "1", "--batch", "8"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["config"]["sequences"] == 8
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 1
+
+
 def _single_rank(backend, device, port):
     """Body of the one-rank tests; runs in a child process so that the process group never leaks into pytest."""
     import subprocess

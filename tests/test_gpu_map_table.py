@@ -154,10 +154,32 @@ def test_search_local_points_over_the_table(gpu, oracle, w, h, nfeat, nprev, th,
     no4, ko4 = oracle.search_by_projection(of, mp, th, 0.8, np.full(of.n, -1, np.int32))
     n4, k4 = gpu.search_local_points_table(dfr, tbl, ids, Tcw, fx, fy, cx, cy, bf, log_sf, th, 0.8)
     assert n4 == no4 and np.array_equal(k4, ko4)
-    bad_ids = ids.copy()
-    bad_ids[5] = 4242424242
-    with pytest.raises(RuntimeError, match="not in the MapPoint table"):
-        gpu.search_local_points_table(dfr, tbl, bad_ids, Tcw, fx, fy, cx, cy, bf, log_sf, th, 0.8)
+    # (e) ids the table has not been told about yet (LocalMapping publishes a point before its attributes are final,
+    #     LocalMapping.cc:434-440): unknown list rows are skipped rows, unknown key-point ids count as held
+    unk = rng.choice(m, 40, replace=False)
+    late_ids = ids.copy()
+    late_ids[unk] = 4242424242 + np.arange(40)
+    mp5 = dict(mp)
+    mp5["bad"] = mp["bad"].copy()
+    mp5["bad"][unk] = 1
+    k05 = np.full(of.n, -1, np.int32)
+    kp5 = np.full(of.n, -1, np.int64)
+    held = rng.choice(of.n, 25, replace=False)
+    k05[held] = -2
+    kp5[held] = 777000000 + np.arange(25)  # associations to points the table does not know: treated as held
+    no5, ko5 = oracle.search_by_projection(of, mp5, th, 0.8, k05)
+    n5b, k5b = gpu.search_local_points_table(dfr, tbl, late_ids, Tcw, fx, fy, cx, cy, bf, log_sf, th, 0.8, kp_ids=kp5)
+    assert n5b == no5 and np.array_equal(k5b, ko5)
+    assert tbl.last_unknown() == (40, 25)
+    gpu.search_local_points_table(dfr, tbl, ids, Tcw, fx, fy, cx, cy, bf, log_sf, th, 0.8)
+    assert tbl.last_unknown() == (0, 0)
+    # (f) an empty list: nothing is searched, the associations are still translated through the table -- a key point
+    #     holding an observed outside point is -2, one holding an unobserved point is -1 (as with a non-empty list)
+    n6, k6 = gpu.search_local_points_table(dfr, tbl, np.zeros(0, np.int64), Tcw, fx, fy, cx, cy, bf, log_sf, th, 0.8, kp_ids=kp_ids)
+    want6 = np.full(of.n, -1, np.int32)
+    want6[pre[:100]] = np.where(mp["obs_pos"][k0[pre[:100]]] != 0, -2, -1)  # list points are outside an empty list
+    want6[pre[100:200]] = -2
+    assert n6 == 0 and np.array_equal(k6, want6)
     # the table path and the host-pointer entry point agree as well
     n5, k5 = gpu.ORBmatcher(0.8, True).SearchByProjection(make_gframe(gpu, of), mp, th, k0)
     assert n5 == no and np.array_equal(k5, want)
