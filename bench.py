@@ -61,7 +61,7 @@ STAGE_KERNELS = {"pyramid": ["k_border0_fast"] + ["k_resize_fast"] * 7, "fast": 
                  "blur": ["k_blur"], "describe": ["k_describe"]}
 
 
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest first (the round-1 file predates the fused FAST kernel)
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest first (the round-1 file predates the fused FAST kernel)
 
 
 def pmc_traffic(stage, frames_per_launch):
@@ -85,7 +85,8 @@ def valu_issue(stage, frames_per_launch, ms_per_launch):
     the committed SQ counter pass (profiles/r03_pmc_sq.json, rocprofv3 --pmc SQ_INSTS_VALU ... at B = 256), scaled to
     this launch, against the live launch duration; the ceiling is tools/ubench/valu_rate (profiles/r02_valu_rate.txt)."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq.json")))
+        sq = [n for n in ("r04_pmc_sq.json", "r03_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))][0]
+        j = json.load(open(os.path.join(ROOT, "profiles", sq)))
         insts = sum(j["kernels"][kn]["valu_insts_per_launch"] for kn in j["kernels"]
                     if kn.split("<")[0] in STAGE_KERNELS[stage]) / 256.0 * frames_per_launch
         cyc = 1024 * ms_per_launch * 1e-3 * 2.4e9 / insts  # 1024 SIMDs at the nominal 2.4 GHz, as in r02_valu_rate.txt
@@ -96,9 +97,41 @@ def valu_issue(stage, frames_per_launch, ms_per_launch):
                         "cost is 4.3 cycles",
                 "scaled": "instruction count SCALED from the committed B = 256 counter pass to %d frames per launch; the launch "
                           "duration is live" % frames_per_launch,
-                "source": "profiles/r03_pmc_sq.json (SQ_INSTS_VALU, GRBM_GUI_ACTIVE), profiles/r02_valu_rate.txt"}
+                "source": "profiles/%s (SQ_INSTS_VALU, GRBM_GUI_ACTIVE), profiles/r02_valu_rate.txt" % sq}
     except Exception:
         return None
+
+
+VALU_CLASS_COST = {"full_rate": 2.5, "half_rate": 4.3}  # SIMD cycles per wave-instruction, tools/ubench/valu_rate (profiles/r02_valu_rate.txt)
+
+
+def valu_issue_step(frames_per_step, ms_per_step):
+    """VALU issue budget of the WHOLE step: the VALU wave-instructions of every kernel of a step (SQ
+    counter pass under profiles/, per 256 frames, scaled to this step) priced at the measured issue cost of the two
+    instruction classes, over the SIMD cycles of the live step (1024 SIMDs at 2.4 GHz)."""
+    for name in ("r04_pmc_sq.json", "r03_pmc_sq.json"):
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", name)))
+            nsteps = j["kernels"]["k_fast_detect"]["launches"]  # one launch per step
+            per = {kn: v["valu_insts_per_launch"] * v["launches"] / nsteps / 256.0 * frames_per_step
+                   for kn, v in j["kernels"].items()}
+            insts = sum(per.values())
+            simd_cycles = 1024 * ms_per_step * 1e-3 * 2.4e9
+            top = sorted(per.items(), key=lambda kv: -kv[1])
+            return {"valu_wave_insts_per_step": int(insts),
+                    "share": {k: round(v / insts, 3) for k, v in top[:8]},
+                    "simd_cycles_per_valu_inst": round(simd_cycles / insts, 2),
+                    "issue_busy_frac": {"if_all_half_rate": round(insts * VALU_CLASS_COST["half_rate"] / simd_cycles, 3),
+                                        "if_all_full_rate": round(insts * VALU_CLASS_COST["full_rate"] / simd_cycles, 3)},
+                    "note": "fraction of the step's SIMD cycles the VALU issue ports are busy, bracketed by the two measured "
+                            "instruction-class costs (%.1f / %.1f cycles); the instruction mix of the dominant kernel is mostly "
+                            "half rate" % (VALU_CLASS_COST["full_rate"], VALU_CLASS_COST["half_rate"]),
+                    "scaled": "instruction counts SCALED from the committed B = 256 counter pass (profiles/%s) to %d frames; "
+                              "the step time is live" % (name, frames_per_step),
+                    "source": "profiles/%s (SQ_INSTS_VALU), profiles/r02_valu_rate.txt" % name}
+        except Exception:
+            continue
+    return None
 
 
 def _cpu_worker(libpath, frames, seconds_budget, want_stages):
@@ -321,9 +354,13 @@ def main():
     ap.add_argument("--no-overlap-match", dest="overlap_match", action="store_false",
                     help="serialise the matcher behind the extraction (default: the matcher of step i runs on a "
                          "second stream next to the extraction of step i+1)")
+    ap.add_argument("--schedule", default="best", choices=["best", "overlap", "serial"],
+                    help="schedule of the timed region: best (default) = matcher of step i-1 on its own stream next to extraction "
+                         "i + the blur on a stream of the handle's own; overlap = the matcher stream only (round-3 default); "
+                         "serial = one stream.  Per-kernel times always come from a serial calibration pass in front of it")
     ap.add_argument("--concurrent-blur", action="store_true",
-                    help="run the blur of every extraction on a stream of the handle's own next to FAST / quadtree "
-                         "(orbgpu_extractor_set_concurrent_blur)")
+                    help="with --schedule overlap: run the blur of every extraction on a stream of the handle's own next to FAST / "
+                         "quadtree (orbgpu_extractor_set_concurrent_blur); implied by --schedule best")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3_batch"],
                     help="c2 (default, the contract line): 640x480 / 1000 features, extract + BF match.  c3_batch: the 1280x960 "
                          "stream of BASELINE.json configs[2] in throughput mode -- --batch independent sequences per GPU, one "
@@ -369,6 +406,13 @@ def main():
     W, H, NFEAT = 640, 480, 1000
     B, POOL = args.batch, max(args.pool, args.batch)
     POOL = (POOL // B) * B
+    # schedule of the TIMED region.  "best" = the fastest one measured: the matcher of step i-1 on a
+    # stream of its own next to extraction i, and the blur of every extraction on a stream of the handle's own next to
+    # FAST / quadtree.  Per-kernel times and the roofline come from a serial CALIBRATION pass in front of it, where no
+    # kernel shares the device, so the per-kernel figures and the headline no longer constrain each other.
+    sched = args.schedule if args.overlap_match else "serial"
+    overlap = sched != "serial"
+    cblur = overlap and (sched == "best" or args.concurrent_blur)
     # one independent sequence per rank
     st = Stream(W, H, D.sequence_seed(1234, rank))
     host_pool = np.stack([st.frame(t)[0] for t in range(POOL)])
@@ -376,36 +420,70 @@ def main():
 
     ext = G.ORBextractor(NFEAT, max_batch=B, device_id=local_rank)
     cap = ext.max_keypoints(W, H)
-    P = args.parts if args.overlap_match else 1
+    P = args.parts if overlap else 1
     pl = G.ExtractorPipeline(NFEAT, max_batch=B, parts=P, device_id=local_rank) if P > 1 else None
     parts = pl.parts if pl else [ext]  # the handles that run the timed extraction
-    if args.concurrent_blur:
-        for e in parts:
-            e.set_concurrent_blur(True)
     matcher = G.BatchMatcher(B, cap, device_id=local_rank)
     match_b = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
     nmatch = torch.zeros(B, dtype=torch.int32, device="cuda")
     KP, DS = cap * 28, cap * 32
-    # Two output sets (slot 0 of a set carries the previous step's last frame; this step's frames go to
-    # slots 1..B).  Extraction runs on the current stream; with --overlap-match the matcher of step i
-    # runs on a second stream next to the extraction of step i+1 (no data dependency between them).
-    nsets = (3 if args.match_after != "start" else 2) if args.overlap_match else 1  # a deferred matcher holds its set one step longer
+    # Output sets (slot 0 of a set carries the previous step's last frame; this step's frames go to slots 1..B).
+    # Extraction runs on the current stream; in the overlapped schedules the matcher of step i runs on a second stream
+    # next to the extraction of step i+1 (no data dependency between them).
+    nsets = (3 if args.match_after != "start" else 2) if overlap else 1  # a deferred matcher holds its set one step longer
     kps = [torch.zeros((B + 1, cap, 7), dtype=torch.float32, device="cuda") for _ in range(nsets)]
     desc = [torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device="cuda") for _ in range(nsets)]
     nout = [torch.zeros(B + 1, dtype=torch.int32, device="cuda") for _ in range(nsets)]
     s_ext = torch.cuda.current_stream()
-    s_match = torch.cuda.Stream() if args.overlap_match else s_ext
+    s_match = torch.cuda.Stream() if overlap else s_ext
     ev_ext = [torch.cuda.Event() for _ in range(nsets)]
     ev_match = [torch.cuda.Event() for _ in range(nsets)]
     ev_copy = [torch.cuda.Event() for _ in range(nsets)]  # slot B of set k has been carried over to the other set
 
+    def run_match(k, stream):
+        matcher.match(B, cap, desc[k].data_ptr(), kps[k].data_ptr() + 12, None, nout[k].data_ptr(),
+                      desc[k].data_ptr() + DS, kps[k].data_ptr() + KP + 12, nout[k].data_ptr() + 4, 28, 50, 0.7,
+                      True, match_b.data_ptr(), nmatch.data_ptr(), stream.cuda_stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            D.barrier(world)
+        torch.cuda.synchronize()
+
+    # ---- calibration: the serial schedule (one stream, plain handle), HIP events at every stage boundary of every step
+    #      (recorded by the library on the launch stream) and around the matcher.  Outside the timed region.
+    NCAL = 12
+    cal_pairs = []
+    for i in range(NCAL + 2):
+        src = frames[(i * B) % POOL:(i * B) % POOL + B]
+        ext.set_profiling(i >= 2)
+        ext.extract_batch_device(src.data_ptr(), B, W, H, W, W * H, kps[0].data_ptr() + KP, desc[0].data_ptr() + DS, cap,
+                                 nout[0].data_ptr() + 4, s_ext.cuda_stream)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s_ext)
+        run_match(0, s_ext)
+        b.record(s_ext)
+        if i >= 2:
+            cal_pairs.append((a, b))
+        kps[0][0].copy_(kps[0][B], non_blocking=True)
+        desc[0][0].copy_(desc[0][B], non_blocking=True)
+        nout[0][0:1].copy_(nout[0][B:B + 1], non_blocking=True)
+    torch.cuda.synchronize()
+    stage_ms = ext.stage_times()  # per stage: the launches that cover the B frames of a step, nothing else on the device
+    ext.set_profiling(False)
+    match_ms = sum(a.elapsed_time(b) for a, b in cal_pairs) / len(cal_pairs)
+    match_how = "k_bf_topk + k_bf_resolve of one step, HIP events on the launch stream, serial calibration pass (%d steps)" % NCAL
+
+    if cblur:
+        for e in parts:
+            e.set_concurrent_blur(True)
     # Overlapped schedule: the matcher of step i-1 is enqueued on its own stream while extraction i runs, and starts when
     # that extraction has passed the stage named by --match-after (the library records ev_mid there).  The brute-force
-    # matcher is matrix-core / LDS work; next to the FAST pass (VALU-bound at three waves per SIMD) or the pyramid
-    # (HBM-bound) it takes more from the extraction than next to the quadtree, whose long level-0 workgroups leave
-    # most of the device idle.
+    # matcher is matrix-core / LDS work; next to the FAST pass (VALU-bound) or the pyramid (HBM-bound) it takes more from
+    # the extraction than next to the quadtree, whose long level-0 workgroups leave most of the device idle.
     ev_mid = torch.cuda.Event()
-    if args.overlap_match and args.match_after != "start":
+    if overlap and args.match_after != "start":
         ev_mid.record(s_ext)  # torch creates the hipEvent_t on first use
         assert ev_mid.cuda_event, "no event handle"
         parts[args.match_part % len(parts)].set_stage_signal(args.match_after, ev_mid.cuda_event)
@@ -417,23 +495,10 @@ def main():
     for e in ev_gate + ev_ext:
         e.record(s_ext)  # create the handles
 
-    def run_match(k):
-        matcher.match(B, cap, desc[k].data_ptr(), kps[k].data_ptr() + 12, None, nout[k].data_ptr(),
-                      desc[k].data_ptr() + DS, kps[k].data_ptr() + KP + 12, nout[k].data_ptr() + 4, 28, 50, 0.7,
-                      True, match_b.data_ptr(), nmatch.data_ptr(), s_match.cuda_stream)
-
-    match_timing = {"on": False, "pairs": []}  # HIP events around the matcher on ITS stream, on the profiled steps
-
     def flush_match():
         if pending[0] is not None:
             with torch.cuda.stream(s_match):
-                if match_timing["on"]:
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record(s_match)
-                run_match(pending[0])
-                if match_timing["on"]:
-                    b.record(s_match)
-                    match_timing["pairs"].append((a, b))
+                run_match(pending[0], s_match)
                 ev_match[pending[0]].record(s_match)
             pending[0] = None
 
@@ -441,7 +506,7 @@ def main():
         k = i % nsets
         p = (i - 1) % nsets  # set holding the previous step's last frame (its own slot B when nsets == 1)
         src = frames[(i * B) % POOL:(i * B) % POOL + B]
-        if args.overlap_match:
+        if overlap:
             # carry-over first: set p's slot B (extraction i-1, already ordered before on s_match) -> set k's slot 0,
             # which extraction i never writes.  Extraction i+1 overwrites set p and waits for ev_copy[p].
             if i > 0:
@@ -461,7 +526,7 @@ def main():
         else:
             ext.extract_batch_device(src.data_ptr(), B, W, H, W, W * H, kps[k].data_ptr() + KP, desc[k].data_ptr() + DS,
                                      cap, nout[k].data_ptr() + 4, s_ext.cuda_stream)
-        if args.overlap_match:
+        if overlap:
             if not pl:
                 ev_ext[k].record(s_ext)
             if pending[0] is not None and args.match_after != "start":
@@ -474,74 +539,54 @@ def main():
             else:
                 pending[0] = k
         else:
-            with torch.cuda.stream(s_match):
-                run_match(k)
-                kps[0][0].copy_(kps[0][B], non_blocking=True)
-                desc[0][0].copy_(desc[0][B], non_blocking=True)
-                nout[0][0:1].copy_(nout[0][B:B + 1], non_blocking=True)
+            run_match(k, s_match)
+            kps[0][0].copy_(kps[0][B], non_blocking=True)
+            desc[0][0].copy_(desc[0][B], non_blocking=True)
+            nout[0][0:1].copy_(nout[0][B:B + 1], non_blocking=True)
 
-    def barrier():
+    def drain():
+        flush_match()
+        if pl:
+            pl.wait(s_ext.cuda_stream)
+        if overlap:
+            s_ext.wait_stream(s_match)
+
+    it = [0]  # steps issued so far: the output sets rotate with it across warm-up and the repetitions
+
+    def run_steps(n):
+        for _ in range(n):
+            step(it[0])
+            it[0] += 1
+
+    run_steps(args.warmup)
+    drain()
+    # ---- the timed region, NREP times: EXACTLY K steps each, barrier + synchronize on both sides, the last step's
+    #      matcher inside; max over ranks per repetition; `value` is the MEDIAN repetition
+    NREP = 3
+    reps = []
+    for _ in range(NREP):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        drain()
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
         if world > 1:
             D.barrier(world)
         torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    flush_match()
-    barrier()
-    # per-stage HIP events (recorded by the library on the launch stream) cost the stream a bubble per event, so
-    # they are taken on one timed step in PROF_EVERY; the averages come from those steps of the timed region
-    PROF_EVERY = 4
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        for e in parts:
-            e.set_profiling(i % PROF_EVERY == 0)
-        match_timing["on"] = args.overlap_match and i % PROF_EVERY == 0
-        step(args.warmup + i)
-    match_timing["on"] = False
-    flush_match()  # the last step's matcher belongs to the timed region
-    if pl:
-        pl.wait(s_ext.cuda_stream)
-    s_ext.wait_stream(s_match) if args.overlap_match else None
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        D.barrier(world)
-    torch.cuda.synchronize()
-    # per stage: the launches that cover the B frames of a step (one per part; with parts > 1 they run next to other
-    # parts' kernels, so their sum is not a duration of the step)
-    stage_ms = {}
-    for e in parts:
-        for name, v in e.stage_times().items():
-            stage_ms[name] = stage_ms.get(name, 0.0) + v
-        e.set_profiling(False)
-    # serial schedule only: what the step spends outside the extraction stages = the matcher (+ 3 small copies);
-    # with the matcher on its own stream the difference is not a duration of anything
-    if not args.overlap_match:
-        match_ms = max(ev0.elapsed_time(ev1) / args.steps - sum(stage_ms.values()), 0.0)
-        match_how = "step time minus the six extraction stages (serial schedule, one stream)"
-    else:  # k_bf_topk + k_bf_resolve of one step, timed on the matcher's own stream while the next extraction shares the device
-        match_ms = (sum(a.elapsed_time(b) for a, b in match_timing["pairs"]) / len(match_timing["pairs"])
-                    if match_timing["pairs"] else None)
-        match_how = ("HIP events on the matcher's stream around the %d-pair match of a step, every %dth timed step; it runs "
-                     "next to the following extraction, so it is not additive with the extraction stages" % (B, PROF_EVERY))
-
-    elapsed_max, total_frames = D.aggregate(elapsed, B * args.steps, world,
-                                            device="cuda" if args.backend == "nccl" else "cpu")
+        reps.append(D.aggregate(elapsed, B * args.steps, world, device="cuda" if args.backend == "nccl" else "cpu"))
+    order = sorted(range(NREP), key=lambda r: reps[r][0])
+    elapsed_max, total_frames = reps[order[NREP // 2]]
 
     # sanity of the measured work (rank-local): every frame produced key points and matches
     n_host = nout[0].cpu().numpy()
     nm_host = nmatch.cpu().numpy()
     sweeps = matcher.last_sweeps(B)
     assert n_host[1:].min() > 0 and nm_host.min() >= 0, "benchmark produced empty frames"
-    if args.steps > 0 and args.warmup + args.steps > 1 and not args.no_self_check:
+    if args.steps > 0 and it[0] > 1 and not args.no_self_check:
         # the pipelined schedule must give what a serial schedule gives: redo the last step from the frames, one
         # stream, fresh buffers (previous step's last frame -> slot 0, this step's frames -> slots 1..B), and compare
-        last_i = args.warmup + args.steps - 1
+        last_i = it[0] - 1
         c_kps, c_desc, c_n = torch.zeros_like(kps[0]), torch.zeros_like(desc[0]), torch.zeros_like(nout[0])
         chk_b, chk_n = torch.zeros_like(match_b), torch.zeros_like(nmatch)
         s0 = torch.cuda.current_stream().cuda_stream
@@ -559,27 +604,28 @@ def main():
 
     n_kp = float(n_host[1:].mean())
 
-    # What the opt-in schedule is worth on this box (informational, after the contract's timed region): the same loop with
-    # the blur of every extraction on a stream of the handle's own (orbgpu_extractor_set_concurrent_blur).
-    upside = None
-    if world == 1 and not args.no_secondary and P == 1 and not args.concurrent_blur and args.overlap_match and args.steps >= 10:
-        ext.set_concurrent_blur(True)
-        i0, nup = args.warmup + args.steps, 30
-        for i in range(3):
-            step(i0 + i)
-        flush_match()
+    # What the other schedules give on this box (informational, after the contract's timed region): the same loop without
+    # the concurrent blur (the r03 default); the serial schedule is the calibration pass.
+    others = None
+    if world == 1 and not args.no_secondary and P == 1 and cblur and args.steps >= 10:
+        ext.set_concurrent_blur(False)
+        nup = 30
+        run_steps(3)
+        drain()
         torch.cuda.synchronize()
         tu = time.perf_counter()
-        for i in range(nup):
-            step(i0 + 3 + i)
-        flush_match()
-        s_ext.wait_stream(s_match)
+        run_steps(nup)
+        drain()
         torch.cuda.synchronize()
         tu = time.perf_counter() - tu
-        ext.set_concurrent_blur(False)
-        upside = {"concurrent_blur": {"frames_per_s": B * nup / tu, "ms_per_step": tu / nup * 1e3, "steps": nup,
-                                      "note": "bench.py --concurrent-blur makes it the timed schedule; not the default because "
-                                              "the dominant kernel's stage time then contains the blur running next to it"}}
+        ext.set_concurrent_blur(True)
+        others = {"overlapped_matcher_only": {"frames_per_s": B * nup / tu, "ms_per_step": tu / nup * 1e3, "steps": nup,
+                                              "note": "bench.py --schedule overlap: matcher on its own stream, blur in line (the "
+                                                      "round-3 default)"},
+                  "serial_calibration": {"ms_per_step": sum(stage_ms.values()) + match_ms,
+                                         "frames_per_s": B / ((sum(stage_ms.values()) + match_ms) * 1e-3),
+                                         "note": "one stream, HIP events at every stage boundary (they cost the stream a bubble "
+                                                 "each): bench.py --schedule serial times it without the events"}}
 
     if rank == 0:
         # dominant kernel of the extraction pipeline + its roofline fraction
@@ -601,12 +647,9 @@ def main():
                 per_stage[k]["hbm_traffic_GB/s_scaled_pmc"] = round(tb / (max(stage_ms[k], 1e-6) * 1e-3) / 1e9, 1)
         traffic, traffic_src = pmc_traffic(dom, B)
         ext_bytes = sum(algorithmic_bytes(k, n_kp, n_cand) for k in ("pyramid", "fast", "blur", "orient", "describe"))
-        # one part: the six stages follow each other, their sum is the extraction time of a step.  Several parts: the
-        # stages of different parts overlap, so the step time itself (which also holds the matcher) is the denominator
-        ext_ms = sum(stage_ms.values()) if P == 1 else elapsed_max / args.steps * 1e3
-        if P == 1 and args.concurrent_blur:
-            ext_ms -= stage_ms["blur"]  # it ran next to fast / quadtree on its own stream, inside their stage times
+        ext_ms = sum(stage_ms.values())  # serial calibration: the six stages follow each other
         ext_ach = ext_bytes * B / (ext_ms * 1e-3) / 1e9
+        step_ms = elapsed_max / args.steps * 1e3
         out = {
             "metric": "frames/sec ORB extract+match (640x480, 1000 feat)",
             "value": total_frames / elapsed_max,
@@ -614,12 +657,16 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            "timed_region_repeats": {"n": NREP, "frames_per_s": [round(t / e, 1) for e, t in reps],
+                                     "ms_per_step": [round(e / args.steps * 1e3, 4) for e, _ in reps],
+                                     "spread_pct": round(100 * (max(e for e, _ in reps) - min(e for e, _ in reps)) / elapsed_max, 2),
+                                     "value_is": "the median repetition; every repetition is K steps between barrier + synchronize"},
             "config": {"workload": "C2: synthetic 640x480 RGB-D stream, 1000 features, 8 levels, extract + BF-Hamming "
                                    "match of consecutive frames", "frames_per_step_per_gpu": B,
                        "resident_frame_pool": POOL, "sequences": world, "parallelism": "1 sequence per GPU",
@@ -627,23 +674,25 @@ def main():
                                      "previous one has passed its pyramid stage); " % (P, P) if pl else "") +
                                     ("matcher of step i-1 on a stream of its own, started when extraction i has passed its '%s' stage"
                                      % args.match_after if args.match_after != "start" else
-                                     "matcher of step i overlapped with extraction of step i+1 (2 streams)"))
-                       if args.overlap_match else "serial, 1 stream", "extraction_parts": P},
+                                     "matcher of step i overlapped with extraction of step i+1 (2 streams)") +
+                                    ("; blur of every extraction on a stream of the handle's own next to FAST / quadtree" if cblur else ""))
+                       if overlap else "serial, 1 stream", "schedule_name": sched, "extraction_parts": P},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": algorithmic_bytes(dom, n_kp, n_cand) * B,
-                         "ms_per_launch": stage_ms[dom], "frames_per_launch": B, "launches": P,
-                         "launch_note": None if P == 1 else "ms_per_launch = the %d sub-batch launches of a step, each timed "
-                         "with HIP events on its own stream while the other parts' kernels share the device" % P},
-            "stages": dict(per_stage, **({"match": {"ms": round(match_ms, 4), "how": match_how}} if match_ms is not None else {})),
+                         "ms_per_launch": stage_ms[dom], "frames_per_launch": B, "launches": 1,
+                         "measured_in": "serial calibration pass of this run (%d steps, nothing else on the device), HIP events "
+                                        "on the launch stream" % NCAL},
+            "stages": dict(per_stage, **{"match": {"ms": round(match_ms, 4), "how": match_how}}),
+            "stages_measured_in": "serial calibration pass (not the timed region, whose schedule overlaps kernels)",
             "valu_issue": valu_issue(dom, B, stage_ms[dom]),
+            "valu_issue_step": valu_issue_step(B, step_ms),
             "extract_ms_per_step": round(ext_ms, 4),
             "extract_roofline": {"achieved": ext_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ext_ach / HBM_PEAK_GBS,
                                  "algorithmic_bytes": ext_bytes * B,
-                                 "note": "all six extraction stages of one step against SURVEY.md 8d's 5.74 MB/frame" +
-                                         ("" if P == 1 else "; time = the whole step (parts overlap, the matcher runs inside it)")},
+                                 "note": "all six extraction stages of one step (serial calibration) against SURVEY.md 8d's 5.74 MB/frame"},
             "fast_candidates_per_frame": n_cand,
-            "match_ms_per_step": None if match_ms is None else round(match_ms, 4),
+            "match_ms_per_step": round(match_ms, 4),
             "keypoints_per_frame": n_kp,
             "matches_per_frame": float(nm_host.mean()),
             "bf_sweeps_max": int(sweeps.max()),
@@ -658,8 +707,8 @@ def main():
             out["roofline"]["practical_peak"] = {"copy_kernel_GB/s": copy_gbs, "frac_of_practical": ach / copy_gbs,
                                                  "what": "16 B/lane device-to-device copy, 1 GiB, read + write bytes"}
             out["secondary"] = {}
-            if upside:
-                out["secondary"]["c2_schedules"] = upside
+            if others:
+                out["secondary"]["c2_schedules"] = others
             for name, fn in (("c3", workloads.c3), ("c3_batch", workloads.c3_batch), ("c4", workloads.c4)):
                 try:
                     r = fn(device_id=local_rank)
@@ -671,7 +720,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline([host_pool[i] for i in range(min(POOL, 400))])
         print(json.dumps(out), flush=True)
     D.finalize(world)
-
 
 if __name__ == "__main__":
     main()

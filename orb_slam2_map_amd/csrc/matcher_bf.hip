@@ -760,6 +760,20 @@ static int match_host(const uint8_t *desc_a, const float *angle_a, const uint8_t
         orbgpu_matcher *m = nullptr;
         hipStream_t st = nullptr;
         DevBuf da, db, aa, ab, va, cnt, mb, nm, nda, ndb;
+        ~Ws()  // end of the owning thread: release, unless the process is exiting (workspace.h)
+        {
+            if (device < 0 || process_exiting().load())
+                return;
+            (void)hipSetDevice(device);
+            if (st)
+                (void)hipStreamSynchronize(st);
+            if (m)
+                orbgpu_matcher_destroy(m);
+            for (DevBuf *b : {&da, &db, &aa, &ab, &va, &cnt, &mb, &nm, &nda, &ndb})
+                b->release();
+            if (st)
+                (void)hipStreamDestroy(st);
+        }
     };
     int rc = select_device(device_id);
     if (rc != ORBGPU_OK)

@@ -619,9 +619,26 @@ struct ProjWorkspace {
     unsigned attr_set = 0;  // bit per call site: the dynamic-LDS limit of its kernels has been raised ON THIS DEVICE
     DevBuf kp_x, kp_y, kp_octave, u_right, desc, cell_start, cell_items, kp_angle;
     DevBuf queries, row_desc, row_angle, claim_init, topk, match, slow, k2m, out, inv_sigma2, tri, problems, sweeps;
+    void release_device_resources()
+    {
+        DevBuf *bufs[] = {&kp_x,  &kp_y,  &kp_octave, &u_right, &desc, &cell_start, &cell_items, &kp_angle, &queries, &row_desc, &row_angle,
+                          &claim_init, &topk, &match, &slow, &k2m, &out, &inv_sigma2, &tri, &problems, &sweeps};
+        for (DevBuf *b : bufs)
+            b->release();
+        if (stream)
+            (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
     ~ProjWorkspace()
     {
-        // device memory is released with the process; the HIP runtime may already be gone here
+        // end of the owning thread (or proj_workspace_delete): give the stream and the buffers back -- unless the process
+        // is exiting, when the HIP runtime may already be gone and everything goes with the process (workspace.h)
+        if (device >= 0 && !process_exiting().load()) {
+            (void)hipSetDevice(device);
+            if (stream)
+                (void)hipStreamSynchronize(stream);
+            release_device_resources();
+        }
     }
 };
 
@@ -629,19 +646,7 @@ struct ProjWorkspace {
 // buffers with asynchronous calls the same thread has in flight on another stream) installs it for the duration of a call.
 static thread_local ProjWorkspace *t_ws_override = nullptr;
 ProjWorkspace *proj_workspace_new() { return new (std::nothrow) ProjWorkspace(); }
-void proj_workspace_delete(ProjWorkspace *ws)
-{
-    if (!ws)
-        return;
-    DevBuf *bufs[] = {&ws->kp_x,  &ws->kp_y,     &ws->kp_octave, &ws->u_right,    &ws->desc,  &ws->cell_start, &ws->cell_items,
-                      &ws->kp_angle, &ws->queries, &ws->row_desc, &ws->row_angle, &ws->claim_init, &ws->topk, &ws->match,
-                      &ws->slow,  &ws->k2m,      &ws->out,       &ws->inv_sigma2, &ws->tri,   &ws->problems,   &ws->sweeps};
-    for (DevBuf *b : bufs)
-        b->release();
-    if (ws->stream)
-        (void)hipStreamDestroy(ws->stream);
-    delete ws;
-}
+void proj_workspace_delete(ProjWorkspace *ws) { delete ws; }  // the destructor releases
 ProjWorkspaceScope::ProjWorkspaceScope(ProjWorkspace *ws) : prev_(t_ws_override) { t_ws_override = ws; }
 ProjWorkspaceScope::~ProjWorkspaceScope() { t_ws_override = prev_; }
 

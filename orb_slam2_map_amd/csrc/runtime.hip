@@ -1,10 +1,18 @@
 // Error reporting, device selection and the ABI's bookkeeping entry points.
 #include "common.h"
+#include "workspace.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace orbgpu {
+
+// see workspace.h: from here on per-thread workspaces are dropped without HIP calls
+__attribute__((constructor)) static void register_exit_flag()
+{
+    std::atexit([] { process_exiting().store(true); });
+}
 
 static thread_local char t_err[512] = "";
 

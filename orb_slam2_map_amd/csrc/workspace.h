@@ -8,10 +8,23 @@
 // one workspace per device, nothing is reused across devices and nothing is dropped on a switch.
 #pragma once
 
+#include <atomic>
 #include <memory>
 #include <vector>
 
 namespace orbgpu {
+
+// A workspace dies with its thread (the thread_local table below) and must give its stream and device buffers back
+// then: a caller that matches from short-lived worker threads would otherwise leak ~20 buffers and a stream per thread.
+// The one moment it must NOT touch HIP is process exit, when the runtime may already be torn down: the library
+// registers an atexit handler at load time (runtime.hip) that raises this flag; libamdhip64 was loaded before
+// liborbgpu (it is a dependency), so its own handlers ran their registration earlier and run their teardown LATER than
+// ours.  Workspace destructors release their device resources iff the flag is still down.
+inline std::atomic<bool> &process_exiting()
+{
+    static std::atomic<bool> flag{false};
+    return flag;
+}
 
 template <typename W> W &per_device_workspace(int device_id)
 {

@@ -92,3 +92,41 @@ def test_concurrent_threads_own_handles_and_stateless_matchers(gpu, oracle, stre
         t.join(300)
     assert not errors, errors
     assert all(not t.is_alive() for t in ts)
+
+
+def test_short_lived_worker_threads_give_their_workspaces_back(gpu, stream640):
+    """A caller that matches from short-lived worker threads: every thread's workspace (a stream, ~20 device buffers, a
+    matcher handle) is released when the thread ends (csrc/workspace.h), so device memory does not grow with the number
+    of threads that ever called in."""
+    import torch
+    st = stream640
+    ge = gpu.ORBextractor(1000, max_batch=2)
+    (ka, kb), (da, db) = ge.extract_batch(np.stack([st.frame(3)[0], st.frame(4)[0]]))
+    want = gpu.ORBmatcher(0.7, True).MatchBruteForce(da, ka["angle"], db, kb["angle"])
+    errors = []
+
+    def worker():
+        try:
+            got = gpu.ORBmatcher(0.7, True).MatchBruteForce(da, ka["angle"], db, kb["angle"])
+            assert got[0] == want[0] and np.array_equal(got[1], want[1])
+            d = gpu.ORBmatcher.DescriptorDistance(da[:64], db[:64])
+            assert len(d) == 64
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+
+    def run(n):
+        for _ in range(n):
+            t = threading.Thread(target=worker)
+            t.start()
+            t.join(120)
+            assert not t.is_alive()
+
+    run(4)  # allocator pools, code objects, the first-use costs
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    run(40)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert not errors, errors
+    # one brute-force workspace is ~0.5 MB of buffers + a matcher handle; 40 leaked ones would be tens of MB
+    assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MB over 40 worker threads" % ((free0 - free1) / 2**20)

@@ -7,13 +7,22 @@
 #include <thread>
 
 struct Fake {
-    static int live;
+    static int live, released, dropped;
     int device = -1;
     int stream_of_device = -1;  // stands for the hipStream_t / DevBufs created on `device`
     Fake() { live++; }
-    ~Fake() { live--; }
+    ~Fake()  // the shape of ProjWorkspace / the brute-force Ws: release on thread exit, never while the process exits
+    {
+        live--;
+        if (device < 0)
+            return;
+        if (orbgpu::process_exiting().load())
+            dropped++;
+        else
+            released++;  // "hipSetDevice(device); hipStreamDestroy(stream); hipFree(...)"
+    }
 };
-int Fake::live = 0;
+int Fake::live = 0, Fake::released = 0, Fake::dropped = 0;
 
 static Fake &use(int device)
 {
@@ -53,6 +62,28 @@ int main()
     t.join();
     CHECK(other_thread_ok);             // workspaces are per thread: no sharing of a stream between host threads
     CHECK(Fake::live == 3);             // the other thread's workspace went away with the thread
+    CHECK(Fake::released == 1 && Fake::dropped == 0);  // ... and gave its device resources back (the runtime is alive)
+    // a pool of short-lived workers, two devices each: everything they created is released at their exit
+    for (int k = 0; k < 8; k++) {
+        std::thread w([&] { use(1), use(2); });
+        w.join();
+    }
+    CHECK(Fake::live == 3 && Fake::released == 1 + 16 && Fake::dropped == 0);
+    // a workspace that was never bound to a device has nothing to release
+    {
+        std::thread w([&] { (void)orbgpu::per_device_workspace<Fake>(5); });
+        w.join();
+    }
+    CHECK(Fake::released == 17);
+    // process exit: the library's atexit handler raises the flag before the HIP runtime is torn down; a thread that
+    // ends after that must not touch the device any more
+    orbgpu::process_exiting().store(true);
+    {
+        std::thread w([&] { use(4); });
+        w.join();
+    }
+    CHECK(Fake::released == 17 && Fake::dropped == 1);
+    orbgpu::process_exiting().store(false);
     std::printf("workspace_test ok\n");
     return 0;
 }

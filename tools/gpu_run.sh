@@ -32,10 +32,10 @@ profserial) run profserial 420 bash -c "cd /tmp && export TMPDIR=/tmp && rocprof
 extra) run extra 420 bash -c "python tools/bench_extra.py c1 c3 c4 pcie > $OUT/extra.json 2> $OUT/extra.err; cat $OUT/extra.json; tail -5 $OUT/extra.err" ;;
 ubench) run ubench 300 bash -c "cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o valu_rate valu_rate.hip && ./valu_rate > $OUT/valu_rate.txt 2>&1; cat $OUT/valu_rate.txt" ;;
 ab) # A/B of schedule options on the C2 bench line (40 steps each, same process settings otherwise)
-    for v in ${AB_VARIANTS:-"base:" "cblur:--concurrent-blur" "p4:--parts 4" "base2:"}; do
+    for v in ${AB_VARIANTS:-"best:" "overlap:--schedule@overlap" "p4:--parts@4" "p2:--parts@2" "serial:--schedule@serial" "best2:"}; do
         name=${v%%:*}; rest=${v#*:}; envs=""; flags=""
-        for t in $rest; do case $t in @*) envs="$envs ${t#@}";; *) flags="$flags $t";; esac; done
-        run ab_$name 300 bash -c "env $envs python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary $flags > $OUT/ab_$name.json 2> $OUT/ab_$name.err; python -c \"import json; j=json.loads(open('$OUT/ab_$name.json').read().strip().splitlines()[-1]); print('$name', round(j['value']), round(j['ms_per_step'],4), {k: v['ms'] for k, v in j['stages'].items()})\""
+        for t in $rest; do case $t in @*) envs="$envs ${t#@}";; *) flags="$flags ${t//@/ }";; esac; done
+        run ab_$name 300 bash -c "env $envs python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary $flags > $OUT/ab_$name.json 2> $OUT/ab_$name.err; python -c \"import json; j=json.loads(open('$OUT/ab_$name.json').read().strip().splitlines()[-1]); print('$name', round(j['value']), round(j['ms_per_step'],4), j['timed_region_repeats']['frames_per_s'], {k: v['ms'] for k, v in j['stages'].items()})\""
     done ;;
 *) echo "unknown step $step" ;;
 esac

@@ -6,7 +6,11 @@
 Units (MI355X_MICROARCH.md, per-instruction constants): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles
 summed over waves; SQ_INSTS_* count wave-instructions; GRBM_GUI_ACTIVE is summed over the 8 XCDs.  Derived per kernel:
   duration_us          from the dispatch timestamps of the counter pass (profiled clock, a few % slower than unprofiled)
-  valu_per_simd_cycle  SQ_INSTS_VALU / (1024 SIMDs x duration x clock), clock = GRBM_GUI_ACTIVE / 8 / duration
+  clock_GHz            GRBM_GUI_ACTIVE / 8 / duration for launches of >= 100 us.  The counter window of a dispatch is wider
+                       than the dispatch (it includes the serialisation the counter pass puts around every launch), so for
+                       short kernels that quotient is not a clock (round 3 printed 5.2 GHz for k_trig): kernels under
+                       100 us per launch take the median clock of the long ones and say so (clock_source)
+  valu_per_simd_cycle  SQ_INSTS_VALU / (1024 SIMDs x duration x clock)
   cycles_per_valu      its inverse: SIMD cycles available per VALU wave-instruction (the issue ceiling measured by
                        tools/ubench/valu_rate is 2.5 cycles for the full-rate class and 4.3 for the half-rate class)
   wave_*_frac          ACTIVE_INST_ANY, WAIT_ANY, WAIT_INST_ANY as fractions of WAVE_CYCLES
@@ -42,14 +46,24 @@ def main():
     a2, _ = collect(sys.argv[2])
     tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
     out = {}
+    # clock: only launches long enough for the counter window to be the launch
+    raw_clock = {}
+    for name in a1:
+        g = sum(a1[name].get("GRBM_GUI_ACTIVE", []))
+        us = sum(d1[name].values())
+        raw_clock[name] = g / 8 / us / 1e3 if g and us else 0.0
+    longk = sorted(raw_clock[n] for n in a1 if raw_clock[n] and sum(d1[n].values()) / len(d1[n]) >= 100.0)
+    ref_clock = longk[len(longk) // 2] if longk else 2.4
     for name in a1:
         c = {k: sum(v) for k, v in a1[name].items()}
         c.update({k: sum(v) for k, v in a2.get(name, {}).items()})
         n = len(d1[name])
         us = sum(d1[name].values())
-        clock = c["GRBM_GUI_ACTIVE"] / 8 / us / 1e3 if c.get("GRBM_GUI_ACTIVE") else 0.0  # GHz
+        own = us / n >= 100.0 and raw_clock[name] > 0
+        clock = raw_clock[name] if own else ref_clock  # GHz
         simd_cycles = SIMDS * us * 1e3 * clock
         k = {"launches": n, "duration_us": round(us / n, 1), "clock_GHz": round(clock, 2),
+             "clock_source": "GRBM_GUI_ACTIVE of its own launches" if own else "median of the kernels >= 100 us per launch (own quotient %.2f is not a clock)" % raw_clock[name],
              "valu_insts_per_launch": int(c.get("SQ_INSTS_VALU", 0) / n), "salu_insts_per_launch": int(c.get("SQ_INSTS_SALU", 0) / n),
              "waves_per_launch": int(c.get("SQ_WAVES", 0) / n)}
         if simd_cycles and c.get("SQ_INSTS_VALU"):
