@@ -709,7 +709,8 @@ def main():
             out["secondary"] = {}
             if others:
                 out["secondary"]["c2_schedules"] = others
-            for name, fn in (("c3", workloads.c3), ("c3_batch", workloads.c3_batch), ("c4", workloads.c4)):
+            for name, fn in (("c3", workloads.c3), ("c3_batch", workloads.c3_batch), ("c4", workloads.c4),
+                             ("c2_fast_early_out", workloads.c2_fast_early_out)):
                 try:
                     r = fn(device_id=local_rank)
                     r.pop("per_keyframe", None)

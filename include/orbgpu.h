@@ -173,6 +173,13 @@ int orbgpu_extractor_set_profiling(orbgpu_extractor *h, int32_t enable);
  * pyramid and joined in front of the descriptor stage.  Results are unchanged; with profiling on, the blur's stage time
  * is the one measured on its own stream (it overlaps the "fast" / "quadtree" stage times). */
 int orbgpu_extractor_set_concurrent_blur(orbgpu_extractor *h, int32_t enable);
+/* Option of the FAST stage (no counterpart in the reference, results unchanged): before the corner-score network of a
+ * pixel pair runs, an exact bound from the four compass pixels of the ring (cv::FAST's own high-speed test, A4: an arc of
+ * 9 contains two adjacent compass pixels) is evaluated; where it clears every pixel pair of a wavefront's row segment, the
+ * network is skipped.  Pays on images with flat regions (walls, table tops); costs ~20 % of the FAST stage on images that
+ * are textured everywhere, like the synthetic benchmark stream -- hence off by default.  Environment variable
+ * ORBGPU_FAST_EARLY_OUT=1 turns it on for handles created afterwards. */
+int orbgpu_extractor_set_fast_early_out(orbgpu_extractor *h, int32_t enable);
 /* Pipelining aid for callers that run other work next to an extraction (bench.py starts the matcher of the previous
  * batch there): `hip_event` (a hipEvent_t, or NULL to clear) is recorded on the launch stream of every later
  * orbgpu_extract_batch_device call right after stage `stage` (index as in orbgpu_extractor_stage_name). */

@@ -461,6 +461,28 @@ __device__ __forceinline__ pk16 fast_score_half(const RowU &r0, const RowU &r1, 
     return fast_score_pk(c, p);
 }
 
+// Exact upper bound of the corner score from the four compass pixels (0,3) (3,0) (0,-3) (-3,0): an arc of 9 contiguous
+// ring pixels contains two ADJACENT compass pixels, so
+//   bright score <= max over adjacent pairs of min(p_a, p_b) - c,   dark score <= c - min over adjacent pairs of max(p_a, p_b).
+// Returns the sign bits of the lanes' two pixels that MAY exceed the threshold (0 = neither can be a corner at t, whose
+// score may then be written as 0 without changing any output: a non-corner's score is only ever compared as "<= t").
+// 18 packed operations against the 72 of the two score networks of a pixel pair.
+template <int ODD>
+__device__ __forceinline__ uint32_t fast_maybe_half(const RowU &r0, const RowU &r3, const RowU &r6, pkh tpk)
+{
+    const pkh c = as_h(ring_half<0, ODD>(r3));
+    const pkh p0 = as_h(ring_half<0, ODD>(r6)), p4 = as_h(ring_half<3, ODD>(r3));
+    const pkh p8 = as_h(ring_half<0, ODD>(r0)), p12 = as_h(ring_half<-3, ODD>(r3));
+    const pkh bm = hmax3(__builtin_elementwise_minimum(p0, p4), __builtin_elementwise_minimum(p4, p8),
+                         __builtin_elementwise_maximum(__builtin_elementwise_minimum(p8, p12), __builtin_elementwise_minimum(p12, p0)));
+    const pkh dm = hmin3(__builtin_elementwise_maximum(p0, p4), __builtin_elementwise_maximum(p4, p8),
+                         __builtin_elementwise_minimum(__builtin_elementwise_maximum(p8, p12), __builtin_elementwise_maximum(p12, p0)));
+    const pk16 ci = h_as_pk(c), ti = h_as_pk(tpk);
+    const uint32_t eb = as_u32((ci + ti) - h_as_pk(bm));  // negative <=> bm - c > t
+    const uint32_t ed = as_u32(h_as_pk(dm) - (ci - ti));  // negative <=> c - dm > t
+    return (eb | ed) & 0x80008000u;
+}
+
 struct StripGeom {  // strips of all levels, flattened (k_blur)
     int first[ORBGPU_MAX_LEVELS + 1];  // first strip index of each level
     int nsx[ORBGPU_MAX_LEVELS];        // strips per row of strips
@@ -498,6 +520,7 @@ struct StripGeom {  // strips of all levels, flattened (k_blur)
 constexpr int FD_OWN = 62;    // columns a wave owns (lanes 1..62)
 constexpr int FD_QCAP = 512;  // row records a wave can queue before it falls back to emitting them directly
 constexpr int FD_CELLS = 32;  // cells a wave's 64 columns can touch (consecutive ids)
+constexpr int FD_EARLY_HOLD = 3;  // k_fast_detect<true>: rows scored without the early-out test after a test that found work
 
 struct DetectGeom {
     int first[ORBGPU_MAX_LEVELS + 1];  // first flat column strip of each level (bands x dword columns)
@@ -530,6 +553,9 @@ __device__ __forceinline__ void detect_record(uint32_t sc4, uint32_t rec, const 
     }
 }
 
+// EARLY: skip the score network of a half row (a pixel pair per lane) when the compass bound clears it for the whole wave --
+// exact, pays on images with flat regions (orbgpu_extractor_set_fast_early_out); off, the kernel is the round-3 one.
+template <bool EARLY>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fast_detect(const uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                      const LevelGeom *__restrict__ geom, DetectGeom dg,
                                                      const ColumnInfo *__restrict__ ctab,
@@ -654,12 +680,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         unpack_row(nx, G);                                                                                   \
         if ((k) + 1 < rows)                                                                                  \
             FD_FETCH((k) + 7)                                                                                \
-        const pk16 se = fast_score_half<0>(A, B, C, D, E, F, G);                                             \
+        pk16 se = {0, 0}, so = {0, 0};                                                                       \
+        bool runE = true, runO = true;                                                                       \
+        if (EARLY) {                                                                                         \
+            if (hold == 0) {                                                                                 \
+                runE = __builtin_amdgcn_ballot_w64(fast_maybe_half<0>(A, D, G, tpk) != 0u) != 0ull;          \
+                runO = __builtin_amdgcn_ballot_w64(fast_maybe_half<1>(A, D, G, tpk) != 0u) != 0ull;          \
+                hold = (runE && runO) ? FD_EARLY_HOLD : 0;                                                   \
+            } else                                                                                           \
+                hold--;                                                                                      \
+        }                                                                                                    \
+        if (runE)                                                                                            \
+            se = fast_score_half<0>(A, B, C, D, E, F, G);                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        const pk16 so = fast_score_half<1>(A, B, C, D, E, F, G);                                             \
+        if (runO)                                                                                            \
+            so = fast_score_half<1>(A, B, C, D, E, F, G);                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         nms_row(as_u32(se), as_u32(so), (k));                                                                \
     }
+    // EARLY: rows to go before the bound is evaluated again -- after a row whose segment was NOT clear the next
+    // FD_EARLY_HOLD rows run the network untested (textured regions pay a quarter of the test), after a clear one every row is
+    // tested (flat regions are contiguous).  Only the cost depends on it: the bound is exact whenever it is used.
+    int hold = 0;
     Row3 nx;  // next input row (raw), fetched one step ahead
     nx.d[0] = nx.d[1] = nx.d[2] = 0u;
 #pragma unroll
@@ -2015,6 +2057,7 @@ struct orbgpu_extractor {
     bool qt_no_prefilter = false;  // ORBGPU_DEBUG_QT_NOPRE: single frames filter their keys inside k_quadtree<true> (tests, A/B)
     int qt_keys_hook = -1;  // ORBGPU_DEBUG_QT_KEYS (read at creation): LDS key share of k_quadtree<true>; -1 = as many as fit
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
+    bool fast_early_out = false;   // k_fast_detect<true>: exact wave-level early-out (orbgpu_extractor_set_fast_early_out; ORBGPU_FAST_EARLY_OUT=1 at creation)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
     TrigTable trig = {nullptr, nullptr, nullptr, 0u};  // the host libm's cosf / sinf exceptions (trig.hip); none in ORBGPU_TRIG_ROUNDED_DOUBLE mode
 
@@ -2533,7 +2576,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     {
         const int t_ini = std::max(e->prm.ini_th_fast, 1), t_min = std::max(e->prm.min_th_fast, 1);
         const int nwaves = (e->det_geom.first[nl] + FD_OWN - 1) / FD_OWN;
-        hipLaunchKernelGGL(k_fast_detect, dim3((nwaves + 3) / 4, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg,
+        hipLaunchKernelGGL(e->fast_early_out ? k_fast_detect<true> : k_fast_detect<false>, dim3((nwaves + 3) / 4, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg,
                            e->det_geom, e->d_ctab.as<ColumnInfo>(), e->d_cells.as<CellDesc>(), (int)e->cells.size(),
                            e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(), std::min(t_ini, t_min),
                            t_ini, e->fast_queue_cap);
@@ -2619,6 +2662,8 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
     e->qt_no_prefilter = getenv("ORBGPU_DEBUG_QT_NOPRE") != nullptr;
     if (const char *q = getenv("ORBGPU_DEBUG_QT_KEYS"))  // test hook, read here like the others (configure() runs at the first extraction)
         e->qt_keys_hook = std::max(atoi(q), 0);
+    if (const char *q = getenv("ORBGPU_FAST_EARLY_OUT"))  // default of the option for handles created from now on (fuzzing, A/B)
+        e->fast_early_out = atoi(q) != 0;
     if (const char *q = getenv("ORBGPU_DEBUG_FAST_QUEUE"))  // test hook: forces k_fast_detect's queue-full path
         e->fast_queue_cap = std::min(std::max(atoi(q), 0), FD_QCAP);
     e->nlevels = p->nlevels;
@@ -3085,6 +3130,16 @@ int orbgpu_extractor_set_profiling(orbgpu_extractor *e, int32_t enable)
     e->profiling = enable != 0;  // the averaging window is kept: stage_times() reads and resets it
     return ORBGPU_OK;
 }
+int orbgpu_extractor_set_fast_early_out(orbgpu_extractor *e, int32_t enable)
+{
+    ORBGPU_REQUIRE(e, "null handle");
+    if (e->fast_early_out != (enable != 0)) {
+        e->fast_early_out = enable != 0;
+        e->graph_key = 0;  // a captured launch sequence holds the other kernel
+    }
+    return ORBGPU_OK;
+}
+
 int orbgpu_extractor_set_concurrent_blur(orbgpu_extractor *e, int32_t enable)
 {
     ORBGPU_REQUIRE(e, "null argument");

@@ -113,7 +113,7 @@ ABI_SYMBOLS = [
     "orbgpu_extractor_get_inv_scale_factors", "orbgpu_extractor_get_sigma2", "orbgpu_extractor_get_inv_sigma2",
     "orbgpu_extractor_get_quotas", "orbgpu_extractor_max_keypoints", "orbgpu_extract", "orbgpu_extract_batch",
     "orbgpu_extract_batch_device", "orbgpu_extractor_get_pyramid_level", "orbgpu_extractor_debug_read",
-    "orbgpu_extractor_graph_state", "orbgpu_extractor_debug_quadtree_config", "orbgpu_extractor_set_profiling", "orbgpu_extractor_set_concurrent_blur", "orbgpu_extractor_set_stage_signal", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
+    "orbgpu_extractor_graph_state", "orbgpu_extractor_debug_quadtree_config", "orbgpu_extractor_set_profiling", "orbgpu_extractor_set_concurrent_blur", "orbgpu_extractor_set_fast_early_out", "orbgpu_extractor_set_stage_signal", "orbgpu_extractor_stage_count", "orbgpu_extractor_stage_name",
     "orbgpu_extractor_stage_times",
     "orbgpu_pipeline_create", "orbgpu_pipeline_destroy", "orbgpu_pipeline_parts", "orbgpu_pipeline_part",
     "orbgpu_pipeline_extract_device", "orbgpu_pipeline_wait",
@@ -401,6 +401,11 @@ class ORBextractor:
 
     def set_concurrent_blur(self, on):
         check(self.L.orbgpu_extractor_set_concurrent_blur(self.h, int(on)))
+
+    def set_fast_early_out(self, on):
+        """Exact wave-level early-out of the FAST score network (orbgpu_extractor_set_fast_early_out)."""
+        self.L.orbgpu_extractor_set_fast_early_out.argtypes = [C.c_void_p, C.c_int32]
+        check(self.L.orbgpu_extractor_set_fast_early_out(self.h, int(on)))
 
     def set_profiling(self, on):
         check(self.L.orbgpu_extractor_set_profiling(self.h, int(on)))

@@ -51,8 +51,13 @@ def _tri(k, period):
 class Stream:
     """Synthetic RGB-D sequence. frame(t) -> (gray u8 HxW, rgb u8 HxWx3, depth f32 HxW)."""
 
-    def __init__(self, width=640, height=480, seed=1234, n_shapes=None):
+    def __init__(self, width=640, height=480, seed=1234, n_shapes=None, flat_fraction=0.0):
+        """flat_fraction > 0: that share of the canvas is covered by large low-texture regions (walls, table tops, a
+        monitor: rectangles of 90-320 px with a gentle shading and +-1 sensor noise instead of the +-3 elsewhere), the way a
+        real indoor sequence such as TUM fr1/desk has them -- the default stream (0.0) is textured everywhere, which is the
+        worst case for any early-out of the FAST score.  The default stream's bytes do not depend on this option."""
         self.w, self.h, self.seed = width, height, seed
+        self.flat_fraction = float(flat_fraction)
         s = width / 640.0
         self.fx, self.fy = np.float32(TUM1_FX * s), np.float32(TUM1_FY * s)
         self.cx, self.cy = np.float32(TUM1_CX * s), np.float32(TUM1_CY * s)
@@ -86,6 +91,23 @@ class Stream:
         holes = rng.random((ch, cw)) < 0.05
         dep[holes] = 0.0
         self.depth_canvas = dep.astype(np.float32)
+        self.flat_mask = None
+        if self.flat_fraction > 0:
+            frng = np.random.Generator(np.random.PCG64([seed, 424242]))  # a generator of its own: the draws above stay as they are
+            mask = np.zeros((ch, cw), bool)
+            shade = 10.0 * (_value_noise(frng, ch, cw, 128) - 0.5)
+            target = self.flat_fraction * ch * cw
+            for _ in range(10000):
+                if mask.sum() >= target:
+                    break
+                rw, rh = int(frng.integers(90, 321)), int(frng.integers(90, 321))
+                x0, y0 = int(frng.integers(-rw // 2, cw - rw // 2)), int(frng.integers(-rh // 2, ch - rh // 2))
+                x1, y1 = min(cw, x0 + rw), min(ch, y0 + rh)
+                x0, y0 = max(0, x0), max(0, y0)
+                level = float(frng.integers(50, 200))
+                self.canvas[y0:y1, x0:x1] = level + shade[y0:y1, x0:x1]
+                mask[y0:y1, x0:x1] = True
+            self.flat_mask = mask
 
     def offset(self, t):
         return _tri(5 * t, MARGIN), _tri(3 * t + 17, MARGIN)
@@ -93,7 +115,10 @@ class Stream:
     def frame(self, t):
         ox, oy = self.offset(t)
         rng = np.random.Generator(np.random.PCG64([self.seed, 7919, t]))
-        g = self.canvas[oy:oy + self.h, ox:ox + self.w] + rng.integers(-3, 4, (self.h, self.w))
+        noise = rng.integers(-3, 4, (self.h, self.w))
+        if self.flat_mask is not None:  # low-texture regions carry less sensor noise than the +-3 of the textured canvas
+            noise = np.where(self.flat_mask[oy:oy + self.h, ox:ox + self.w], np.clip(noise, -1, 1), noise)
+        g = self.canvas[oy:oy + self.h, ox:ox + self.w] + noise
         gray = np.clip(np.rint(g), 0, 255).astype(np.uint8)
         rgb = np.empty((self.h, self.w, 3), np.uint8)
         rgb[..., 0] = np.clip(gray.astype(np.int32) - 10, 0, 255)

@@ -389,3 +389,41 @@ def c4(nkf=24, device_id=0, leaf=0.01):
                          "traffic": None, "algorithmic_bytes": alg, "ms_per_launch": ins_ms,
                          "note": "8 dependent launches per key frame over <= 34 k new points + one pass over the map"},
             "per_keyframe": rows}
+
+
+def c2_fast_early_out(batch=256, reps=8, device_id=0, flat_fraction=0.5):
+    """The FAST stage with and without its exact wave-level early-out (orbgpu_extractor_set_fast_early_out) on two 640x480
+    streams: the benchmark stream (textured everywhere: the option's worst case) and a stream with TUM-desk-like flat
+    regions (Stream(..., flat_fraction)).  Extraction only, resident batch, HIP events of the library per stage."""
+    import torch
+    W, H, NF = 640, 480, 1000
+    dev = "cuda:%d" % device_id
+    out = {"batch": batch, "flat_fraction": flat_fraction,
+           "what": "ms per %d-frame launch of k_fast_detect / of the whole extraction, option off and on; key points are "
+                   "bit-identical either way (tests/test_gpu_extractor.py)" % batch}
+    ext = G.ORBextractor(NF, max_batch=batch, device_id=device_id)
+    cap = ext.max_keypoints(W, H)
+    kps = torch.zeros((batch, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((batch, cap, 32), dtype=torch.uint8, device=dev)
+    nout = torch.zeros(batch, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for name, ff in (("benchmark_stream", 0.0), ("flat_region_stream", flat_fraction)):
+        st = Stream(W, H, 1234, flat_fraction=ff)
+        imgs = torch.from_numpy(np.stack([st.frame(t)[0] for t in range(batch)])).to(dev)
+        row = {}
+        for on in (False, True):
+            ext.set_fast_early_out(on)
+            for i in range(reps + 2):
+                ext.set_profiling(i >= 2)
+                ext.extract_batch_device(imgs.data_ptr(), batch, W, H, W, W * H, kps.data_ptr(), desc.data_ptr(), cap,
+                                         nout.data_ptr(), s)
+            torch.cuda.synchronize()
+            stg = ext.stage_times()
+            ext.set_profiling(False)
+            row["early_out_on" if on else "early_out_off"] = {"fast_ms": round(stg["fast"], 4), "extract_ms": round(sum(stg.values()), 4),
+                                                               "extract_frames_per_s": round(batch / (sum(stg.values()) * 1e-3), 0),
+                                                               "keypoints_per_frame": float(nout.float().mean())}
+        row["fast_speedup_with_option"] = round(row["early_out_off"]["fast_ms"] / row["early_out_on"]["fast_ms"], 3)
+        out[name] = row
+    ext.set_fast_early_out(False)
+    return out

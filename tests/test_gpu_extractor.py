@@ -9,6 +9,17 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
 
 
+@pytest.fixture(autouse=True, params=["default", "fast_early_out"])
+def fast_stage_variant(request, monkeypatch):
+    """Every test of this module runs twice: with the round-3 FAST kernel and with its exact wave-level early-out
+    (k_fast_detect<true>; the environment variable is the option's default for handles created afterwards)."""
+    if request.param == "fast_early_out":
+        monkeypatch.setenv("ORBGPU_FAST_EARLY_OUT", "1")
+    else:
+        monkeypatch.delenv("ORBGPU_FAST_EARLY_OUT", raising=False)
+    return request.param
+
+
 def assert_same_keypoints(gk, gd, ok, od, what):
     assert len(gk) == len(ok), "%s: key point count %d != oracle %d" % (what, len(gk), len(ok))
     for f in FIELDS:
@@ -412,3 +423,24 @@ def test_device_input_with_unaligned_rows(gpu, oracle, stream640):
         n = int(nout[0])
         gk = kps[0, :n].cpu().numpy().view(gpu.KEYPOINT_DTYPE).reshape(-1)
         assert_same_keypoints(gk, desc[0, :n].cpu().numpy(), ok, od, "stride %d shift %d" % (stride, shift))
+
+
+@pytest.mark.parametrize("w,h,nfeat,flat", [(640, 480, 1000, 0.6), (1280, 960, 2000, 0.45), (640, 480, 1000, 0.95)])
+def test_fast_early_out_on_images_with_flat_regions(gpu, oracle, w, h, nfeat, flat, fast_stage_variant):
+    """The early-out only ever fires where a wavefront's whole row segment is clear of corner candidates: a stream with
+    flat regions (Stream(..., flat_fraction)), a constant image and a smooth ramp, stage by stage against the oracle; the
+    option toggled on one handle gives the same bytes as the other kernel."""
+    from orb_slam2_map_amd.synth import Stream
+    st = Stream(w, h, 4321, flat_fraction=flat)
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs = np.stack([st.frame(2)[0], st.frame(3)[0], np.full((h, w), 117, np.uint8), ((xx + yy) // 9).astype(np.uint8)])
+    ge = gpu.ORBextractor(nfeat, max_batch=len(imgs))
+    oe = oracle.Extractor(nfeat)
+    for on in (fast_stage_variant == "fast_early_out", fast_stage_variant != "fast_early_out"):
+        ge.set_fast_early_out(on)
+        gk, gd = ge.extract_batch(imgs)
+        for f in range(len(imgs)):
+            ok, od = oe.extract(imgs[f])
+            check_stages(gpu, ge, oe, f, 8, "flat %.2f %dx%d frame %d early-out %s" % (flat, w, h, f, on))
+            assert_same_keypoints(gk[f], gd[f], ok, od, "flat %.2f %dx%d frame %d early-out %s" % (flat, w, h, f, on))
+    assert len(gk[0]) > nfeat // 4  # the textured part still fills most of the quota

@@ -19,6 +19,8 @@ FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
 def image(kind, w, h):
     if kind == 0:
         return Stream(w, h, int(rng.integers(1, 1 << 30))).frame(int(rng.integers(0, 40)))[0]
+    if kind == 4:  # textured stream with large flat regions (what the FAST early-out keys on)
+        return Stream(w, h, int(rng.integers(1, 1 << 30)), flat_fraction=float(rng.uniform(0.2, 0.95))).frame(int(rng.integers(0, 40)))[0]
     if kind == 1:
         return rng.integers(0, 256, (h, w)).astype(np.uint8)
     if kind == 2:  # low texture with a few blobs: threshold fallback cells
@@ -42,7 +44,7 @@ while time.time() - t0 < budget:
     while min(w, h) / sf ** (nl - 1) < 70 and nl > 1:
         nl -= 1
     ini, mn = int(rng.integers(5, 40)), int(rng.integers(1, 25))
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     cfg = dict(w=w, h=h, nfeat=nfeat, sf=sf, nl=nl, ini=ini, mn=mn, kind=kind)
     img = image(kind, w, h)
     try:

@@ -37,6 +37,8 @@ ab) # A/B of schedule options on the C2 bench line (40 steps each, same process 
         for t in $rest; do case $t in @*) envs="$envs ${t#@}";; *) flags="$flags ${t//@/ }";; esac; done
         run ab_$name 300 bash -c "env $envs python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary $flags > $OUT/ab_$name.json 2> $OUT/ab_$name.err; python -c \"import json; j=json.loads(open('$OUT/ab_$name.json').read().strip().splitlines()[-1]); print('$name', round(j['value']), round(j['ms_per_step'],4), j['timed_region_repeats']['frames_per_s'], {k: v['ms'] for k, v in j['stages'].items()})\""
     done ;;
+earlyout) run earlyout 300 bash -c "python tools/early_out_ab.py > $OUT/early_out.json 2> $OUT/early_out.err; cat $OUT/early_out.json; tail -3 $OUT/early_out.err" ;;
+exttests) run exttests 900 bash -c "python -m pytest tests/test_gpu_extractor.py tests/test_gpu_threads.py tests/test_gpu_pipeline.py -m gpu -q -x --timeout 600 > $OUT/pytest_ext.log 2>&1; tail -15 $OUT/pytest_ext.log" ;;
 *) echo "unknown step $step" ;;
 esac
 done
