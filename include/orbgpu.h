@@ -139,7 +139,13 @@ int orbgpu_extract_batch_device(orbgpu_extractor *h, const uint8_t *d_gray, int3
 
 /* mvImagePyramid[level] (public member, ORBextractor.h:85; read by Frame::ComputeStereoMatches,
  * Frame.cc:471,561,578).  Copies level `level` of frame `frame` of the LAST call (without the
- * 19 px border) to host memory, dst_stride bytes per row. */
+ * 19 px border) to host memory, dst_stride bytes per row.
+ * Level 0: when the input rows of the last call were 4-byte aligned (base pointer, stride, frame stride) and the width a
+ * multiple of 8, no stage needs ComputePyramid's padded copy of the image (ORBextractor.cc:1125-1129: FAST, the
+ * orientation disc and the resize only read the image interior, the blur reflects its own rim) and the library does not
+ * make one ("direct mode"); this getter then makes it on demand from the image of the last call.  For the host entry
+ * points that is the handle's own staging copy; after orbgpu_extract_batch_device it is the CALLER's device buffer, which
+ * must still hold the images when level 0 is asked for (the RGB-D path never asks: only stereo matching reads it). */
 int orbgpu_extractor_get_pyramid_level(orbgpu_extractor *h, int32_t frame, int32_t level, uint8_t *dst,
                                        size_t dst_stride, int32_t *width, int32_t *height);
 

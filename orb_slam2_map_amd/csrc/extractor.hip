@@ -83,6 +83,20 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// Level 0 read straight from the caller's image ("direct" mode).  ComputePyramid's level 0 is copyMakeBorder(image) into a
+// padded plane (ORBextractor.cc:1125-1129) -- 0.67 MB of traffic per 640x480 frame that no stage needs: FAST, the
+// orientation disc and the resize to level 1 only read the image interior, and the blur can reflect its 3-px
+// rim itself.  With aligned inputs (launch_pipeline) the kernels that read level 0 take the image from here and the
+// padded copy is only materialised when mvImagePyramid[0] is asked for (orbgpu_extractor_get_pyramid_level).
+// Pixel (x, y) of frame f = p[f * frame_stride + y * pitch + x]; the padded planes have the pixel at (x + EDGE, y + EDGE).
+struct Src0 {
+    const uint8_t *p;
+    size_t frame_stride;
+    uint32_t pitch;
+    int direct;  // 0: level 0 is the padded plane like every other level
+};
+constexpr int BLUR0_OX = EDGE + 1;  // direct mode: column of pixel 0 in the BLURRED level-0 plane (k_blur0_direct stores 8 aligned bytes per strip)
+
 // ---------------------------------------------------------------------------------------------
 // K1a: level 0 = copyMakeBorder(image, REFLECT_101)           (ORBextractor.cc:1125-1129, A6)
 // ---------------------------------------------------------------------------------------------
@@ -248,17 +262,21 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 // host-precomputed selectors forms (left tap | right tap << 16) pairs and v_dot2_u32_u16 applies the 11-bit weights.
 // Same integer arithmetic as k_resize_level.
 struct ResizeStrip {  // per padded output dword column of a level
-    uint32_t base_q;  // bits 0..15: window base (padded source column, multiple of 4); bits 16..17: byte shift of the window
+    uint32_t base_q;  // bits 0..15: window base (padded source column, multiple of 4); bits 16..17: byte shift of the window;
+                      // bit 18 (direct level-0 source only): the window ends at the row end -- its third dword is not read
 };
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
-template <bool REUSE>  // keep a source row's horizontal interpolation for the next output row (pays on the large levels)
+// REUSE: keep a source row's horizontal interpolation for the next output row (pays on the large levels).
+// DIRECT: level 1 from the caller's image (Src0) instead of the padded level-0 plane; the strip tables are built for
+// unpadded source columns and a window that would run past the end of an image row re-reads its second dword.
+template <bool REUSE, bool DIRECT>
 __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, size_t frame_pyr,
                                                      const LevelGeom *__restrict__ geom, int level,
                                                      const ResizeStrip *__restrict__ strips,
                                                      const uint4 *__restrict__ sels, const uint4 *__restrict__ wts,
-                                                     const YTab *__restrict__ ytab, int strip_off, int rows)
+                                                     const YTab *__restrict__ ytab, int strip_off, int rows, Src0 s0)
 {
     const LevelGeom g = geom[level];
     const LevelGeom gs = geom[level - 1];
@@ -271,12 +289,16 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     if (rg * rows >= g.h + 2 * EDGE)
         return;
     const uint32_t bq = strips[strip_off + sdw].base_q;
-    const uint32_t sh = bq >> 16;  // byte shift of the 12-byte window (0..3)
+    const uint32_t sh = (bq >> 16) & 3u;  // byte shift of the 12-byte window (0..3)
     const uint4 sel = sels[strip_off + sdw], wt = wts[strip_off + sdw];
     const uint32_t selv[4] = {sel.x, sel.y, sel.z, sel.w}, wv[4] = {wt.x, wt.y, wt.z, wt.w};
     // wave-uniform frame base + 32-bit offsets
     uint8_t *fb = pyr + (size_t)f * frame_pyr;
-    const uint32_t base = (uint32_t)gs.plane_off + (bq & 0xFFFFu);
+    const uint8_t *sb = DIRECT ? s0.p + (size_t)f * s0.frame_stride : fb;  // source plane: padded level l-1, or the image itself
+    const int spitch = DIRECT ? (int)s0.pitch : gs.pitch;
+    const int soy = DIRECT ? 0 : EDGE;  // row of source pixel row 0 in the source plane
+    const uint32_t base = (DIRECT ? 0u : (uint32_t)gs.plane_off) + (bq & 0xFFFFu);
+    const uint32_t o2 = DIRECT && ((bq >> 18) & 1u) ? 1u : 2u;  // third dword of the window (DIRECT at a row end: the second again)
     const uint32_t dst = (uint32_t)g.plane_off + (uint32_t)sdw * 4u;
     // the row table entries of all rows of the item first (one round trip), so that the source loads of a row do
     // not wait for a table load of their own
@@ -295,12 +317,12 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
         if (rr >= rows || py >= g.h + 2 * EDGE)
             break;
         const YTab yt = yts[rr];
-        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(fb + (base + rowoff(yt.sy1 + EDGE, gs.pitch)));
-        const uint32_t c0 = S1[0], c1 = S1[1], c2 = S1[2];
+        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(sb + (base + rowoff(yt.sy1 + soy, spitch)));
+        const uint32_t c0 = S1[0], c1 = S1[1], c2 = DIRECT ? S1[o2] : S1[2];
         int t0[4];
         if (!REUSE || (int)yt.sy0 != kept_row) {
-            const uint32_t *S0 = reinterpret_cast<const uint32_t *>(fb + (base + rowoff(yt.sy0 + EDGE, gs.pitch)));
-            const uint32_t a0 = S0[0], a1 = S0[1], a2 = S0[2];
+            const uint32_t *S0 = reinterpret_cast<const uint32_t *>(sb + (base + rowoff(yt.sy0 + soy, spitch)));
+            const uint32_t a0 = S0[0], a1 = S0[1], a2 = DIRECT ? S0[o2] : S0[2];
             const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, sh), hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -527,6 +549,8 @@ struct DetectGeom {
     int nsx[ORBGPU_MAX_LEVELS];        // dword columns per band: padded dwords 9 .. (w-1)/4
     int ncols[ORBGPU_MAX_LEVELS];      // cell columns of the level's cell grid (skipped ones excluded)
     int ctab_off[ORBGPU_MAX_LEVELS];   // first ColumnInfo of the level
+    int xfirst[ORBGPU_MAX_LEVELS];     // image column of pixel 0 of the level's first strip: 17 for a padded plane (its aligned
+                                       // dword 9), 16 for level 0 read directly from the image (Src0: aligned to the image)
     int nlevels;
 };
 
@@ -561,7 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                      const ColumnInfo *__restrict__ ctab,
                                                      const CellDesc *__restrict__ cells, int ncells_total,
                                                      uint32_t *__restrict__ slots, size_t frame_slots,
-                                                     int *__restrict__ cell_cnt, int t_lo, int t_ini, int qcap)
+                                                     int *__restrict__ cell_cnt, int t_lo, int t_ini, int qcap, Src0 s0)
 {
     __shared__ uint2 s_q[4][FD_QCAP];
     __shared__ DetectLane s_lane[4][64];
@@ -582,12 +606,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const LevelGeom g = geom[level];
     const int local = max(q, 0) - dg.first[level];
     const int band = local / dg.nsx[level], sx = local - band * dg.nsx[level];
-    const int col = (9 + sx) * 4;          // padded byte column of pixel 0: image x = col - 19
-    const int y0 = EDGE + band * g.hcell;  // first row of the band (image coordinates)
-    const int rows = in_range ? min(g.hcell, g.h - EDGE - y0) : 0;
-    // wave-uniform frame base + 32-bit offset (one v_mad_u32_u24 per row instead of a 64-bit multiply-add)
-    const uint8_t *fsrc = pyr + (size_t)f * frame_pyr;
-    const uint32_t src0 = (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE - 3) * (uint32_t)g.pitch + (uint32_t)(col - 4);
+    const int xs = dg.xfirst[level] + 4 * sx;  // image column of the strip's pixel 0
+    const int y0 = EDGE + band * g.hcell;      // first row of the band (image coordinates)
+    // The wave's plane: the padded pyramid, or -- direct mode, level 0 -- the caller's image.  In direct mode the host ends
+    // level 0's strips on a wave boundary (DetectGeom::first[1] is a multiple of FD_OWN), so the choice is wave-uniform for
+    // the owned lanes: a scalar base + 32-bit offsets, as before.  A halo lane that belongs to the other side of that
+    // boundary sits out (rows = 0): the neighbour it would deliver is outside every cell and masked anyway.
+    const bool wave_dir0 = s0.direct != 0 && __builtin_amdgcn_readlane(level, 1) == 0;
+    const bool dir0 = s0.direct != 0 && level == 0;
+    const int rows = in_range && dir0 == wave_dir0 ? min(g.hcell, g.h - EDGE - y0) : 0;  // (<= 0 for the padding strips)
+    const uint8_t *fsrc = wave_dir0 ? s0.p + (size_t)f * s0.frame_stride : pyr + (size_t)f * frame_pyr;
+    const int lpitch = dir0 ? (int)s0.pitch : g.pitch;
+    const uint32_t src0 = dir0 ? (uint32_t)(y0 - 3) * (uint32_t)lpitch + (uint32_t)(xs - 4)
+                               : (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE - 3) * (uint32_t)lpitch + (uint32_t)(xs + EDGE - 4);
     uint32_t *fslots = slots + (size_t)f * frame_slots;
     int *fcnt = cell_cnt + (size_t)f * (ncells_total + ORBGPU_MAX_LEVELS);  // per-cell counters ...
     int *lcnt = fcnt + ncells_total;                                         // ... then the stored keys of every level
@@ -595,7 +626,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const ColumnInfo ci = in_range ? ctab[dg.ctab_off[level] + sx] : ColumnInfo{0xFFFFFFFFu, 0u};
     {
         DetectLane dl;
-        dl.xrel = col - EDGE - BORDER0;
+        dl.xrel = xs - BORDER0;
         dl.yrel = y0 - BORDER0;
         dl.cell_base = g.cell_first + band * dg.ncols[level];
         dl.cellj = ci.cellj;
@@ -665,7 +696,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     RowU r0, r1, r2, r3, r4, r5, r6;
 #define FD_FETCH(row)                                                                                        \
     {                                                                                                        \
-        const uint32_t *qq = reinterpret_cast<const uint32_t *>(fsrc + (src0 + rowoff((row), g.pitch)));    \
+        const uint32_t *qq = reinterpret_cast<const uint32_t *>(fsrc + (src0 + rowoff((row), lpitch)));     \
         nx.d[0] = qq[0];                                                                                     \
         nx.d[1] = qq[1];                                                                                     \
         nx.d[2] = qq[2];                                                                                     \
@@ -1554,7 +1585,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const LevelGeom *__rest
 // K4: orientation + key-point assembly
 //     (IC_Angle :77-104, fastAtan2 A5, fix-up :837-847, scaling :1095-1101)
 // ---------------------------------------------------------------------------------------------
-struct KpAux {
+struct KpAux {  // x: the key point's column in its blurred plane minus EDGE (= its image column, except level 0 in direct mode)
     int x, y, level;
     float angle;
     float ca, sb;  // cosf / sinf of the angle in radians as the handle's trig mode defines them (k_trig)
@@ -1601,7 +1632,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
                                                 const uint32_t *__restrict__ sel, int sel_cap_total,
                                                 const int *__restrict__ nsel, const uint32_t *__restrict__ orw,
                                                 orbgpu_keypoint *__restrict__ kps, KpAux *__restrict__ aux,
-                                                int cap, int *__restrict__ n_out, int iters)
+                                                int cap, int *__restrict__ n_out, int iters, Src0 s0)
 {
     __shared__ uint32_t W10[4 * 16 * 9], M01[4 * 16 * 9];
     __shared__ __align__(16) uint8_t stage[8][31 * 48];
@@ -1652,14 +1683,17 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         continue;
     const uint32_t key = sel[(size_t)f * sel_cap_total + g.sel_off + j];
     const int x = key_x(key) + BORDER0, y = key_y(key) + BORDER0;
-    const int xl = x + EDGE - HALF_PATCH;  // leftmost padded column of the disc
+    // the key point's plane: the padded level, or -- level 0 in direct mode -- the caller's image (pixel 0 at column 0)
+    const bool dir0 = s0.direct != 0 && level == 0;
+    const int porg = dir0 ? 0 : EDGE, ppitch = dir0 ? (int)s0.pitch : g.pitch;
+    const int xl = x + porg - HALF_PATCH;  // leftmost column of the disc in that plane
     const int a = xl & 3;
     const int v = hl - HALF_PATCH;         // rows -15..15 (lane 31 idles)
     int m10 = 0, m01 = 0;
     {
         // the disc's 31 rows x 48 bytes staged in LDS as 93 16-byte pieces, lane = (row, piece): a wave-load then touches
         // ~21 rows instead of 62 (the 12 bytes past the 36 a row needs are inside the padded row)
-        const uint8_t *base = pyr + (size_t)f * frame_pyr + g.plane_off + (xl - a);
+        const uint8_t *base = (dir0 ? s0.p + (size_t)f * s0.frame_stride : pyr + (size_t)f * frame_pyr + g.plane_off) + (xl - a);
         struct __attribute__((packed, aligned(4))) Piece {
             uint32_t d[4];
         };
@@ -1668,7 +1702,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         for (int k = 0; k < 3; k++) {
             const int q = hl + 32 * k, r = (q * 171) >> 9, part = q - 3 * r;
             if (q < 93)
-                pc[k] = *reinterpret_cast<const Piece *>(base + rowoff(y + EDGE - HALF_PATCH + r, g.pitch) + part * 16);
+                pc[k] = *reinterpret_cast<const Piece *>(base + rowoff(y + porg - HALF_PATCH + r, ppitch) + part * 16);
         }
         uint4 *pl = reinterpret_cast<uint4 *>(stage[threadIdx.x >> 5]);
 #pragma unroll
@@ -1716,7 +1750,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
         kp.class_id = -1;
         kps[(size_t)f * cap + out_off + j] = kp;
         KpAux ax;
-        ax.x = x;
+        ax.x = x + (dir0 ? BLUR0_OX - EDGE : 0);  // k_describe reads the BLURRED plane: column x + EDGE there (direct level 0: BLUR0_OX)
         ax.y = y;
         ax.level = level;
         ax.plane_off = g.plane_off;
@@ -1799,11 +1833,11 @@ __device__ __forceinline__ uint32_t blur_vsum(const uint32_t A[4], const uint32_
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                               size_t frame_pyr, const LevelGeom *__restrict__ geom, StripGeom bg)
+                                               size_t frame_pyr, const LevelGeom *__restrict__ geom, StripGeom bg, int strip0)
 {
     int bx, f;
     xcd_frame_block(bx, f);
-    const int strip = bx * 256 + threadIdx.x;
+    const int strip = strip0 + bx * 256 + threadIdx.x;  // strip0 = first strip of level 1 when level 0 is blurred by k_blur0_direct
     if (strip >= bg.first[bg.nlevels])
         return;
     int level = 0;
@@ -1864,6 +1898,100 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     B8_LOAD(p5, p5, 0) B8_LOAD(p0, p5, 1) B8_LOAD(p1, p0, 2) B8_LOAD(p2, p1, 3) B8_LOAD(p3, p2, 4) B8_LOAD(p4, p3, 5)
     nx = *reinterpret_cast<const Q4 *>(fsrc + soff);  // next input row, fetched one step ahead (two: no gain)
     // now p0 = P_{-2} = (row -3, row -2), p1 = P_{-1}, p2 = P_0, p3 = P_1, p4 = P_2; p5 = (-, row -3) is free for P_3
+#pragma unroll 1
+    for (int k = 0; k < BLUR_ROWS; k += 6) {
+        B8_STEP(p0, p2, p4, p5, k)
+        B8_STEP(p1, p3, p5, p0, k + 1)
+        B8_STEP(p2, p4, p0, p1, k + 2)
+        B8_STEP(p3, p5, p1, p2, k + 3)
+        B8_STEP(p4, p0, p2, p3, k + 4)
+        B8_STEP(p5, p1, p3, p4, k + 5)
+    }
+#undef B8_PAIR
+#undef B8_STEP
+#undef B8_LOAD
+#undef B8_HSUM
+}
+
+// Level 0 of the blur in direct mode: the same arithmetic on the caller's image (Src0).  A strip is 8 pixels aligned to the
+// IMAGE (x0 = 8 sx; requires width % 8 == 0), its 16-byte window x0-4 .. x0+11 one aligned load; what the padded plane
+// gave for free is done here: rows outside the image are reflected (REFLECT_101 on the cloned level, ORBextractor.cc:1085-
+// 1086), the first strip of a row builds x = -4..-1 and the last one x = w..w+3 from the neighbouring pixels with one
+// v_perm each (their loads start at x = 0 resp. w-16, so nothing outside an image row is ever read).  Output: the
+// blurred level-0 plane with pixel 0 at column BLUR0_OX (8 aligned bytes per strip and row).
+__global__ __launch_bounds__(256) void k_blur0_direct(Src0 s0, uint8_t *__restrict__ blur, size_t frame_pyr,
+                                                       const LevelGeom *__restrict__ geom)
+{
+    int bx, f;
+    xcd_frame_block(bx, f);
+    const LevelGeom g = geom[0];
+    const int nsx = g.w >> 3;
+    const int strip = bx * 256 + threadIdx.x;
+    const int sy = strip / nsx, sx = strip - sy * nsx;
+    const int y0 = sy * BLUR_ROWS;
+    if (y0 >= g.h)
+        return;
+    const int rows = min(BLUR_ROWS, g.h - y0);
+    const bool first = sx == 0, last = sx == nsx - 1;
+    const uint8_t *fsrc = s0.p + (size_t)f * s0.frame_stride + (first ? 0 : (last ? g.w - 16 : 8 * sx - 4));
+    uint8_t *fdst = blur + (size_t)f * frame_pyr;
+    const uint32_t pitch = (uint32_t)g.pitch;
+    uint32_t doff = (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE) * pitch + (uint32_t)(8 * sx + BLUR0_OX);
+    struct __attribute__((packed, aligned(4))) Q4 {
+        uint32_t d[4];
+    };
+    struct __attribute__((packed, aligned(4))) O2 {
+        uint32_t d[2];
+    };
+    // the window of image row y (any y in [-3, h+2]) as the four dwords x0-4 .. x0+11
+    auto fetch = [&](int y) -> Q4 {
+        const int ry = y < 0 ? -y : (y >= g.h ? 2 * g.h - 2 - y : y);
+        return *reinterpret_cast<const Q4 *>(fsrc + __umul24((unsigned)ry, s0.pitch));
+    };
+    auto window = [&](const Q4 &q) -> Q4 {
+        Q4 w;
+        // first strip: q = x 0..15 -> (x4 x3 x2 x1 | q0 | q1 | q2); last strip: q = x w-16..w-1 -> (q1 | q2 | q3 | w-2 w-3 w-4 w-5)
+        const uint32_t left = __builtin_amdgcn_perm(q.d[1], q.d[0], 0x01020304u);
+        const uint32_t right = __builtin_amdgcn_perm(q.d[3], q.d[2], 0x03040506u);
+        w.d[0] = first ? left : (last ? q.d[1] : q.d[0]);
+        w.d[1] = first ? q.d[0] : (last ? q.d[2] : q.d[1]);
+        w.d[2] = first ? q.d[1] : (last ? q.d[3] : q.d[2]);
+        w.d[3] = first ? q.d[2] : (last ? right : q.d[3]);
+        return w;
+    };
+    uint32_t p0[8], p1[8], p2[8], p3[8], p4[8], p5[8], hn[8];  // six row PAIRS (blur_vsum) and the newest row's sums
+    Q4 nx;
+#define B8_HSUM(R, Q)                                                                                        \
+    {                                                                                                        \
+        const Q4 wq = window(Q);                                                                             \
+        blur_hsum(wq.d[0], wq.d[1], wq.d[2], R);                                                             \
+        blur_hsum(wq.d[1], wq.d[2], wq.d[3], R + 4);                                                         \
+    }
+#define B8_PAIR(P, PREV, H)                                                                                  \
+    _Pragma("unroll") for (int p = 0; p < 8; p++) P[p] = __builtin_amdgcn_alignbit(H[p], PREV[p], 16);
+#define B8_LOAD(P, PREV, row)                                                                                \
+    {                                                                                                        \
+        const Q4 q = fetch(y0 - 3 + (row));                                                                  \
+        B8_HSUM(hn, q)                                                                                       \
+        B8_PAIR(P, PREV, hn)                                                                                 \
+    }
+#define B8_STEP(A, C, E, F, k)                                                                               \
+    if ((k) < rows) {                                                                                        \
+        B8_HSUM(hn, nx)                                                                                      \
+        B8_PAIR(F, E, hn)                                                                                    \
+        if ((k) + 1 < rows)                                                                                  \
+            nx = fetch(y0 + 4 + (k));                                                                        \
+        O2 o;                                                                                                \
+        o.d[0] = blur_vsum(A, C, E, F);                                                                      \
+        o.d[1] = blur_vsum(A + 4, C + 4, E + 4, F + 4);                                                      \
+        *reinterpret_cast<O2 *>(fdst + doff) = o;                                                            \
+        doff += pitch;                                                                                       \
+    }
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+        p5[p] = 0;
+    B8_LOAD(p5, p5, 0) B8_LOAD(p0, p5, 1) B8_LOAD(p1, p0, 2) B8_LOAD(p2, p1, 3) B8_LOAD(p3, p2, 4) B8_LOAD(p4, p3, 5)
+    nx = fetch(y0 + 3);
 #pragma unroll 1
     for (int k = 0; k < BLUR_ROWS; k += 6) {
         B8_STEP(p0, p2, p4, p5, k)
@@ -2059,6 +2187,13 @@ struct orbgpu_extractor {
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
     bool fast_early_out = false;   // k_fast_detect<true>: exact wave-level early-out (orbgpu_extractor_set_fast_early_out; ORBGPU_FAST_EARLY_OUT=1 at creation)
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
+    // direct mode (Src0): level 0 read from the caller's image, no padded copy
+    bool direct0_ok = false;       // the configured geometry has the tables for it (width % 8 == 0, >= 2 levels on the fast resize path)
+    bool no_direct0 = false;       // ORBGPU_DEBUG_NO_DIRECT0 (read at creation): always make the padded copy (tests, A/B)
+    int rs_off_direct = 0;         // level 1's strip tables for the unpadded source
+    DetectGeom det_geom_direct;    // k_fast_detect's strips with level 0 aligned to the image
+    Src0 last_src = {nullptr, 0, 0u, 0};  // level-0 source of the last call (direct != 0: the call ran in direct mode)
+    bool level0_materialized = true;      // d_pyr holds level 0 of the last call (false after a direct-mode call until a getter asks)
     TrigTable trig = {nullptr, nullptr, nullptr, 0u};  // the host libm's cosf / sinf exceptions (trig.hip); none in ORBGPU_TRIG_ROUNDED_DOUBLE mode
 
 };
@@ -2266,6 +2401,47 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
             }
         }
     }
+    // direct mode: level 1's strips once more, for source columns counted from the image's own column 0 (Src0).  A window
+    // that would run past the end of an image row (the next row, or -- last row of the last frame -- the end of the
+    // caller's buffer) is placed on the row's last 8 bytes and its third dword is not read (bit 18).
+    bool direct_ok = nl >= 2 && w % 8 == 0 && w >= 64 && geom[std::min(1, nl - 1)].rs_fast != 0;
+    int rs_off_direct = 0;
+    if (direct_ok) {
+        const LevelGeom &g = geom[1];
+        const int sw = geom[0].w;
+        rs_off_direct = (int)rstrip.size();
+        for (int sdw = 0; sdw < g.pitch / 4 && direct_ok; sdw++) {
+            int cl[4], cr[4], mn = 1 << 30;
+            const XTab *xt[4];
+            for (int k = 0; k < 4; k++) {
+                const int px = std::min(sdw * 4 + k, g.w + 2 * EDGE - 1);
+                xt[k] = &xtab[g.xtab_off + reflect101(px - EDGE, g.w)];
+                cl[k] = xt[k]->sx;
+                cr[k] = xt[k]->sx1;
+                mn = std::min(mn, cl[k]);
+            }
+            int wbase = mn & ~3, ps = mn;  // ps: first byte of the 8-byte pair the selectors index
+            uint32_t edge = 0;
+            if (wbase + 12 > sw) {
+                wbase = sw - 8;
+                ps = std::min(mn, wbase + 3);
+                edge = 1u << 18;
+            }
+            const int sh = ps - wbase;
+            uint32_t sel[4], wt[4];
+            for (int k = 0; k < 4; k++) {
+                const int ol = cl[k] - ps, orr = cr[k] - ps;
+                // inside the pair, and -- at a row end -- inside its valid part (the bytes above 7 - sh come from the re-read dword)
+                if (sh < 0 || sh > 3 || wbase < 0 || ol < 0 || orr < ol || orr > (edge ? 7 - sh : 7))
+                    direct_ok = false;
+                sel[k] = (uint32_t)(ol & 7) | 0x0c00u | ((uint32_t)(orr & 7) << 16) | 0x0c000000u;
+                wt[k] = (uint32_t)xt[k]->a0 | ((uint32_t)xt[k]->a1 << 16);
+            }
+            rstrip.push_back(ResizeStrip{(uint32_t)wbase | ((uint32_t)sh << 16) | edge});
+            rsel.push_back(uint4{sel[0], sel[1], sel[2], sel[3]});
+            rwt.push_back(uint4{wt[0], wt[1], wt[2], wt[3]});
+        }
+    }
     ncap = std::max(ncap, (max_cells_level + 3) / 4);  // the cell scan reuses the [ncap*4] child-count array
     ncap = ((ncap + 7) / 8) * 8;
     const size_t qt_lds = (size_t)ncap * (2 * sizeof(short4) + 2 * sizeof(int) + 8 * sizeof(int) + 2 * sizeof(int) +
@@ -2300,46 +2476,57 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         for (int l = nl; l <= ORBGPU_MAX_LEVELS; l++)
             bgm.first[l] = acc;
     }
-    // k_fast_detect: bands (rows of cells) x dword columns, and what every dword column knows about the cell grid
+    // k_fast_detect: bands (rows of cells) x dword columns, and what every dword column knows about the cell grid.  Built
+    // twice: every level a padded plane (strips = its aligned dwords from dword 9: image column 17), and with level 0 read
+    // from the image itself (direct mode: strips aligned to the image, from column 16)
     std::vector<ColumnInfo> ctab;
-    {
-        DetectGeom &dgm = e->det_geom;
+    for (int l = 0; l < nl; l++) {
+        const LevelGeom &g = geom[l];
+        int ncols_eff = 0;  // cell columns that are not skipped (ORBextractor.cc:797: iniX >= maxBorderX-6)
+        for (int j = 0; j < g.ncols; j++)
+            if (BORDER0 + j * g.wcell < g.max_bx - 6)
+                ncols_eff++;
+        const int nbands = (g.h - 2 * EDGE + g.hcell - 1) / g.hcell;  // bands with interior rows
+        ORBGPU_REQUIRE(ncols_eff > 0 && g.ncells % ncols_eff == 0 && nbands <= g.ncells / ncols_eff && ncols_eff < 255 &&
+                           g.ncells / ncols_eff < 256 && g.hcell < 128,
+                       "unexpected cell grid at level %d", l);
+        geom[l].ncols_eff = ncols_eff;
+        for (int which = 0; which < 2; which++) {
+            const int d = which ? g.hcell : g.wcell;
+            const uint32_t m = (uint32_t)(((1ull << 32) + (uint64_t)d - 1u) / (uint64_t)d);
+            for (uint32_t v = 0; v < 8192u; v++)
+                ORBGPU_REQUIRE((uint32_t)(((uint64_t)v * m) >> 32) == v / (uint32_t)d, "cell size %d at level %d has no exact reciprocal", d, l);
+            (which ? geom[l].inv_hcell : geom[l].inv_wcell) = m;
+        }
+    }
+    auto build_detect = [&](bool direct0, DetectGeom &dgm) -> bool {
         memset(&dgm, 0, sizeof(dgm));
         dgm.nlevels = nl;
         int acc = 0;
         for (int l = 0; l < nl; l++) {
             const LevelGeom &g = geom[l];
-            const int nsx = (g.w - 1) / 4 - 9 + 1;
-            const int nbands = (g.h - 2 * EDGE + g.hcell - 1) / g.hcell;  // bands with interior rows
-            int ncols_eff = 0;  // cell columns that are not skipped (ORBextractor.cc:797: iniX >= maxBorderX-6)
-            for (int j = 0; j < g.ncols; j++)
-                if (BORDER0 + j * g.wcell < g.max_bx - 6)
-                    ncols_eff++;
-            ORBGPU_REQUIRE(ncols_eff > 0 && g.ncells % ncols_eff == 0 && nbands <= g.ncells / ncols_eff && ncols_eff < 255 &&
-                               g.ncells / ncols_eff < 256 && g.hcell < 128,
-                           "unexpected cell grid at level %d", l);
-            geom[l].ncols_eff = ncols_eff;
-            for (int which = 0; which < 2; which++) {
-                const int d = which ? g.hcell : g.wcell;
-                const uint32_t m = (uint32_t)(((1ull << 32) + (uint64_t)d - 1u) / (uint64_t)d);
-                for (uint32_t v = 0; v < 8192u; v++)
-                    ORBGPU_REQUIRE((uint32_t)(((uint64_t)v * m) >> 32) == v / (uint32_t)d, "cell size %d at level %d has no exact reciprocal", d, l);
-                (which ? geom[l].inv_hcell : geom[l].inv_wcell) = m;
-            }
+            const bool dir = direct0 && l == 0;
+            const int xfirst = dir ? 16 : 9 * 4 - EDGE;
+            // strips must reach the last scored column, w - 20 (padded planes: up to their aligned dword (w-1)/4)
+            const int nsx = dir ? (g.w - 20 - xfirst) / 4 + 1 : (g.w - 1) / 4 - 9 + 1;
+            const int nbands = (g.h - 2 * EDGE + g.hcell - 1) / g.hcell;
             dgm.first[l] = acc;
             dgm.nsx[l] = nsx;
-            dgm.ncols[l] = ncols_eff;
+            dgm.ncols[l] = g.ncols_eff;
             dgm.ctab_off[l] = (int)ctab.size();
+            dgm.xfirst[l] = xfirst;
             acc += nsx * nbands;
+            if (dir)  // level 0's strips end on a wave boundary: a wave of k_fast_detect then reads ONE plane (image or pyramid)
+                acc = (acc + FD_OWN - 1) / FD_OWN * FD_OWN;
             for (int sx = 0; sx < nsx; sx++) {
                 ColumnInfo c{0u, 0u};
                 for (int p = 0; p < 4; p++) {
-                    const int x = (9 + sx) * 4 + p - EDGE;  // image column
+                    const int x = xfirst + 4 * sx + p;  // image column
                     int j = 0xFF;
                     if (x >= EDGE && x < g.w - EDGE) {
                         j = (x - EDGE) / g.wcell;
                         const int xs = EDGE + j * g.wcell, xe = std::min(xs + g.wcell, g.w - EDGE);  // interior [xs, xe)
-                        if (j < ncols_eff) {
+                        if (j < g.ncols_eff) {
                             c.flags |= 1u << p;
                             if (x == xs)
                                 c.flags |= 16u << p;
@@ -2360,7 +2547,8 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
         std::vector<std::pair<int, int>> strip_cells;  // per flat strip: lowest / highest cell id (-1: none)
         for (int l = 0; l < nl; l++) {
             const LevelGeom &g = geom[l];
-            const int nbands = (dgm.first[l + 1] - dgm.first[l]) / dgm.nsx[l];
+            const int nbands = (g.h - 2 * EDGE + g.hcell - 1) / g.hcell;
+            strip_cells.resize((size_t)dgm.first[l], {-1, -1});  // (the padding strips in front of this level)
             for (int b = 0; b < nbands; b++)
                 for (int sx = 0; sx < dgm.nsx[l]; sx++) {
                     const ColumnInfo &c = ctab[dgm.ctab_off[l] + sx];
@@ -2381,10 +2569,17 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
                     lo = lo < 0 ? strip_cells[q].first : std::min(lo, strip_cells[q].first);
                     hi = std::max(hi, strip_cells[q].second);
                 }
-            ORBGPU_REQUIRE(hi - lo < FD_CELLS, "image too small for the FAST kernel's cell bookkeeping (%d cells in one wave)",
-                           hi - lo + 1);
+            if (hi - lo >= FD_CELLS)
+                return false;
         }
-    }
+        return true;
+    };
+    ORBGPU_REQUIRE(build_detect(false, e->det_geom), "image too small for the FAST kernel's cell bookkeeping (more than %d cells in one wave)", FD_CELLS);
+    if (direct_ok)
+        direct_ok = build_detect(true, e->det_geom_direct);
+    e->direct0_ok = direct_ok;
+    e->rs_off_direct = rs_off_direct;
+    e->geom = geom;  // (with the cell-grid fields filled in above)
     // k_border0_fast: per aligned dword of the padded level-0 row, the two adjacent source dwords and the byte selector
     std::vector<BorderCol> bcol;
     if (w % 4 == 0 && w >= 8) {
@@ -2491,6 +2686,44 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     return ORBGPU_OK;
 }
 
+// Level 0 as a padded plane: copyMakeBorder(image, REFLECT_101) (ORBextractor.cc:1125-1129).  Every call when the input is
+// not aligned for direct mode; otherwise only when mvImagePyramid[0] is asked for (the getters below).
+static int materialize_level0(orbgpu_extractor *e, const Src0 &s0, int batch, hipStream_t st)
+{
+    const LevelGeom &g = e->geom[0];
+    const LevelGeom *dg = e->d_geom.as<LevelGeom>();
+    uint8_t *pyr = e->d_pyr.as<uint8_t>();
+    const size_t stride = s0.pitch;
+    if (e->border_fast && stride % 4 == 0 && s0.frame_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(s0.p) & 3) == 0) {
+        dim3 gridf(((g.pitch / 16) * ((g.h + 2 * EDGE + BORDER_ROWS - 1) / BORDER_ROWS) + 255) / 256, batch);
+        hipLaunchKernelGGL(k_border0_fast, gridf, dim3(256), 0, st, s0.p, stride, s0.frame_stride, pyr, e->frame_pyr, dg,
+                           e->d_bcol.as<BorderCol>());
+    } else {
+        dim3 grid(((g.pitch / 4) * ((g.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS) + 255) / 256, batch);
+        hipLaunchKernelGGL(k_border0, grid, dim3(256), 0, st, s0.p, stride, s0.frame_stride, pyr, e->frame_pyr, dg);
+    }
+    ORBGPU_HIP_TRY(hipGetLastError());
+    return ORBGPU_OK;
+}
+
+// the blur of all levels: one launch, or -- direct mode -- level 0 from the image (k_blur0_direct) + the other levels
+static void launch_blur(orbgpu_extractor *e, const Src0 &s0, int batch, hipStream_t st)
+{
+    const int nl = e->nlevels;
+    const LevelGeom *dg = e->d_geom.as<LevelGeom>();
+    uint8_t *pyr = e->d_pyr.as<uint8_t>(), *blur = e->d_blur.as<uint8_t>();
+    int strip0 = 0;
+    if (s0.direct) {
+        const LevelGeom &g = e->geom[0];
+        const int nstrips = (g.w / 8) * ((g.h + BLUR_ROWS - 1) / BLUR_ROWS);
+        hipLaunchKernelGGL(k_blur0_direct, dim3((nstrips + 255) / 256, batch), dim3(256), 0, st, s0, blur, e->frame_pyr, dg);
+        strip0 = e->blur_geom.first[1];
+    }
+    if (e->blur_geom.first[nl] > strip0)
+        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] - strip0 + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
+                           e->frame_pyr, dg, e->blur_geom, strip0);
+}
+
 static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch, int w, int h, size_t stride,
                            size_t frame_stride, orbgpu_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n_out,
                            hipStream_t st)
@@ -2521,16 +2754,19 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
         if (e->pipe_signal[stage])                                             \
             ORBGPU_HIP_TRY(hipEventRecord(e->pipe_signal[stage], s));          \
     }
+    // direct mode: aligned rows, and strides the 24-bit row-offset multiplies cover (checked by the callers: stride < 2^24)
+    const bool aligned4 = stride % 4 == 0 && frame_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_gray) & 3) == 0;
+    const bool direct = e->direct0_ok && !e->no_direct0 && aligned4;
+    const Src0 s0{d_gray, frame_stride, (uint32_t)stride, direct ? 1 : 0};
+    e->last_src = s0;
+    e->level0_materialized = !direct;
     BEGIN(ST_PYRAMID, st);
     {
-        const LevelGeom &g = e->geom[0];
-        dim3 grid(((g.pitch / 4) * ((g.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS) + 255) / 256, batch);
-        if (e->border_fast && stride % 4 == 0 && frame_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_gray) & 3) == 0) {
-            dim3 gridf(((g.pitch / 16) * ((g.h + 2 * EDGE + BORDER_ROWS - 1) / BORDER_ROWS) + 255) / 256, batch);
-            hipLaunchKernelGGL(k_border0_fast, gridf, dim3(256), 0, st, d_gray, stride, frame_stride, pyr, e->frame_pyr, dg,
-                               e->d_bcol.as<BorderCol>());
-        } else
-            hipLaunchKernelGGL(k_border0, grid, dim3(256), 0, st, d_gray, stride, frame_stride, pyr, e->frame_pyr, dg);
+        if (!direct) {
+            int rcb = materialize_level0(e, s0, batch, st);
+            if (rcb != ORBGPU_OK)
+                return rcb;
+        }
         for (int l = 1; l < nl; l++) {
             const LevelGeom &gl = e->geom[l];
             dim3 gr((gl.pitch / 4 + 255) / 256, gl.h + 2 * EDGE, batch);
@@ -2538,10 +2774,14 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
             const int ndw_l = (gl.pitch / 4) * (gl.h + 2 * EDGE);
             const int rows = ndw_l >= 32768 ? PYR_ROWS : ndw_l >= 16384 ? PYR_ROWS / 2 : PYR_ROWS / 4;
             dim3 grf(((gl.pitch / 4) * ((gl.h + 2 * EDGE + rows - 1) / rows) + 255) / 256, batch);
-            if (gl.rs_fast)
-                hipLaunchKernelGGL(rows == PYR_ROWS ? k_resize_fast<true> : k_resize_fast<false>, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
-                                   e->d_rstrip.as<ResizeStrip>(), e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(),
-                                   e->d_ytab.as<YTab>(), gl.rs_off, rows);
+            if (gl.rs_fast) {
+                const bool dir1 = direct && l == 1;  // level 1 straight from the image
+                auto kern = dir1 ? (rows == PYR_ROWS ? k_resize_fast<true, true> : k_resize_fast<false, true>)
+                                 : (rows == PYR_ROWS ? k_resize_fast<true, false> : k_resize_fast<false, false>);
+                hipLaunchKernelGGL(kern, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l, e->d_rstrip.as<ResizeStrip>(),
+                                   e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(), e->d_ytab.as<YTab>(),
+                                   dir1 ? e->rs_off_direct : gl.rs_off, rows, s0);
+            }
             else
                 hipLaunchKernelGGL(k_resize_level, gr, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
                                    e->d_xtab.as<XTab>(), e->d_ytab.as<YTab>());
@@ -2558,14 +2798,12 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
         ORBGPU_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
         if (prof)
             ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 1], e->side));
-        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, e->side, pyr, blur,
-                           e->frame_pyr, dg, e->blur_geom);
+        launch_blur(e, s0, batch, e->side);
         if (prof)
             ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 2], e->side));
         ORBGPU_HIP_TRY(hipEventRecord(e->ev_join, e->side));
     } else
-        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
-                           e->frame_pyr, dg, e->blur_geom);
+        launch_blur(e, s0, batch, st);
     END(ST_BLUR, st);
     BEGIN(ST_FAST, st);
     if (e->counters_dirty) {  // a previous call enqueued the FAST pass but not the quadtree that re-arms the counters
@@ -2575,11 +2813,12 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     e->counters_dirty = true;
     {
         const int t_ini = std::max(e->prm.ini_th_fast, 1), t_min = std::max(e->prm.min_th_fast, 1);
-        const int nwaves = (e->det_geom.first[nl] + FD_OWN - 1) / FD_OWN;
+        const DetectGeom &dgeo = direct ? e->det_geom_direct : e->det_geom;
+        const int nwaves = (dgeo.first[nl] + FD_OWN - 1) / FD_OWN;
         hipLaunchKernelGGL(e->fast_early_out ? k_fast_detect<true> : k_fast_detect<false>, dim3((nwaves + 3) / 4, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg,
-                           e->det_geom, e->d_ctab.as<ColumnInfo>(), e->d_cells.as<CellDesc>(), (int)e->cells.size(),
+                           dgeo, e->d_ctab.as<ColumnInfo>(), e->d_cells.as<CellDesc>(), (int)e->cells.size(),
                            e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(), std::min(t_ini, t_min),
-                           t_ini, e->fast_queue_cap);
+                           t_ini, e->fast_queue_cap, s0);
     }
     END(ST_FAST, st);
     BEGIN(ST_QUADTREE, st);
@@ -2610,7 +2849,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 8 * or_iters - 1) / (8 * or_iters), batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(),
                        reinterpret_cast<const uint32_t *>(e->d_pattern.as<uint8_t>() + 1024), d_kps,
-                       e->d_aux.as<KpAux>(), cap, d_n_out, or_iters);
+                       e->d_aux.as<KpAux>(), cap, d_n_out, or_iters, s0);
     hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
                        e->d_aux.as<KpAux>(), d_n_out, cap, e->trig);
     END(ST_ORIENT, st);
@@ -2662,6 +2901,7 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
     e->qt_no_prefilter = getenv("ORBGPU_DEBUG_QT_NOPRE") != nullptr;
     if (const char *q = getenv("ORBGPU_DEBUG_QT_KEYS"))  // test hook, read here like the others (configure() runs at the first extraction)
         e->qt_keys_hook = std::max(atoi(q), 0);
+    e->no_direct0 = getenv("ORBGPU_DEBUG_NO_DIRECT0") != nullptr;
     if (const char *q = getenv("ORBGPU_FAST_EARLY_OUT"))  // default of the option for handles created from now on (fuzzing, A/B)
         e->fast_early_out = atoi(q) != 0;
     if (const char *q = getenv("ORBGPU_DEBUG_FAST_QUEUE"))  // test hook: forces k_fast_detect's queue-full path
@@ -2820,9 +3060,10 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch
     bool launched = false;
     if (!e->profiling && e->graph_state >= 0) {
         if (e->graph_exec && e->graph_key == key) {
-            if (hipGraphLaunch(e->graph_exec, e->stream) == hipSuccess)
+            if (hipGraphLaunch(e->graph_exec, e->stream) == hipSuccess) {
                 launched = true;
-            else
+                e->level0_materialized = !e->last_src.direct;  // the replay did what launch_pipeline recorded: no padded level 0 in direct mode
+            } else
                 e->graph_state = -1;
         } else if (e->graph_key == key) {  // second call of this configuration: capture
             hipGraph_t g = nullptr;
@@ -2846,6 +3087,7 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch
                 e->graph_state = 1;
                 ok = hipGraphLaunch(e->graph_exec, e->stream) == hipSuccess;
                 launched = ok;
+                e->level0_materialized = !e->last_src.direct;
             }
             if (!ok) {
                 (void)hipGetLastError();
@@ -2894,6 +3136,22 @@ int orbgpu_extract(orbgpu_extractor *e, const uint8_t *gray, int32_t w, int32_t 
     return orbgpu_extract_batch(e, gray, 1, w, h, stride, stride * (size_t)(h > 0 ? h : 0), kps, desc, cap, n_out);
 }
 
+// Direct mode leaves level 0 of the padded pyramid unwritten (no stage reads it); whoever asks for it gets it now, from the
+// image of the last call -- the handle's own staging copy for the host entry points, the caller's device buffer for
+// orbgpu_extract_batch_device (which must still hold the images: orbgpu.h).
+static int ensure_level0(orbgpu_extractor *e)
+{
+    if (e->level0_materialized)
+        return ORBGPU_OK;
+    ORBGPU_HIP_TRY(hipDeviceSynchronize());
+    int rc = materialize_level0(e, e->last_src, e->last_batch, nullptr);
+    if (rc != ORBGPU_OK)
+        return rc;
+    ORBGPU_HIP_TRY(hipDeviceSynchronize());
+    e->level0_materialized = true;
+    return ORBGPU_OK;
+}
+
 int orbgpu_extractor_get_pyramid_level(orbgpu_extractor *e, int32_t frame, int32_t level, uint8_t *dst,
                                        size_t dst_stride, int32_t *width, int32_t *height)
 {
@@ -2904,6 +3162,8 @@ int orbgpu_extractor_get_pyramid_level(orbgpu_extractor *e, int32_t frame, int32
     ORBGPU_REQUIRE(dst_stride >= (size_t)g.w, "bad dst_stride");
     int rc = select_device(e->prm.device_id);
     if (rc != ORBGPU_OK)
+        return rc;
+    if (level == 0 && (rc = ensure_level0(e)) != ORBGPU_OK)
         return rc;
     const uint8_t *src = e->d_pyr.as<uint8_t>() + e->frame_pyr * frame + g.plane_off + (size_t)EDGE * g.pitch + EDGE;
     ORBGPU_HIP_TRY(hipDeviceSynchronize());
@@ -2929,8 +3189,16 @@ int orbgpu_extractor_debug_read(orbgpu_extractor *e, int32_t what, int32_t frame
     if (what == ORBGPU_DBG_PYRAMID_PADDED || what == ORBGPU_DBG_BLURRED_PADDED) {
         const size_t bytes = (size_t)g.pitch * (g.h + 2 * EDGE);
         ORBGPU_REQUIRE(dst_bytes >= bytes, "dst too small (%zu needed)", bytes);
+        if (what == ORBGPU_DBG_PYRAMID_PADDED && level == 0 && (rc = ensure_level0(e)) != ORBGPU_OK)
+            return rc;
         const uint8_t *base = (what == ORBGPU_DBG_PYRAMID_PADDED ? e->d_pyr : e->d_blur).as<uint8_t>();
         ORBGPU_HIP_TRY(hipMemcpy(dst, base + e->frame_pyr * frame + g.plane_off, bytes, hipMemcpyDeviceToHost));
+        if (what == ORBGPU_DBG_BLURRED_PADDED && level == 0 && e->last_src.direct) {
+            // direct mode keeps the blurred level 0 with pixel 0 at column BLUR0_OX: present it in the common layout
+            uint8_t *rowp = static_cast<uint8_t *>(dst);
+            for (int r = 0; r < g.h + 2 * EDGE; r++, rowp += g.pitch)
+                memmove(rowp, rowp + (BLUR0_OX - EDGE), (size_t)g.pitch - (BLUR0_OX - EDGE));
+        }
         *n = bytes;
         if (aux)
             *aux = g.pitch;

@@ -402,6 +402,15 @@ class ORBextractor:
     def set_concurrent_blur(self, on):
         check(self.L.orbgpu_extractor_set_concurrent_blur(self.h, int(on)))
 
+    def get_pyramid_level(self, frame, level):
+        """mvImagePyramid[level] of frame `frame` of the last call (ORBextractor.h:85) through the drop-in getter
+        orbgpu_extractor_get_pyramid_level: (pixels HxW, width, height)."""
+        buf = np.zeros((4112, 4112), np.uint8)  # the largest level the library accepts
+        w, h = C.c_int32(), C.c_int32()
+        check(self.L.orbgpu_extractor_get_pyramid_level(self.h, int(frame), int(level), _p(buf), buf.strides[0], C.byref(w),
+                                                        C.byref(h)))
+        return buf[:h.value, :w.value].copy(), w.value, h.value
+
     def set_fast_early_out(self, on):
         """Exact wave-level early-out of the FAST score network (orbgpu_extractor_set_fast_early_out)."""
         self.L.orbgpu_extractor_set_fast_early_out.argtypes = [C.c_void_p, C.c_int32]

@@ -9,14 +9,18 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
 
 
-@pytest.fixture(autouse=True, params=["default", "fast_early_out"])
+@pytest.fixture(autouse=True, params=["default", "fast_early_out", "padded_level0"])
 def fast_stage_variant(request, monkeypatch):
-    """Every test of this module runs twice: with the round-3 FAST kernel and with its exact wave-level early-out
-    (k_fast_detect<true>; the environment variable is the option's default for handles created afterwards)."""
+    """Every test of this module runs three times: as shipped (level 0 read straight from the caller's image where the
+    input is aligned -- direct mode --, the round-3 FAST kernel), with the FAST kernel's exact wave-level early-out
+    (k_fast_detect<true>), and with direct mode off (level 0 always copied into a padded plane, the round-3 data path).
+    The environment variables are read when a handle is created."""
+    monkeypatch.delenv("ORBGPU_FAST_EARLY_OUT", raising=False)
+    monkeypatch.delenv("ORBGPU_DEBUG_NO_DIRECT0", raising=False)
     if request.param == "fast_early_out":
         monkeypatch.setenv("ORBGPU_FAST_EARLY_OUT", "1")
-    else:
-        monkeypatch.delenv("ORBGPU_FAST_EARLY_OUT", raising=False)
+    elif request.param == "padded_level0":
+        monkeypatch.setenv("ORBGPU_DEBUG_NO_DIRECT0", "1")
     return request.param
 
 
@@ -444,3 +448,32 @@ def test_fast_early_out_on_images_with_flat_regions(gpu, oracle, w, h, nfeat, fl
             check_stages(gpu, ge, oe, f, 8, "flat %.2f %dx%d frame %d early-out %s" % (flat, w, h, f, on))
             assert_same_keypoints(gk[f], gd[f], ok, od, "flat %.2f %dx%d frame %d early-out %s" % (flat, w, h, f, on))
     assert len(gk[0]) > nfeat // 4  # the textured part still fills most of the quota
+
+
+def test_direct_mode_level0_is_materialised_on_demand(gpu, oracle, stream640):
+    """Device-resident, aligned input: no stage writes level 0 of the padded pyramid (the kernels read the image); the
+    getters of mvImagePyramid[0] and of the padded debug view produce it when asked, from the image of the last call.
+    Strides that are multiples of 4 but not of 64, and a stride > width, stay on the direct path."""
+    import torch
+    g0, g1 = stream640.frame(21)[0], stream640.frame(22)[0]
+    oe = oracle.Extractor(1000)
+    for stride in (640, 644, 704):
+        ge = gpu.ORBextractor(1000, max_batch=2)
+        cap = ge.max_keypoints(640, 480)
+        buf = torch.zeros((2, 480, stride), dtype=torch.uint8, device="cuda")
+        buf[0, :, :640] = torch.from_numpy(g0).cuda()
+        buf[1, :, :640] = torch.from_numpy(g1).cuda()
+        kps = torch.zeros((2, cap, 7), dtype=torch.float32, device="cuda")
+        desc = torch.zeros((2, cap, 32), dtype=torch.uint8, device="cuda")
+        n = torch.zeros(2, dtype=torch.int32, device="cuda")
+        ge.extract_batch_device(buf.data_ptr(), 2, 640, 480, stride, 480 * stride, kps.data_ptr(), desc.data_ptr(), cap, n.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for f, g in enumerate((g0, g1)):
+            ok, od = oe.extract(g)
+            nf = int(n[f])
+            gk = np.frombuffer(kps[f, :nf].cpu().numpy().tobytes(), gpu.KEYPOINT_DTYPE)
+            assert_same_keypoints(gk, desc[f, :nf].cpu().numpy(), ok, od, "stride %d frame %d" % (stride, f))
+            lvl0, w0, h0 = ge.get_pyramid_level(f, 0)
+            assert (w0, h0) == (640, 480) and np.array_equal(lvl0, g)
+            check_stages(gpu, ge, oe, f, 8, "stride %d frame %d" % (stride, f))
