@@ -2181,7 +2181,7 @@ struct orbgpu_extractor {
     // optional: the blur (HBM-bound) on a stream of the handle's own next to the FAST pass (VALU-bound) and the quadtree
     bool concurrent_blur = false;
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_fork0 = nullptr, ev_join = nullptr;
     bool qt_no_prefilter = false;  // ORBGPU_DEBUG_QT_NOPRE: single frames filter their keys inside k_quadtree<true> (tests, A/B)
     int qt_keys_hook = -1;  // ORBGPU_DEBUG_QT_KEYS (read at creation): LDS key share of k_quadtree<true>; -1 = as many as fit
     int fast_queue_cap = FD_QCAP;  // row records a wave of k_fast_detect queues (ORBGPU_DEBUG_FAST_QUEUE shrinks it: tests)
@@ -2189,6 +2189,7 @@ struct orbgpu_extractor {
     int graph_state = 0;  // 0 = not tried, 1 = usable, -1 = capture failed: plain launches from then on
     // direct mode (Src0): level 0 read from the caller's image, no padded copy
     bool direct0_ok = false;       // the configured geometry has the tables for it (width % 8 == 0, >= 2 levels on the fast resize path)
+    bool no_early_blur0 = false;   // ORBGPU_DEBUG_NO_EARLY_BLUR0: concurrent blur forks after the pyramid for level 0 too (A/B)
     bool no_direct0 = false;       // ORBGPU_DEBUG_NO_DIRECT0 (read at creation): always make the padded copy (tests, A/B)
     int rs_off_direct = 0;         // level 1's strip tables for the unpadded source
     DetectGeom det_geom_direct;    // k_fast_detect's strips with level 0 aligned to the image
@@ -2707,7 +2708,8 @@ static int materialize_level0(orbgpu_extractor *e, const Src0 &s0, int batch, hi
 }
 
 // the blur of all levels: one launch, or -- direct mode -- level 0 from the image (k_blur0_direct) + the other levels
-static void launch_blur(orbgpu_extractor *e, const Src0 &s0, int batch, hipStream_t st)
+// (which: 0 = everything, 1 = only the direct-mode level 0, which needs nothing but the image, 2 = only the rest)
+static void launch_blur(orbgpu_extractor *e, const Src0 &s0, int batch, hipStream_t st, int which = 0)
 {
     const int nl = e->nlevels;
     const LevelGeom *dg = e->d_geom.as<LevelGeom>();
@@ -2716,9 +2718,12 @@ static void launch_blur(orbgpu_extractor *e, const Src0 &s0, int batch, hipStrea
     if (s0.direct) {
         const LevelGeom &g = e->geom[0];
         const int nstrips = (g.w / 8) * ((g.h + BLUR_ROWS - 1) / BLUR_ROWS);
-        hipLaunchKernelGGL(k_blur0_direct, dim3((nstrips + 255) / 256, batch), dim3(256), 0, st, s0, blur, e->frame_pyr, dg);
+        if (which != 2)
+            hipLaunchKernelGGL(k_blur0_direct, dim3((nstrips + 255) / 256, batch), dim3(256), 0, st, s0, blur, e->frame_pyr, dg);
         strip0 = e->blur_geom.first[1];
     }
+    if (which == 1)
+        return;
     if (e->blur_geom.first[nl] > strip0)
         hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] - strip0 + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
                            e->frame_pyr, dg, e->blur_geom, strip0);
@@ -2761,6 +2766,16 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     e->last_src = s0;
     e->level0_materialized = !direct;
     BEGIN(ST_PYRAMID, st);
+    // concurrent blur in direct mode: level 0's blur depends on the image only -- it starts on the side stream now, next
+    // to the resize chain (seven dependent launches whose small levels leave most of the device idle)
+    const bool early_blur0 = e->concurrent_blur && direct && !e->no_early_blur0;
+    if (early_blur0) {
+        ORBGPU_HIP_TRY(hipEventRecord(e->ev_fork0, st));
+        ORBGPU_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork0, 0));
+        if (prof)
+            ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 1], e->side));
+        launch_blur(e, s0, batch, e->side, 1);
+    }
     {
         if (!direct) {
             int rcb = materialize_level0(e, s0, batch, st);
@@ -2796,9 +2811,9 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
         // fork: the side stream waits for the pyramid, blurs, and is joined in front of the descriptor stage
         ORBGPU_HIP_TRY(hipEventRecord(e->ev_fork, st));
         ORBGPU_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-        if (prof)
+        if (prof && !early_blur0)
             ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 1], e->side));
-        launch_blur(e, s0, batch, e->side);
+        launch_blur(e, s0, batch, e->side, early_blur0 ? 2 : 0);
         if (prof)
             ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 2], e->side));
         ORBGPU_HIP_TRY(hipEventRecord(e->ev_join, e->side));
@@ -2902,6 +2917,7 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
     if (const char *q = getenv("ORBGPU_DEBUG_QT_KEYS"))  // test hook, read here like the others (configure() runs at the first extraction)
         e->qt_keys_hook = std::max(atoi(q), 0);
     e->no_direct0 = getenv("ORBGPU_DEBUG_NO_DIRECT0") != nullptr;
+    e->no_early_blur0 = getenv("ORBGPU_DEBUG_NO_EARLY_BLUR0") != nullptr;
     if (const char *q = getenv("ORBGPU_FAST_EARLY_OUT"))  // default of the option for handles created from now on (fuzzing, A/B)
         e->fast_early_out = atoi(q) != 0;
     if (const char *q = getenv("ORBGPU_DEBUG_FAST_QUEUE"))  // test hook: forces k_fast_detect's queue-full path
@@ -2949,6 +2965,8 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
         (void)hipStreamDestroy(e->side);
     if (e->ev_fork)
         (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_fork0)
+        (void)hipEventDestroy(e->ev_fork0);
     if (e->ev_join)
         (void)hipEventDestroy(e->ev_join);
     delete e;
@@ -3417,6 +3435,7 @@ int orbgpu_extractor_set_concurrent_blur(orbgpu_extractor *e, int32_t enable)
     if (enable && !e->side) {
         ORBGPU_HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
         ORBGPU_HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        ORBGPU_HIP_TRY(hipEventCreateWithFlags(&e->ev_fork0, hipEventDisableTiming));
         ORBGPU_HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     }
     if ((enable != 0) != e->concurrent_blur) {
