@@ -121,3 +121,39 @@ def synthetic_vocabulary(k, L, seed, irregular=False, stop_frac=0.0, flip_bits=4
     weight[leaves] = np.log(1000.0 / rng.integers(1, 900, len(leaves)))
     weight[leaves[rng.random(len(leaves)) < stop_frac]] = 0.0
     return {"k": k, "L": L, "parent": parent, "is_leaf": is_leaf, "desc": np.stack(desc), "weight": weight}
+
+
+def face_depth_values(leaf, kmin=21, kmax=200):
+    """Depth values whose voxel the voxel grid's own centroid leaves: for the float32 leaf size `leaf`, all (k, z, count)
+    with z the largest float of z-voxel k-1 such that the float mean of `count` copies of z (summed left to right, as PCL
+    does) already lies in voxel k.  A voxel filled with `count` such points yields a centroid that the NEXT filter call
+    puts into the neighbouring voxel -- the map is then not strictly increasing under the new indices, which is the
+    merge path's non-overflow precondition failure."""
+    f = np.float32
+    inv = f(1.0) / f(leaf)
+    out = []
+    for k in range(kmin, kmax):
+        x = f(k) / inv
+        while np.floor(f(x * inv)) >= k:
+            x = np.nextafter(x, f(-np.inf))
+        while np.floor(f(np.nextafter(x, f(np.inf)) * inv)) < k:
+            x = np.nextafter(x, f(np.inf))
+        for cnt in (2, 3, 4, 5, 6, 7):
+            s = x
+            for _ in range(cnt - 1):
+                s = f(s + x)
+            if np.floor(f(f(s / f(cnt)) * inv)) >= k:
+                out.append((k, float(x), cnt))
+    return out
+
+
+def plant_face_voxel(depth, stream, k, z, count, row=258, col0=321):
+    """Clears a window of the depth image and plants `count` samples of depth z (one voxel in x, y near the optical axis)
+    plus one sample just above the voxel face, so that after one insert the map holds the voxels (.., k-1) and (.., k) of
+    one column and the centroid of the first already belongs to the second.  Returns the modified copy."""
+    d = depth.copy()
+    d[row - 12:row + 13, col0 - 12:col0 + 3 * count + 16] = 0.0  # invalid: nothing else lands in these voxels
+    for i in range(count):
+        d[row, col0 + 3 * i] = np.float32(z)
+    d[row, col0 + 3 * count] = np.float32(z) + np.float32(0.001)  # the same column's voxel k
+    return d

@@ -249,6 +249,32 @@ def test_cloud_overflow_then_recovery(gpu, oracle, stream640):
     cloud.close()
 
 
+@pytest.mark.parametrize("which", [0, 1, 4])
+def test_cloud_centroid_on_a_voxel_face_redoes_the_key_frame(gpu, oracle, stream640, which):
+    """The merge path's OTHER precondition failure (no int32 overflow involved): a voxel whose float centroid the next
+    filter call puts into the neighbouring voxel.  Key frame 1 plants `count` samples at the largest depth of voxel k-1
+    whose mean already indexes voxel k, plus one sample in voxel k of the same column; the map that comes back holds two
+    points with the same index under any later grid, so key frame 2 finds the resident map "not strictly increasing",
+    redoes the insert through the general path (3) and must still equal PCL's result.  Afterwards the merge path resumes."""
+    camv = cam(stream640)
+    leaf = 0.05
+    k, z, cnt = [v for v in scenario.face_depth_values(leaf) if v[2] == 3][which]  # (three samples 9 px apart share an x voxel)
+    _, rgb, depth = stream640.frame(3)
+    d1 = scenario.plant_face_voxel(depth, stream640, k, z, cnt)
+    T = np.eye(4, dtype=np.float32)
+    cloud = gpu.PointCloudMapping(leaf)
+    omap = np.zeros(0, oracle.POINT_DTYPE)
+    paths = []
+    for dep in (d1, depth, stream640.frame(9)[2]):
+        cloud.insertKeyFrame(dep, rgb, *camv, T)
+        omap, ov = _oracle_step(oracle, omap, dep, rgb, camv, T, leaf)
+        assert not ov
+        paths.append(cloud.last_path())
+        assert cloud.download().tobytes() == omap.tobytes(), "key frame %d (path %d)" % (len(paths), paths[-1])
+    assert paths == [1, 3, 1], paths
+    cloud.close()
+
+
 def test_cloud_insert_device_resident(gpu, oracle, stream640):
     """orbgpu_cloud_insert_device: depth / rgb already in HBM (strided views of larger device buffers)."""
     import torch

@@ -27,11 +27,25 @@ while time.time() - t0 < budget:
     cloud = G.PointCloudMapping(leaf)
     omap = np.zeros(0, O.POINT_DTYPE)
     kfs = []
+    # scenarios that leave the merge path: "face" plants voxels whose centroid the next call indexes into the neighbouring
+    # voxel (the resident map is then not strictly increasing: the key frame is redone, path 3); "far" moves the camera
+    # tens of metres in all axes so that PCL's int32 overflow rule returns map ++ new unfiltered (path 3) and the key
+    # frame after it starts from an unsorted map (general path, 2)
+    kind = ["plain", "face", "far"][int(rng.choice([0, 0, 1, 2]))]
+    faces = scenario.face_depth_values(leaf, 11, 120) if kind == "face" else []
     for i in range(int(rng.integers(2, 7))):
         _, rgb, depth = st.frame(int(rng.integers(0, 60)))
         step = float(rng.choice([0.0, 0.05, 0.4, 3.0]))  # same view, small motion, new area, far away
+        if kind == "far" and i >= 1 and rng.random() < 0.5:
+            step = 30.0 if leaf <= 0.02 else 120.0
         T = scenario.rigid(float(rng.normal(0, 0.02)), float(rng.normal(0, 0.02)), float(rng.normal(0, 0.02)),
                            tuple((rng.normal(0, 1, 3) * step).tolist()))
+        if kind == "face":
+            T = np.eye(4, dtype=np.float32)  # the planted depths must reach the map unrotated
+            if faces and rng.random() < 0.7:
+                k, z, cnt = faces[int(rng.integers(0, len(faces)))]
+                depth = scenario.plant_face_voxel(depth, st, k, z, cnt, row=3 * int(rng.integers(10, h // 3 - 10)),
+                                                  col0=3 * int(rng.integers(10, w // 3 - 20)))
         kfs.append((depth, rgb, T))
         cloud.insertKeyFrame(depth, rgb, *camv, T)
         paths[cloud.last_path()] += 1
