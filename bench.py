@@ -56,9 +56,11 @@ def algorithmic_bytes(stage, n_kp, n_cand):
     raise KeyError(stage)
 
 
-STAGE_KERNELS = {"pyramid": ["k_border0_fast"] + ["k_resize_fast"] * 7, "fast": ["k_fast_detect"],
+# kernels of a stage in direct mode (aligned device input: level 0 is read from the image); the
+# round-3 data path had k_border0_fast in front of the seven resize launches and one k_blur launch
+STAGE_KERNELS = {"pyramid": ["k_resize_fast"] * 7, "fast": ["k_fast_detect"],
                  "quadtree": ["k_quadtree"], "orient": ["k_orient", "k_trig"],
-                 "blur": ["k_blur"], "describe": ["k_describe"]}
+                 "blur": ["k_blur0_direct", "k_blur"], "describe": ["k_describe"]}
 
 
 PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")  # newest first (the round-1 file predates the fused FAST kernel)

@@ -42,6 +42,7 @@ struct LevelGeom {
     int rs_off, rs_fast;     // fast-path strip tables (k_resize_fast); rs_fast = 0 -> k_resize_level
     int ncols_eff;           // cell columns that are not skipped (ORBextractor.cc:797)
     uint32_t inv_wcell, inv_hcell;  // mul_hi(v, inv) == v / wcell (hcell) for every key coordinate (host-verified)
+    int yrow_off;                   // k_resize_fast: first YRow of the level (one per PADDED output row)
 };
 
 struct CellDesc {
@@ -61,6 +62,9 @@ struct XTab {  // cv::resize horizontal table entry (A2)
 struct YTab {
     uint16_t sy0, sy1;
     int16_t b0, b1;
+};
+struct YRow {  // the same per PADDED output row (border rows = the entry of the row they reflect to), as four ints: one
+    int sy0, sy1, b0, b1;  // 16-byte load, no reflection and no field extraction in k_resize_fast's row loop
 };
 
 
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void k_resize_level(uint8_t *__restrict__ pyr,
 // Same integer arithmetic as k_resize_level.
 struct ResizeStrip {  // per padded output dword column of a level
     uint32_t base_q;  // bits 0..15: window base (padded source column, multiple of 4); bits 16..17: byte shift of the window;
-                      // bit 18 (direct level-0 source only): the window ends at the row end -- its third dword is not read
+                      // bit 18 (direct level-0 source only): the window is the last 12 bytes of the row and the pair comes from its dwords 1, 2
 };
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
                                                      const LevelGeom *__restrict__ geom, int level,
                                                      const ResizeStrip *__restrict__ strips,
                                                      const uint4 *__restrict__ sels, const uint4 *__restrict__ wts,
-                                                     const YTab *__restrict__ ytab, int strip_off, int rows, Src0 s0)
+                                                     const YRow *__restrict__ yrows, int strip_off, int rows, Src0 s0)
 {
     const LevelGeom g = geom[level];
     const LevelGeom gs = geom[level - 1];
@@ -296,18 +300,18 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
     uint8_t *fb = pyr + (size_t)f * frame_pyr;
     const uint8_t *sb = DIRECT ? s0.p + (size_t)f * s0.frame_stride : fb;  // source plane: padded level l-1, or the image itself
     const int spitch = DIRECT ? (int)s0.pitch : gs.pitch;
-    const int soy = DIRECT ? 0 : EDGE;  // row of source pixel row 0 in the source plane
-    const uint32_t base = (DIRECT ? 0u : (uint32_t)gs.plane_off) + (bq & 0xFFFFu);
-    const uint32_t o2 = DIRECT && ((bq >> 18) & 1u) ? 1u : 2u;  // third dword of the window (DIRECT at a row end: the second again)
+    // (source pixel row 0 is row EDGE of a padded source plane: folded into the base offset)
+    const uint32_t base = (DIRECT ? 0u : (uint32_t)gs.plane_off + (uint32_t)EDGE * (uint32_t)gs.pitch) + (bq & 0xFFFFu);
+    // DIRECT, a window at the end of an image row: it is placed on the row's LAST 12 bytes (nothing past the row is read)
+    // and the 8-byte pair is taken from its second and third dword instead of the first and second
+    const bool edge = DIRECT && ((bq >> 18) & 1u) != 0u;
     const uint32_t dst = (uint32_t)g.plane_off + (uint32_t)sdw * 4u;
     // the row table entries of all rows of the item first (one round trip), so that the source loads of a row do
     // not wait for a table load of their own
-    YTab yts[PYR_ROWS];
+    YRow yts[PYR_ROWS];
 #pragma unroll
-    for (int rr = 0; rr < PYR_ROWS; rr++) {
-        const int py = min(rg * rows + rr, g.h + 2 * EDGE - 1);
-        yts[rr] = ytab[g.ytab_off + reflect101(py - EDGE, g.h)];
-    }
+    for (int rr = 0; rr < PYR_ROWS; rr++)
+        yts[rr] = yrows[g.yrow_off + min(rg * rows + rr, g.h + 2 * EDGE - 1)];
     // consecutive output rows share a source row (row y's lower tap row is usually row y+1's upper one): its horizontal
     // interpolation is kept instead of being loaded and computed again
     int kept_row = -1, kept[4] = {0, 0, 0, 0};
@@ -316,13 +320,23 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
         const int py = rg * rows + rr;
         if (rr >= rows || py >= g.h + 2 * EDGE)
             break;
-        const YTab yt = yts[rr];
-        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(sb + (base + rowoff(yt.sy1 + soy, spitch)));
-        const uint32_t c0 = S1[0], c1 = S1[1], c2 = DIRECT ? S1[o2] : S1[2];
+        const YRow yt = yts[rr];
+        const uint32_t *S1 = reinterpret_cast<const uint32_t *>(sb + (base + rowoff(yt.sy1, spitch)));
+        uint32_t c0 = S1[0], c1 = S1[1];
+        const uint32_t c2 = S1[2];
+        if (DIRECT) {
+            c0 = edge ? c1 : c0;
+            c1 = edge ? c2 : c1;
+        }
         int t0[4];
-        if (!REUSE || (int)yt.sy0 != kept_row) {
-            const uint32_t *S0 = reinterpret_cast<const uint32_t *>(sb + (base + rowoff(yt.sy0 + soy, spitch)));
-            const uint32_t a0 = S0[0], a1 = S0[1], a2 = DIRECT ? S0[o2] : S0[2];
+        if (!REUSE || yt.sy0 != kept_row) {
+            const uint32_t *S0 = reinterpret_cast<const uint32_t *>(sb + (base + rowoff(yt.sy0, spitch)));
+            uint32_t a0 = S0[0], a1 = S0[1];
+            const uint32_t a2 = S0[2];
+            if (DIRECT) {
+                a0 = edge ? a1 : a0;
+                a1 = edge ? a2 : a1;
+            }
             const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, sh), hi = __builtin_amdgcn_alignbyte(a2, a1, sh);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -340,8 +354,8 @@ __global__ __launch_bounds__(256) void k_resize_fast(uint8_t *__restrict__ pyr, 
         for (int k = 0; k < 4; k++) {
             const uint32_t p1 = __builtin_amdgcn_perm(hi1, lo1, selv[k]);
             const int t1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(us2, p1), __builtin_bit_cast(us2, wv[k]), 0u, false);
-            const int o = ((__mul24((int)yt.b0, t0[k] >> 4) >> 16) + (__mul24((int)yt.b1, t1 >> 4) >> 16) + 2) >> 2;  // 12 x 15 bits
-            v |= (uint32_t)(o & 0xFF) << (8 * k);
+            const int o = ((__mul24(yt.b0, t0[k] >> 4) >> 16) + (__mul24(yt.b1, t1 >> 4) >> 16) + 2) >> 2;  // 12 x 15 bits
+            v |= (uint32_t)o << (8 * k);  // o <= 255: the two weights add up to 2048 (+-1) and t >> 4 <= 255 * 128
             kept[k] = t1;
         }
         kept_row = yt.sy1;
@@ -2155,7 +2169,7 @@ struct orbgpu_extractor {
     size_t qt_lds = 0;
     int qt_kcap = 0;  // keys of a level k_quadtree<true> keeps in LDS
     // device state
-    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_pattern, d_rstrip, d_rsel, d_rwt, d_ctab, d_bcol;
+    DevBuf d_geom, d_cells, d_xtab, d_ytab, d_yrow, d_pattern, d_rstrip, d_rsel, d_rwt, d_ctab, d_bcol;
     DevBuf d_pyr, d_blur, d_slots, d_cellcnt, d_dkey, d_dnode, d_sel, d_nsel, d_ncand, d_aux;
     DevBuf d_qtaux;  // k_qt_prefilter -> k_quadtree<true> (single frames): QT_AUX_FRAME ints per frame, < QT_BATCH_MIN frames
     bool qt_prefilter = false;  // every level has <= QT_INI_MAX initial nodes
@@ -2257,6 +2271,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     std::vector<CellDesc> cells;
     std::vector<XTab> xtab;
     std::vector<YTab> ytab;
+    std::vector<YRow> yrow;
     std::vector<ResizeStrip> rstrip;
     std::vector<uint4> rsel, rwt;
     size_t plane_off = 0;
@@ -2368,6 +2383,11 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
                 t.b1 = sat_short(cv_round_host(fy * 2048));
                 ytab.push_back(t);
             }
+            g.yrow_off = (int)yrow.size();
+            for (int py = 0; py < g.h + 2 * EDGE; py++) {
+                const YTab &t = ytab[g.ytab_off + reflect101(py - EDGE, g.h)];
+                yrow.push_back(YRow{(int)t.sy0, (int)t.sy1, (int)t.b0, (int)t.b1});
+            }
             // fast-path strip tables: one entry per aligned output dword of the padded row
             g.rs_off = (int)rstrip.size();
             g.rs_fast = 1;
@@ -2404,7 +2424,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     }
     // direct mode: level 1's strips once more, for source columns counted from the image's own column 0 (Src0).  A window
     // that would run past the end of an image row (the next row, or -- last row of the last frame -- the end of the
-    // caller's buffer) is placed on the row's last 8 bytes and its third dword is not read (bit 18).
+    // caller's buffer) is placed on the row's last 12 bytes and the pair is cut from its second and third dword (bit 18).
     bool direct_ok = nl >= 2 && w % 8 == 0 && w >= 64 && geom[std::min(1, nl - 1)].rs_fast != 0;
     int rs_off_direct = 0;
     if (direct_ok) {
@@ -2422,13 +2442,15 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
                 mn = std::min(mn, cl[k]);
             }
             int wbase = mn & ~3, ps = mn;  // ps: first byte of the 8-byte pair the selectors index
+            int pbase = wbase;             // first byte of the two dwords the pair is cut from
             uint32_t edge = 0;
-            if (wbase + 12 > sw) {
-                wbase = sw - 8;
-                ps = std::min(mn, wbase + 3);
+            if (wbase + 12 > sw) {  // the window would pass the end of the row: the row's last 12 bytes, pair from dwords 1 and 2
+                wbase = sw - 12;
+                pbase = sw - 8;
+                ps = std::min(mn, pbase + 3);
                 edge = 1u << 18;
             }
-            const int sh = ps - wbase;
+            const int sh = ps - pbase;
             uint32_t sel[4], wt[4];
             for (int k = 0; k < 4; k++) {
                 const int ol = cl[k] - ps, orr = cr[k] - ps;
@@ -2623,6 +2645,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_bcol, sizeof(BorderCol) * std::max<size_t>(bcol.size(), 1));
     RSV(e->d_xtab, sizeof(XTab) * std::max<size_t>(xtab.size(), 1));
     RSV(e->d_ytab, sizeof(YTab) * std::max<size_t>(ytab.size(), 1));
+    RSV(e->d_yrow, sizeof(YRow) * std::max<size_t>(yrow.size(), 1));
     RSV(e->d_rstrip, sizeof(ResizeStrip) * std::max<size_t>(rstrip.size(), 1));
     RSV(e->d_rsel, sizeof(uint4) * std::max<size_t>(rsel.size(), 1));
     RSV(e->d_rwt, sizeof(uint4) * std::max<size_t>(rwt.size(), 1));
@@ -2648,6 +2671,7 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     if (!xtab.empty()) {
         ORBGPU_HIP_TRY(hipMemcpy(e->d_xtab.p, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice));
         ORBGPU_HIP_TRY(hipMemcpy(e->d_ytab.p, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpy(e->d_yrow.p, yrow.data(), sizeof(YRow) * yrow.size(), hipMemcpyHostToDevice));
         ORBGPU_HIP_TRY(hipMemcpy(e->d_rstrip.p, rstrip.data(), sizeof(ResizeStrip) * rstrip.size(), hipMemcpyHostToDevice));
         ORBGPU_HIP_TRY(hipMemcpy(e->d_rsel.p, rsel.data(), sizeof(uint4) * rsel.size(), hipMemcpyHostToDevice));
         ORBGPU_HIP_TRY(hipMemcpy(e->d_rwt.p, rwt.data(), sizeof(uint4) * rwt.size(), hipMemcpyHostToDevice));
@@ -2794,7 +2818,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                 auto kern = dir1 ? (rows == PYR_ROWS ? k_resize_fast<true, true> : k_resize_fast<false, true>)
                                  : (rows == PYR_ROWS ? k_resize_fast<true, false> : k_resize_fast<false, false>);
                 hipLaunchKernelGGL(kern, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l, e->d_rstrip.as<ResizeStrip>(),
-                                   e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(), e->d_ytab.as<YTab>(),
+                                   e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(), e->d_yrow.as<YRow>(),
                                    dir1 ? e->rs_off_direct : gl.rs_off, rows, s0);
             }
             else
@@ -2946,7 +2970,7 @@ int orbgpu_extractor_destroy(orbgpu_extractor *e)
         return ORBGPU_OK;
     (void)hipSetDevice(e->prm.device_id);
     (void)hipDeviceSynchronize();
-    DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_pattern, &e->d_rstrip, &e->d_rsel,
+    DevBuf *bufs[] = {&e->d_geom, &e->d_cells, &e->d_xtab, &e->d_ytab, &e->d_yrow, &e->d_pattern, &e->d_rstrip, &e->d_rsel,
                       &e->d_rwt, &e->d_ctab, &e->d_bcol, &e->d_pyr,
                       &e->d_blur, &e->d_slots, &e->d_cellcnt, &e->d_dkey, &e->d_dnode, &e->d_sel, &e->d_nsel,
                       &e->d_ncand, &e->d_aux, &e->d_in, &e->d_kps, &e->d_desc, &e->d_nout, &e->d_dbg, &e->d_qtaux};

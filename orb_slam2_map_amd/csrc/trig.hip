@@ -74,7 +74,7 @@ void build_host_table()
     std::vector<std::thread> th;
     // the low binades hold almost no exceptions and cost the same per value: interleave buckets over the threads in
     // chunks so that every thread gets a share of every binade
-    const uint32_t chunk = 64;
+    const uint32_t chunk = 512;  // buckets per work item (1 M floats)
     for (int t = 0; t < nt; t++)
         th.emplace_back([&, t] {
             Part &P = parts[(size_t)t];

@@ -29,7 +29,8 @@ namespace orbgpu {
 // kpt.angle is in [0, 360] (cv::fastAtan2), angle = kpt.angle * (float)(CV_PI / 180.f) <= 6.2831855f; the table covers
 // a little more
 constexpr float ORBGPU_TRIG_MAX = 6.2832f;
-constexpr int ORBGPU_TRIG_BUCKET_SHIFT = 14;  // 16384 consecutive floats per bucket of the exception table
+constexpr int ORBGPU_TRIG_BUCKET_SHIFT = 11;  // 2048 consecutive floats per bucket of the exception table: 0.53 M buckets (2.1 MB, L2-resident);
+                                               // ~50 keys per bucket where angles fall (the top binades), so a search touches <= 4 cache lines
 
 // x in [0, 6.3]: cos and sin with an error of a few 1e-17 (Cody-Waite reduction by pi/2 in two pieces, Taylor series
 // to r^18 / r^17 on |r| <= pi/4), rounded to float.  Every operation is a single IEEE double operation.
@@ -80,26 +81,28 @@ struct TrigTable {
 };
 
 // cos / sin of `angle` (radians) as the table's host computes cosf / sinf: the base value unless the table lists the
-// argument (two dependent loads for the bucket bounds + a binary search over ~20 keys)
+// argument (one load for the bucket bounds, issued before the double-precision evaluation, then a binary search)
 __device__ __forceinline__ void orbgpu_trig_device(float angle, const TrigTable &tt, float *c, float *s)
 {
-    orbgpu_sincos_base(angle, c, s);
     const uint32_t u = __float_as_uint(angle), b = u >> ORBGPU_TRIG_BUCKET_SHIFT;
+    uint32_t lo = 0, end = 0;
     if (b < tt.nbuckets) {
-        const uint32_t end = tt.bucket[b + 1];
-        uint32_t lo = tt.bucket[b], hi = end;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (tt.key[mid] < u)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        if (lo < end && tt.key[lo] == u) {
-            const float2 v = tt.val[lo];
-            *c = v.x;
-            *s = v.y;
-        }
+        lo = tt.bucket[b];
+        end = tt.bucket[b + 1];
+    }
+    orbgpu_sincos_base(angle, c, s);
+    uint32_t hi = end;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tt.key[mid] < u)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo < end && tt.key[lo] == u) {
+        const float2 v = tt.val[lo];
+        *c = v.x;
+        *s = v.y;
     }
 }
 #endif
