@@ -466,7 +466,7 @@ int orbgpu_search_by_projection(const orbgpu_frame_view *f, const orbgpu_mappoin
 typedef struct orbgpu_mappoint_table orbgpu_mappoint_table;
 int orbgpu_mappoint_table_create(int32_t device_id, int32_t initial_rows, orbgpu_mappoint_table **out);
 int orbgpu_mappoint_table_destroy(orbgpu_mappoint_table *t);
-/* Distinct ids ever inserted (rows are never recycled: a bad point keeps its row, flagged). */
+/* Rows in use: distinct ids inserted since creation or since the last orbgpu_mappoint_table_retain. */
 int orbgpu_mappoint_table_rows(const orbgpu_mappoint_table *t, int32_t *rows);
 /* Inserts or updates n points (ids distinct within a call, >= 0; host arrays).  An attribute array may be NULL: known
  * ids keep that attribute, new ids get zeros (n_obs NULL: a new point counts as observed).  world_pos / normal
@@ -481,6 +481,12 @@ int orbgpu_mappoint_table_set_observations(orbgpu_mappoint_table *t, int32_t n, 
 /* Ids of the most recent orbgpu_search_local_points_table / orbgpu_search_by_projection_last_table call that the table
  * had never been told about: list rows (skipped) and key-point associations (treated as held).  Either may be NULL. */
 int orbgpu_mappoint_table_last_unknown(const orbgpu_mappoint_table *t, int32_t *list_ids, int32_t *kp_ids);
+/* Rows are not recycled by the edits above (a bad point keeps its row, flagged), like the reference, which never frees a
+ * MapPoint (Map.cc:76-83, "This only erase the pointer").  This call bounds the table: only the listed ids stay -- typically
+ * Map::GetAllMapPoints() plus whatever the current and the last Frame still reference --, rows are renumbered densely in the
+ * order given, capacity shrinks to fit; *dropped (optional) = rows released.  Ids dropped here are "unknown" afterwards
+ * (skipped as list entries, held as key-point associations: orbgpu_search_local_points_table). */
+int orbgpu_mappoint_table_retain(orbgpu_mappoint_table *t, int32_t n, const int64_t *ids, int32_t *dropped);
 /* One row back to the host (tests, debugging); any output may be NULL. */
 int orbgpu_mappoint_table_read(orbgpu_mappoint_table *t, int64_t id, float *world_pos, float *normal, float *min_dist,
                                float *max_dist, uint8_t *desc, int32_t *has_observations, int32_t *bad);

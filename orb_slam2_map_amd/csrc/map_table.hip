@@ -116,6 +116,28 @@ __global__ __launch_bounds__(256) void k_table_flag(int n, const int32_t *__rest
         bad[row[i]] = 1;
 }
 
+// orbgpu_mappoint_table_retain: row src[i] of the old arrays becomes row i of the new ones
+__global__ __launch_bounds__(256) void k_table_compact(int n, const int32_t *__restrict__ src, TableDev o, TableDev d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const int r = src[i];
+    for (int c = 0; c < 3; c++) {
+        d.world_pos[3 * i + c] = o.world_pos[3 * r + c];
+        d.normal[3 * i + c] = o.normal[3 * r + c];
+    }
+    d.min_dist[i] = o.min_dist[r];
+    d.max_dist[i] = o.max_dist[r];
+    const uint4 *sd = reinterpret_cast<const uint4 *>(o.desc + (size_t)r * 32);
+    uint4 *dd = reinterpret_cast<uint4 *>(d.desc + (size_t)i * 32);
+    dd[0] = sd[0];
+    dd[1] = sd[1];
+    d.bad[i] = o.bad[r];
+    d.obs[i] = o.obs[r];
+    d.id[i] = o.id[r];
+}
+
 // The call's local map: thread i < m looks up ids[i] and copies the row into the call's arrays (what
 // orbgpu_device_mappoint_table / orbgpu_device_lastframe_view point at).  pos_of_row[row] = first list position of the
 // row (for the translation of the frame's existing associations); unknown ids are counted and skipped.
@@ -603,6 +625,106 @@ int orbgpu_mappoint_table_set_observations(orbgpu_mappoint_table *t, int32_t n, 
 {
     ORBGPU_REQUIRE(n == 0 || n_obs, "null observation counts");
     return table_flag(t, n, ids, n_obs, known);
+}
+
+int orbgpu_mappoint_table_retain(orbgpu_mappoint_table *t, int32_t n, const int64_t *ids, int32_t *dropped)
+{
+    ORBGPU_REQUIRE(t && n >= 0 && (n == 0 || ids) && n <= MT_MAX_CALL, "bad argument");
+    int rc = select_device(t->device_id);
+    if (rc != ORBGPU_OK)
+        return rc;
+    // the rows that stay, in the order given (an id listed twice or unknown is passed over)
+    std::vector<int32_t> src;
+    std::vector<int64_t> kept;
+    src.reserve((size_t)n);
+    kept.reserve((size_t)n);
+    t->call_no++;
+    for (int i = 0; i < n; i++) {
+        const int r = host_find(t, ids[i]);
+        if (r < 0 || t->stamp[(size_t)r] == t->call_no)
+            continue;
+        t->stamp[(size_t)r] = t->call_no;
+        src.push_back(r);
+        kept.push_back(ids[i]);
+    }
+    const int m = (int)src.size(), before = t->rows;
+    int ncap = 1024;
+    while (ncap < m)
+        ncap *= 2;
+    ORBGPU_HIP_TRY(hipStreamSynchronize(t->stream));
+    // new arrays first; the table is only switched over when everything has succeeded
+    DevBuf nb[8], nsrc;
+    const size_t elt[8] = {12, 12, 4, 4, 32, 1, 1, 8};
+    auto drop = [&] {
+        for (DevBuf &b : nb)
+            b.release();
+        nsrc.release();
+    };
+    for (int k = 0; k < 8; k++)
+        if ((rc = nb[k].reserve(elt[k] * (size_t)ncap)) != ORBGPU_OK) {
+            drop();
+            return rc;
+        }
+    if ((rc = nsrc.reserve(sizeof(int32_t) * (size_t)std::max(m, 1))) != ORBGPU_OK) {
+        drop();
+        return rc;
+    }
+    hipError_t he = hipSuccess;
+    for (int k = 0; k < 8 && he == hipSuccess; k++)
+        he = hipMemsetAsync(nb[k].p, 0, elt[k] * (size_t)ncap, t->stream);
+    if (he == hipSuccess && m > 0)
+        he = hipMemcpyAsync(nsrc.p, src.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, t->stream);
+    if (he == hipSuccess && m > 0) {
+        TableDev d{nb[0].as<float>(), nb[1].as<float>(), nb[2].as<float>(), nb[3].as<float>(),
+                   nb[4].as<uint8_t>(), nb[5].as<uint8_t>(), nb[6].as<uint8_t>(), nb[7].as<int64_t>()};
+        hipLaunchKernelGGL(k_table_compact, dim3((m + 255) / 256), dim3(256), 0, t->stream, m, nsrc.as<int32_t>(), t->dev(), d);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess)
+        he = hipStreamSynchronize(t->stream);
+    // the id -> row hash of the kept ids, host and device
+    int l2 = 1;
+    while ((1 << l2) < 2 * ncap)
+        l2++;
+    IdHash nh;
+    nh.rebuild(l2);
+    for (int i = 0; i < m; i++)
+        nh.insert(kept[(size_t)i], i);
+    DevBuf nk, nv;
+    if (he == hipSuccess && ((rc = nk.reserve(sizeof(int64_t) << l2)) != ORBGPU_OK || (rc = nv.reserve(sizeof(int32_t) << l2)) != ORBGPU_OK ||
+                             (rc = t->pos_of_row.reserve(sizeof(int32_t) * (size_t)ncap)) != ORBGPU_OK)) {
+        nk.release(), nv.release();
+        drop();
+        return rc;
+    }
+    if (he == hipSuccess)
+        he = hipMemcpyAsync(nk.p, nh.keys.data(), sizeof(int64_t) << l2, hipMemcpyHostToDevice, t->stream);
+    if (he == hipSuccess)
+        he = hipMemcpyAsync(nv.p, nh.vals.data(), sizeof(int32_t) << l2, hipMemcpyHostToDevice, t->stream);
+    if (he == hipSuccess)
+        he = hipStreamSynchronize(t->stream);
+    if (he != hipSuccess) {
+        set_error("MapPoint table retain: %s", hipGetErrorString(he));
+        nk.release(), nv.release();
+        drop();
+        return ORBGPU_EHIP;
+    }
+    DevBuf *cur[8] = {&t->world_pos, &t->normal, &t->min_dist, &t->max_dist, &t->desc, &t->bad, &t->obs, &t->id};
+    for (int k = 0; k < 8; k++) {
+        cur[k]->release();
+        *cur[k] = nb[k];
+    }
+    nsrc.release();
+    t->d_hkeys.release(), t->d_hvals.release();
+    t->d_hkeys = nk, t->d_hvals = nv;
+    t->hash = nh;
+    t->rows = m;
+    t->cap = ncap;
+    t->stamp.assign((size_t)ncap, 0);
+    t->call_no = 0;
+    if (dropped)
+        *dropped = before - m;
+    return ORBGPU_OK;
 }
 
 int orbgpu_mappoint_table_read(orbgpu_mappoint_table *t, int64_t id, float *world_pos, float *normal, float *min_dist,

@@ -123,7 +123,7 @@ ABI_SYMBOLS = [
     "orbgpu_search_by_projection", "orbgpu_search_by_projection_last", "orbgpu_search_by_projection_keyframe",
     "orbgpu_mappoint_table_create", "orbgpu_mappoint_table_destroy", "orbgpu_mappoint_table_rows",
     "orbgpu_mappoint_table_upsert", "orbgpu_mappoint_table_set_bad", "orbgpu_mappoint_table_set_observations",
-    "orbgpu_mappoint_table_read", "orbgpu_mappoint_table_last_unknown", "orbgpu_frame_create", "orbgpu_frame_destroy", "orbgpu_frame_upload",
+    "orbgpu_mappoint_table_read", "orbgpu_mappoint_table_last_unknown", "orbgpu_mappoint_table_retain", "orbgpu_frame_create", "orbgpu_frame_destroy", "orbgpu_frame_upload",
     "orbgpu_frame_device_view", "orbgpu_search_local_points_table", "orbgpu_search_by_projection_last_table",
     "orbgpu_vocabulary_create", "orbgpu_vocabulary_destroy", "orbgpu_vocabulary_size", "orbgpu_bow_transform",
     "orbgpu_bow_transform_batch_device", "orbgpu_search_by_bow", "orbgpu_search_by_bow_batch_device",
@@ -626,6 +626,14 @@ class MapPointTable:
         self.L.orbgpu_mappoint_table_set_observations.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         check(self.L.orbgpu_mappoint_table_set_observations(self.h, len(ids), _p(ids), _p(n_obs), C.byref(k)))
         return k.value
+
+    def retain(self, ids):
+        """Keeps only the listed ids (rows renumbered densely, capacity shrunk); returns the number of rows released."""
+        ids = np.ascontiguousarray(ids, np.int64)
+        d = C.c_int32()
+        self.L.orbgpu_mappoint_table_retain.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        check(self.L.orbgpu_mappoint_table_retain(self.h, len(ids), _p(ids), C.byref(d)))
+        return d.value
 
     def last_unknown(self):
         """(list ids, key-point ids) of the last search call over the table that the table did not know."""

@@ -417,6 +417,18 @@ template <typename MapPointT> class MapPointTableT {
             ids_[i] = (int64_t)pts[i]->mnId;
         check(orbgpu_mappoint_table_set_bad(h_, (int32_t)ids_.size(), ids_.data(), nullptr), "SetBad (batch)");
     }
+    // Bounds the table: only the listed points stay (Map::GetAllMapPoints() + what the current / last Frame still hold);
+    // returns the number of rows released.  The reference never frees a MapPoint; its table equivalent is this call.
+    int Retain(const std::vector<MapPointT *> &pts)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        ids_.resize(pts.size());
+        for (size_t i = 0; i < pts.size(); i++)
+            ids_[i] = (int64_t)pts[i]->mnId;
+        int32_t dropped = 0;
+        check(orbgpu_mappoint_table_retain(h_, (int32_t)ids_.size(), ids_.data(), &dropped), "Retain");
+        return dropped;
+    }
     // ids of the last table search that the table had not been told about yet (skipped rows, held key points)
     std::pair<int, int> LastUnknown() const
     {

@@ -62,6 +62,27 @@ def test_table_rows_survive_growth_and_edits(gpu):
     assert t.rows() == n + 2 and np.array_equal(t.read(555)["world_pos"], np.ones(3, np.float32))
     with pytest.raises(RuntimeError, match="negative"):
         t.upsert(np.array([-4], np.int64))
+    # retain: the table is bounded by the live map -- only the listed ids stay (shuffled; an unknown id and a repeated one
+    # are passed over), rows are renumbered, attributes and flags travel with their id, dropped ids are unknown afterwards
+    keep = rng.permutation(n)[:1800]
+    listed = np.concatenate([ids[keep], [987654321], ids[keep[:3]]]).astype(np.int64)
+    assert t.retain(listed) == (n + 2) - 1800 and t.rows() == 1800
+    for i in keep[[0, 1, 900, 1799]]:
+        r = t.read(ids[i])
+        want_wp = wp[i] + 1 if i in (3, 1500, 4000) else wp[i]
+        assert np.array_equal(r["world_pos"], want_wp) and np.array_equal(r["normal"], nr[i]) and r["min_dist"] == mn[i]
+        assert r["bad"] == int(i in (7, 8))
+    gone = np.setdiff1d(np.arange(n), keep)[:5]
+    for i in gone:
+        with pytest.raises(RuntimeError, match="not in the table"):
+            t.read(ids[i])
+    assert t.set_bad(ids[gone]) == 0
+    # the shrunk table grows again, a dropped id may come back as a new point
+    back = ids[gone[:2]]
+    t.upsert(np.concatenate([back, np.arange(2_000_000, 2_003_000)]).astype(np.int64),
+             world_pos=np.full((3002, 3), 7, np.float32))
+    assert t.rows() == 1800 + 3002 and np.array_equal(t.read(back[0])["world_pos"], np.full(3, 7, np.float32))
+    assert np.array_equal(t.read(ids[keep[5]])["desc"], ds[keep[5]] if keep[5] not in (3, 1500) else 255 - ds[keep[5]])
 
 
 def local_map_scenario(gpu, oracle, w, h, nfeat, nprev, obs_zero, seed):
@@ -180,6 +201,12 @@ def test_search_local_points_over_the_table(gpu, oracle, w, h, nfeat, nprev, th,
     want6[pre[:100]] = np.where(mp["obs_pos"][k0[pre[:100]]] != 0, -2, -1)  # list points are outside an empty list
     want6[pre[100:200]] = -2
     assert n6 == 0 and np.array_equal(k6, want6)
+    # (g) after a retain() of exactly the listed + held points (shuffled order -> every row number changes) the search
+    #     gives the same result
+    live = np.concatenate([ids, ids_all[m:]])
+    assert tbl.retain(rng.permutation(live)) == 0
+    n7, k7 = gpu.search_local_points_table(dfr, tbl, ids, Tcw, fx, fy, cx, cy, bf, log_sf, th, 0.8, kp_ids=kp_ids)
+    assert n7 == no and np.array_equal(k7, want)
     # the table path and the host-pointer entry point agree as well
     n5, k5 = gpu.ORBmatcher(0.8, True).SearchByProjection(make_gframe(gpu, of), mp, th, k0)
     assert n5 == no and np.array_equal(k5, want)
