@@ -1705,24 +1705,37 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     const int v = hl - HALF_PATCH;         // rows -15..15 (lane 31 idles)
     int m10 = 0, m01 = 0;
     {
-        // the disc's 31 rows x 48 bytes staged in LDS as 93 16-byte pieces, lane = (row, piece): a wave-load then touches
-        // ~21 rows instead of 62 (the 12 bytes past the 36 a row needs are inside the padded row)
+        // The disc's 31 rows staged in LDS as 16-byte pieces of the 48-byte window that starts at the aligned column
+        // xl - a.  A row of half width u needs the window's bytes 15 - u + a .. 15 + u + a: the first two
+        // pieces always, the third only where u + a >= 17 -- 62 to 75 of the 93 pieces (the weights of the bytes that are
+        // not loaded are zero, so what LDS holds there does not matter).  Until round 4 all 93 were loaded.
         const uint8_t *base = (dir0 ? s0.p + (size_t)f * s0.frame_stride : pyr + (size_t)f * frame_pyr + g.plane_off) + (xl - a);
         struct __attribute__((packed, aligned(4))) Piece {
             uint32_t d[4];
         };
+        // lane = (row, piece) for the 62 pieces every disc needs: two neighbouring lanes share a row, so a wave-load touches
+        // ~16 rows per key point; then the rows around the centre whose third piece is needed: |v| <= lim
+        const int lim = a == 2 ? 3 : (a == 3 ? 6 : -1);  // umax[|v|] + a >= 17 (umax: ORBextractor.cc:452-469, host-checked)
+        const uint8_t *rowbase = base + rowoff(y + porg - HALF_PATCH, ppitch);
+        uint4 *pl = reinterpret_cast<uint4 *>(stage[threadIdx.x >> 5]);
         Piece pc[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int q = hl + 32 * k, r = (q * 171) >> 9, part = q - 3 * r;
-            if (q < 93)
-                pc[k] = *reinterpret_cast<const Piece *>(base + rowoff(y + porg - HALF_PATCH + r, ppitch) + part * 16);
+        for (int k = 0; k < 2; k++) {
+            const int q = hl + 32 * k, r = q >> 1, part = q & 1;
+            if (q < 62)
+                pc[k] = *reinterpret_cast<const Piece *>(rowbase + rowoff(r, ppitch) + part * 16);
         }
-        uint4 *pl = reinterpret_cast<uint4 *>(stage[threadIdx.x >> 5]);
+        const int r2 = HALF_PATCH - lim + hl;
+        if (hl < 2 * lim + 1)
+            pc[2] = *reinterpret_cast<const Piece *>(rowbase + rowoff(r2, ppitch) + 32);
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-            if (hl + 32 * k < 93)
-                pl[hl + 32 * k] = make_uint4(pc[k].d[0], pc[k].d[1], pc[k].d[2], pc[k].d[3]);
+        for (int k = 0; k < 2; k++) {
+            const int q = hl + 32 * k;
+            if (q < 62)
+                pl[3 * (q >> 1) + (q & 1)] = make_uint4(pc[k].d[0], pc[k].d[1], pc[k].d[2], pc[k].d[3]);
+        }
+        if (hl < 2 * lim + 1)
+            pl[3 * r2 + 2] = make_uint4(pc[2].d[0], pc[2].d[1], pc[2].d[2], pc[2].d[3]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2204,6 +2217,7 @@ struct orbgpu_extractor {
     // direct mode (Src0): level 0 read from the caller's image, no padded copy
     bool direct0_ok = false;       // the configured geometry has the tables for it (width % 8 == 0, >= 2 levels on the fast resize path)
     bool no_early_blur0 = false;   // ORBGPU_DEBUG_NO_EARLY_BLUR0: concurrent blur forks after the pyramid for level 0 too (A/B)
+    int direct0_min_batch = 8;     // frames per call from which direct mode is used (ORBGPU_DEBUG_DIRECT0_MIN)
     bool no_direct0 = false;       // ORBGPU_DEBUG_NO_DIRECT0 (read at creation): always make the padded copy (tests, A/B)
     int rs_off_direct = 0;         // level 1's strip tables for the unpadded source
     DetectGeom det_geom_direct;    // k_fast_detect's strips with level 0 aligned to the image
@@ -2254,6 +2268,11 @@ static void build_tables(orbgpu_extractor *e)
         um[v] = v0;
         ++v0;
     }
+    // k_orient's "third piece" rule is written for these values (half widths 15 up to |v| = 3, >= 14 up to |v| = 6)
+    static const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    for (int v = 0; v <= HALF_PATCH; v++)
+        if (um[v] != expect[v])
+            abort();
 }
 
 static inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
@@ -2785,7 +2804,10 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     }
     // direct mode: aligned rows, and strides the 24-bit row-offset multiplies cover (checked by the callers: stride < 2^24)
     const bool aligned4 = stride % 4 == 0 && frame_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(d_gray) & 3) == 0;
-    const bool direct = e->direct0_ok && !e->no_direct0 && aligned4;
+    // ... and a batch: for a handful of frames the kernels are latency-bound, the traffic direct mode saves is served from
+    // L2 anyway, and its second blur launch costs more (0.030 against 0.016 ms for one 640x480 frame) than the border kernel
+    // it removes (0.036 against 0.039 ms); ORBGPU_DEBUG_DIRECT0_MIN overrides the threshold (tests run batch 1 - 3 in direct mode)
+    const bool direct = e->direct0_ok && !e->no_direct0 && aligned4 && batch >= e->direct0_min_batch;
     const Src0 s0{d_gray, frame_stride, (uint32_t)stride, direct ? 1 : 0};
     e->last_src = s0;
     e->level0_materialized = !direct;
@@ -2942,6 +2964,8 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
         e->qt_keys_hook = std::max(atoi(q), 0);
     e->no_direct0 = getenv("ORBGPU_DEBUG_NO_DIRECT0") != nullptr;
     e->no_early_blur0 = getenv("ORBGPU_DEBUG_NO_EARLY_BLUR0") != nullptr;
+    if (const char *q = getenv("ORBGPU_DEBUG_DIRECT0_MIN"))
+        e->direct0_min_batch = std::max(atoi(q), 1);
     if (const char *q = getenv("ORBGPU_FAST_EARLY_OUT"))  // default of the option for handles created from now on (fuzzing, A/B)
         e->fast_early_out = atoi(q) != 0;
     if (const char *q = getenv("ORBGPU_DEBUG_FAST_QUEUE"))  // test hook: forces k_fast_detect's queue-full path

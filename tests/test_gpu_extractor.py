@@ -9,14 +9,16 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("x", "y", "size", "angle", "response", "octave", "class_id")
 
 
-@pytest.fixture(autouse=True, params=["default", "fast_early_out", "padded_level0"])
+@pytest.fixture(autouse=True, params=["default", "direct_any_batch", "fast_early_out", "padded_level0"])
 def fast_stage_variant(request, monkeypatch):
-    """Every test of this module runs three times: as shipped (level 0 read straight from the caller's image where the
-    input is aligned -- direct mode --, the round-3 FAST kernel), with the FAST kernel's exact wave-level early-out
-    (k_fast_detect<true>), and with direct mode off (level 0 always copied into a padded plane, the round-3 data path).
-    The environment variables are read when a handle is created."""
-    monkeypatch.delenv("ORBGPU_FAST_EARLY_OUT", raising=False)
-    monkeypatch.delenv("ORBGPU_DEBUG_NO_DIRECT0", raising=False)
+    """Every test of this module runs four times: as shipped (level 0 read straight from the caller's image -- direct mode
+    -- for aligned batches of 8 frames or more, the round-3 FAST kernel), with direct mode for any batch size, with the
+    FAST kernel's exact wave-level early-out on top of that (k_fast_detect<true>), and with direct mode off (level 0
+    always copied into a padded plane, the round-3 data path).  The environment variables are read when a handle is created."""
+    for v in ("ORBGPU_FAST_EARLY_OUT", "ORBGPU_DEBUG_NO_DIRECT0", "ORBGPU_DEBUG_DIRECT0_MIN"):
+        monkeypatch.delenv(v, raising=False)
+    if request.param in ("direct_any_batch", "fast_early_out"):
+        monkeypatch.setenv("ORBGPU_DEBUG_DIRECT0_MIN", "1")
     if request.param == "fast_early_out":
         monkeypatch.setenv("ORBGPU_FAST_EARLY_OUT", "1")
     elif request.param == "padded_level0":
@@ -59,7 +61,7 @@ def check_stages(gpu, ge, oe, frame, nlevels, what):
             what, l, len(gs), len(os_))
 
 
-@pytest.mark.parametrize("w,h,nfeat,batch", [(640, 480, 1000, 3), (1280, 960, 2000, 2)])
+@pytest.mark.parametrize("w,h,nfeat,batch", [(640, 480, 1000, 3), (1280, 960, 2000, 2), (640, 480, 1000, 9)])
 def test_extract_matches_oracle_stage_by_stage(gpu, oracle, w, h, nfeat, batch):
     """C2 / C3 configurations (BASELINE.json configs[1], configs[2]) on the seeded synthetic stream."""
     from orb_slam2_map_amd.synth import Stream
@@ -450,11 +452,12 @@ def test_fast_early_out_on_images_with_flat_regions(gpu, oracle, w, h, nfeat, fl
     assert len(gk[0]) > nfeat // 4  # the textured part still fills most of the quota
 
 
-def test_direct_mode_level0_is_materialised_on_demand(gpu, oracle, stream640):
+def test_direct_mode_level0_is_materialised_on_demand(gpu, oracle, stream640, monkeypatch):
     """Device-resident, aligned input: no stage writes level 0 of the padded pyramid (the kernels read the image); the
     getters of mvImagePyramid[0] and of the padded debug view produce it when asked, from the image of the last call.
     Strides that are multiples of 4 but not of 64, and a stride > width, stay on the direct path."""
     import torch
+    monkeypatch.setenv("ORBGPU_DEBUG_DIRECT0_MIN", "1")  # (two frames: below the shipped threshold of 8)
     g0, g1 = stream640.frame(21)[0], stream640.frame(22)[0]
     oe = oracle.Extractor(1000)
     for stride in (640, 644, 704):
