@@ -52,6 +52,13 @@ __device__ __forceinline__ void xcd_frame_block(int &bx, int &frame)
     frame = (int)(v / gx);
     bx = (int)(v - (unsigned)frame * gx);
 }
+// Serpentine frame order.  The stages of a batched extraction follow each other on one stream, each over all frames: by
+// the time stage k + 1 reaches a frame, the planes stage k read or wrote for it have long left the 256 MB Infinity Cache
+// (a 512-frame batch moves > 1 GB per stage) -- except the frames stage k touched LAST.  Kernels that call this walk
+// the frames in descending order, their neighbours in the chain in ascending order, so a stage starts on what is still
+// cached: blur (descending) -> FAST (ascending) -> orientation (descending).  Measured at 512 frames per launch:
+// k_orient 0.211 -> 0.201 ms, k_fast_detect 0.642 -> 0.634 ms.  Results never depend on the order.
+__device__ __forceinline__ int serpentine(int frame) { return (int)gridDim.y - 1 - frame; }
 #endif
 
 struct DevBuf {

@@ -1660,6 +1660,7 @@ __global__ __launch_bounds__(256) void k_orient(const uint8_t *__restrict__ pyr,
     const int hl = threadIdx.x & 31;  // lane inside the half wave = disc row index
     int bx, f;
     xcd_frame_block(bx, f);
+    f = serpentine(f);
     const int *ns = nsel + (size_t)f * nlevels;
     // `iters` slots per half wave: the weight tables above are built once per 8 * iters key points
     for (int it = 0; it < iters; it++) {
@@ -1864,6 +1865,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 {
     int bx, f;
     xcd_frame_block(bx, f);
+    f = serpentine(f);
     const int strip = strip0 + bx * 256 + threadIdx.x;  // strip0 = first strip of level 1 when level 0 is blurred by k_blur0_direct
     if (strip >= bg.first[bg.nlevels])
         return;
@@ -1951,6 +1953,7 @@ __global__ __launch_bounds__(256) void k_blur0_direct(Src0 s0, uint8_t *__restri
 {
     int bx, f;
     xcd_frame_block(bx, f);
+    f = serpentine(f);
     const LevelGeom g = geom[0];
     const int nsx = g.w >> 3;
     const int strip = bx * 256 + threadIdx.x;
