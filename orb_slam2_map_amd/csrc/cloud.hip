@@ -23,6 +23,7 @@
 // paths, so the per-voxel float sums are reproducible.  HBM-bound integer/float streaming; no MFMA.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include <algorithm>
@@ -65,7 +66,10 @@ __device__ __forceinline__ void lb_publish(unsigned long long *slot, unsigned ep
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// exclusive prefix of channel `chan` over tiles [0, tile); `stride` = channels per tile
+// exclusive prefix of channel `chan` over tiles [0, tile); `stride` = channels per tile.
+// (Requesting 16 or 32 predecessors' words at a time, with or without re-requesting the whole batch while one is
+// missing, measured the same 3 - 3.4 us for the last of 34 tiles as this word-by-word walk: an agent-scope load is served
+// from memory, not from the XCD's L2, and one publish -> read hop across XCDs is ~1.5 us whatever is batched around it.)
 __device__ __forceinline__ unsigned lb_exclusive(unsigned long long *status, int stride, int chan, int tile,
                                                  unsigned epoch)
 {
@@ -84,26 +88,72 @@ __device__ __forceinline__ unsigned lb_exclusive(unsigned long long *status, int
     }
     return sum;
 }
+__device__ __forceinline__ bool lb_valid(unsigned long long w, unsigned epoch)
+{
+    return (unsigned)(w >> 32) == epoch && (w & LB_FLAGS) != 0ull;
+}
 
-// one-channel convenience for a whole workgroup: thread 0 publishes / looks back, everybody gets the base
+// one-channel convenience for a whole workgroup: wave 0 publishes / looks back (lane l reads the word of tile
+// tile-1-l, 64 predecessors per round trip), everybody gets the base
 __device__ __forceinline__ unsigned lb_tile_base(unsigned long long *status, int tile, unsigned epoch, unsigned agg,
                                                  unsigned *s_slot)
 {
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
         unsigned base = 0;
         if (tile > 0) {
-            lb_publish(status + tile, epoch, LB_AGG, agg);
-            base = lb_exclusive(status, 1, 0, tile, epoch);
+            if (lane == 0)
+                lb_publish(status + tile, epoch, LB_AGG, agg);
+            for (int t0 = tile - 1; t0 >= 0;) {
+                const int t = t0 - lane;
+                unsigned long long w = 0ull;
+                if (t >= 0)
+                    w = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = t < 0 || lb_valid(w, epoch);
+                const bool last = t < 0 || (ok && (w & LB_PREFIX) != 0ull);  // nothing below this lane is needed
+                const unsigned long long okm = __ballot(ok), lastm = __ballot(last);
+                const int L = lastm ? (int)__builtin_ctzll(lastm) : 63;      // lanes 0..L are wanted
+                const unsigned long long want = L == 63 ? ~0ull : ((2ull << L) - 1ull);
+                if ((okm & want) != want) {  // a wanted word is not published yet
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                base += (unsigned)wave_reduce_add((lane <= L && t >= 0) ? (int)(w & 0x3FFFFFFFull) : 0);
+                if (lastm)
+                    break;
+                t0 -= 64;
+            }
+            base = (unsigned)__shfl((int)base, 0, 64);
         }
-        lb_publish(status + tile, epoch, LB_PREFIX, base + agg);
-        *s_slot = base;
+        if (lane == 0) {
+            lb_publish(status + tile, epoch, LB_PREFIX, base + agg);
+            *s_slot = base;
+        }
     }
     __syncthreads();
     return *s_slot;
 }
 
+// Tile ids.  A launch of at most LB_STATIC_GRID workgroups uses blockIdx.x and no ticket: every one of its workgroups
+// gets a slot on the device whatever the others do (256 CUs, several such workgroups each; kernels of other streams
+// drain on their own), so a workgroup that spins on a lower tile always sees it arrive.  Larger launches take tickets,
+// which makes the wait safe when only part of the grid is resident.  (The two agent-scope atomics -- ticket and
+// "finished" -- were 1.3 of the 7.7 us of a radix pass over 34 tiles.)
+constexpr unsigned LB_STATIC_GRID = 256;
+__device__ __forceinline__ int lb_take_tile(LbCtl *ctl, int *s_tile)
+{
+    if (gridDim.x <= LB_STATIC_GRID)
+        return (int)blockIdx.x;
+    if (threadIdx.x == 0)
+        *s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return *s_tile;
+}
+
 __device__ __forceinline__ void lb_leave(LbCtl *ctl)
 {
+    if (gridDim.x <= LB_STATIC_GRID)
+        return;
     __syncthreads();
     if (threadIdx.x == 0) {
         // every workgroup has taken its ticket before it gets here; the stores below become visible to the next
@@ -116,6 +166,8 @@ __device__ __forceinline__ void lb_leave(LbCtl *ctl)
 }
 
 constexpr int TILE = 1024;  // elements per workgroup (256 threads x 4), order inside a tile: (round, wave, lane)
+constexpr int MERGE_TABLE = 4096;  // sampled indices of the resident map (k_vox_keys -> k_merge_new)
+static inline long long tiles_of_ll(long long n) { return (n + TILE - 1) / TILE; }
 
 // ------------------------------------------------------------------------------------------
 // bounding boxes (order-preserving encodings of float min / max) and PCL's voxel index
@@ -198,6 +250,41 @@ __device__ __forceinline__ void box_atomic(unsigned *box6, const Box &b)  // box
         if (b.mx[a] > __hip_atomic_load(&box6[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&box6[3 + a], b.mx[a]);
     }
+}
+
+// The bounding box of a map under construction: BOX_SLOTS copies of the six words, one cache line apart.  A workgroup
+// folds its box into slot blockIdx.x % BOX_SLOTS with six atomics it does not wait for; the consumer (the next insert's
+// k_vox_keys) folds the slots.  Until round 4 every workgroup first LOOKED at the six shared words (to skip atomics that
+// would not extend the box): six dependent agent-scope loads, ~1.5 us each, at the tail of every workgroup of the merge
+// kernels -- 9 of k_merge_new's 35 us (s_memrealtime stamps).
+constexpr int BOX_SLOTS = 16, BOX_SLOT_WORDS = 32, BOX_WORDS = BOX_SLOTS * BOX_SLOT_WORDS;
+__device__ __forceinline__ void box_slots_init(unsigned *boxs)  // by one workgroup of 256 threads
+{
+    for (int i = threadIdx.x; i < BOX_WORDS; i += 256)
+        boxs[i] = (i & (BOX_SLOT_WORDS - 1)) < 3 ? 0xFFFFFFFFu : 0u;
+}
+__device__ __forceinline__ void box_slots_atomic(unsigned *boxs, const Box &b)
+{
+    if (!b.nfinite)
+        return;
+    unsigned *box6 = boxs + (blockIdx.x % BOX_SLOTS) * BOX_SLOT_WORDS;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        atomicMin(&box6[a], b.mn[a]);
+        atomicMax(&box6[3 + a], b.mx[a]);
+    }
+}
+__device__ __forceinline__ void box_slots_fold(const unsigned *boxs, Box &b)  // every thread reads all slots (L2 hits)
+{
+    for (int a = 0; a < 3; a++) {
+        b.mn[a] = 0xFFFFFFFFu;
+        b.mx[a] = 0u;
+    }
+    for (int sl = 0; sl < BOX_SLOTS; sl++)
+        for (int a = 0; a < 3; a++) {
+            b.mn[a] = min(b.mn[a], boxs[sl * BOX_SLOT_WORDS + a]);
+            b.mx[a] = max(b.mx[a], boxs[sl * BOX_SLOT_WORDS + 3 + a]);
+        }
 }
 
 // state of one filter call, device resident; the host reads it back when the call has been queued
@@ -291,10 +378,7 @@ __global__ __launch_bounds__(256) void k_bp(const float *__restrict__ depth, siz
     __shared__ int s_tile;
     __shared__ unsigned s_cnt[16], s_base;
     __shared__ Box s_box[4];
-    if (threadIdx.x == 0)
-        s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int tile = s_tile;
+    const int tile = lb_take_tile(ctl, &s_tile);
     const int gw = (w + 2) / 3, gh = (h + 2) / 3;
     const int ns = gw * gh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -302,8 +386,8 @@ __global__ __launch_bounds__(256) void k_bp(const float *__restrict__ depth, siz
         if (ghist)
             for (int i = threadIdx.x; i < 4 * 256; i += 256)
                 ghist[i] = 0u;
-        if (outbox && threadIdx.x < 6)
-            outbox[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+        if (outbox)
+            box_slots_init(outbox);
     }
     float d[4];
     bool ok[4];
@@ -335,14 +419,15 @@ __global__ __launch_bounds__(256) void k_bp(const float *__restrict__ depth, siz
             pre[s >> 2] = tot;
         tot += s_cnt[s];
     }
-    const unsigned base = lb_tile_base(status, tile, epoch, tot, &s_base);
+    // the points are formed before the look-back (their colour loads and the double transform do not need the base)
     Box bx;
     box_init(bx);
+    Point pt[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (!ok[k])
             continue;
-        Point p;
+        Point &p = pt[k];
         p.z = d[k];
         p.x = ((float)nn[k] - cx) * p.z / fx;  // :124-125, this exact operation order
         p.y = ((float)mm[k] - cy) * p.z / fy;
@@ -359,8 +444,12 @@ __global__ __launch_bounds__(256) void k_bp(const float *__restrict__ depth, siz
             p.z = oz;
         }
         box_add(bx, p);
-        out[base + pre[k] + rank[k]] = p;
     }
+    const unsigned base = lb_tile_base(status, tile, epoch, tot, &s_base);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (ok[k])
+            out[base + pre[k] + rank[k]] = pt[k];
     box_block_reduce(bx, s_box);
     if (threadIdx.x == 0) {
         part[tile] = bx;
@@ -382,8 +471,7 @@ __global__ __launch_bounds__(256) void k_vox_minmax(const Point *__restrict__ pt
     if (blockIdx.x == 0) {
         for (int i = threadIdx.x; i < 4 * 256; i += 256)
             ghist[i] = 0u;
-        if (threadIdx.x < 6)
-            outbox[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u;
+        box_slots_init(outbox);
         if (threadIdx.x == 0)
             st->n_sort = n;
     }
@@ -403,12 +491,13 @@ __global__ __launch_bounds__(256) void k_vox_keys(const Point *__restrict__ pts,
                                                   const Box *__restrict__ part, int nparts,
                                                   const unsigned *__restrict__ oldbox, float inv, CloudState *st,
                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                  unsigned *__restrict__ ghist)
+                                                  unsigned *__restrict__ ghist, const Point *__restrict__ old, int K,
+                                                  uint32_t *__restrict__ samp)
 {
     __shared__ Box s_box[4];
     __shared__ unsigned s_h[4 * 256];
     const int n = *n_dev;
-    if ((long long)blockIdx.x * TILE >= n && blockIdx.x != 0)
+    if ((long long)blockIdx.x * TILE >= n && blockIdx.x != 0 && !samp)
         return;
     Box bx;
     box_init(bx);
@@ -418,10 +507,7 @@ __global__ __launch_bounds__(256) void k_vox_keys(const Point *__restrict__ pts,
     int nf_sort = bx.nfinite;
     if (oldbox) {  // the resident map: all finite, its box is maintained exactly by the previous call
         Box ob;
-        for (int a = 0; a < 3; a++) {
-            ob.mn[a] = oldbox[a];
-            ob.mx[a] = oldbox[3 + a];
-        }
+        box_slots_fold(oldbox, ob);
         ob.nfinite = 1;
         box_merge(bx, ob);
     }
@@ -433,6 +519,16 @@ __global__ __launch_bounds__(256) void k_vox_keys(const Point *__restrict__ pts,
     }
     if (vs.overflow)
         return;
+    // merge path: the indices of MERGE_TABLE evenly spaced resident points (all of them if the map is smaller), the
+    // table k_merge_new brackets its tile with -- one scattered load per thread here, beside this kernel's own loads,
+    // instead of the same 1024 scattered loads at the head of every workgroup's chain there (4 us of its 35)
+    if (samp) {
+        const int np = min(K, MERGE_TABLE);
+        for (int s = blockIdx.x * 256 + threadIdx.x; s < np; s += gridDim.x * 256)
+            samp[s] = vox_key(old[K <= MERGE_TABLE ? s : (int)((long long)s * K / MERGE_TABLE)], inv, vs.min_b, vs.mul);
+        if ((long long)blockIdx.x * TILE >= n && blockIdx.x != 0)
+            return;
+    }
     for (int i = threadIdx.x; i < 4 * 256; i += 256)
         s_h[i] = 0u;
     __syncthreads();
@@ -478,10 +574,7 @@ __global__ __launch_bounds__(256) void k_sort_pass(const uint32_t *__restrict__ 
     __shared__ unsigned h[16 * 256];
     __shared__ unsigned s_scan[256];
     __shared__ int s_tile;
-    if (threadIdx.x == 0)
-        s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int tile = s_tile;
+    const int tile = lb_take_tile(ctl, &s_tile);
     const int n = st->n_sort;
     const int ntiles = (n + TILE - 1) / TILE;
     if (tile < ntiles && !st->overflow) {
@@ -668,10 +761,7 @@ __global__ __launch_bounds__(256) void k_vox_reduce(const Point *__restrict__ pt
     __shared__ int s_tile;
     __shared__ unsigned s_cnt[16], s_base;
     __shared__ Box s_box[4];
-    if (threadIdx.x == 0)
-        s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int tile = s_tile;
+    const int tile = lb_take_tile(ctl, &s_tile);
     const int ntiles = (n_in + TILE - 1) / TILE;
     if (st->overflow) {
 #pragma unroll
@@ -706,7 +796,7 @@ __global__ __launch_bounds__(256) void k_vox_reduce(const Point *__restrict__ pt
         }
         box_block_reduce(bx, s_box);
         if (threadIdx.x == 0) {
-            box_atomic(outbox, bx);
+            box_slots_atomic(outbox, bx);
             if (tile == ntiles - 1)
                 st->nout = (int)(base + tot);
         }
@@ -751,197 +841,180 @@ __device__ __forceinline__ int lds_count_le(const uint32_t *a, int n, uint32_t k
     return lo;
 }
 
-constexpr int MERGE_SAMPLES = 1024;
+constexpr int MN_TILE = 256;     // sorted new keys per workgroup (one per thread)
+constexpr int MN_CAP = 24576;    // resident indices a workgroup stages in LDS (96 KB)
+constexpr int MN_SAMPLES = 1024; // fall-back when a tile's range is longer than that: samples of the range
+constexpr int MN_LOADS = 32;     // 16-byte loads a thread has in flight while it stages a range (128 VGPRs; one wave per SIMD anyway)
 
 // new-point side: every run of equal keys among the sorted new points becomes one output voxel -- merged with the
 // resident map's point of that voxel if there is one (it comes first in PCL's input order), a new voxel otherwise.
 // cexcl[j] = new voxels opened by runs before j (look-back); a run's output position is its rank among the
 // resident points plus that count.
-// The rank (number of resident points with index <= key) is found without a 20-deep chain of dependent HBM loads:
-// 1024 evenly spaced resident indices go to LDS (one load per thread), the tile's first / last key bracket the
-// range every rank of the tile lies in, that range is sampled again (or, if it has <= 1024 points, read whole),
-// and only the last few levels are a per-thread search in global memory.
+//
+// The rank (number of resident points with index <= key) without a chain of dependent loads from memory -- inside a
+// kernel every one of those is a 1 - 1.5 us round trip, whichever cache level answers (measured with s_memrealtime
+// stamps; until round 4 this kernel had about twelve of them in a row and took 35 - 39 us):
+//   * `table` (k_vox_keys) holds the indices of 4096 evenly spaced resident points: one coalesced load to LDS;
+//   * the tile's first and last key, looked up there, bracket the range of resident points its ranks lie in: with
+//     256 keys per workgroup that is ~6 k points of a 700 k map;
+//   * the workgroup streams that whole range (coalesced 16-byte loads, many in flight), keeps the indices in LDS and
+//     ranks its keys there.  A range longer than MN_CAP (new points sparse against a dense map) is sampled a second time
+//     instead and the last levels are a search in global memory, as before.
 // Side job: tile_lb[b] = first sorted new key >= the index of resident point b*1024, which brackets the new keys
-// k_merge_old's workgroup b has to look at.
+// k_merge_old's workgroup b has to look at.  It is the work of the workgroups BEHIND the tiles of new points (the
+// launch adds merge_side_groups(K) of them): a 15-deep chain of its own that runs beside the tiles' chain.
 __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old, int K,
                                                    const Point *__restrict__ newp, const uint32_t *__restrict__ skeys,
                                                    const uint32_t *__restrict__ svals, float inv, CloudState *st,
+                                                   const uint32_t *__restrict__ table, int cap,
                                                    unsigned *__restrict__ cexcl, int *__restrict__ tile_lb,
                                                    Point *__restrict__ out, LbCtl *ctl, unsigned long long *status,
                                                    unsigned epoch, unsigned *__restrict__ outbox)
 {
+    extern __shared__ uint32_t s_old[];  // max(cap, MERGE_TABLE) indices
     __shared__ int s_tile, s_lo, s_hi;
-    __shared__ unsigned s_cnt[16], s_base;
+    __shared__ unsigned s_cnt[4], s_base;
     __shared__ Box s_box[4];
-    __shared__ uint32_t s_samp[MERGE_SAMPLES];
-    if (threadIdx.x == 0)
-        s_tile = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int tile = s_tile;
+    const int tile = lb_take_tile(ctl, &s_tile);
     const int nf = st->nfinite;
-    const int ntiles = max((nf + TILE - 1) / TILE, 1);
+    const int ntiles = max((nf + MN_TILE - 1) / MN_TILE, 1);
+    const bool overflow = st->overflow != 0;
     int min_b[3], mul[3];
     for (int a = 0; a < 3; a++) {
         min_b[a] = st->min_b[a];
         mul[a] = st->mul[a];
     }
-    if (tile < ntiles && !st->overflow) {
-        bool head[4], opens[4];
-        int rnk[4];
-        uint32_t key[4];
-        unsigned excl[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = tile * TILE + k * 256 + threadIdx.x;
-            head[k] = opens[k] = false;
-            rnk[k] = 0;
-            key[k] = 0;
-            if (j < nf) {
-                key[k] = skeys[j];
-                head[k] = j == 0 || skeys[j - 1] != key[k];
-            }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (tile < ntiles && !overflow) {
+        const int j = tile * MN_TILE + (int)threadIdx.x;
+        const int jlast = min(tile * MN_TILE + MN_TILE, nf) - 1;  // the tile's last element
+        uint32_t key = 0;
+        bool head = false, opens = false;
+        int rnk = 0;  // rank; negative: the run merges into resident point -rnk - 1
+        if (j < nf) {
+            key = skeys[j];
+            head = j == 0 || skeys[j - 1] != key;
         }
         if (K > 0 && nf > 0) {
-            // level A: samples over the whole resident map
-            const int npa = min(K, MERGE_SAMPLES);
-            for (int s = threadIdx.x; s < npa; s += 256) {
-                const int pos = K <= MERGE_SAMPLES ? s : (int)((long long)s * K / MERGE_SAMPLES);
-                s_samp[s] = vox_key(old[pos], inv, min_b, mul);
-            }
+            // level A: the table of the whole resident map
+            const int npa = min(K, MERGE_TABLE);
+            for (int s = threadIdx.x; s < npa; s += 256)
+                s_old[s] = table[s];
             __syncthreads();
-            if (threadIdx.x == 0) {
-                const int c = lds_count_le(s_samp, npa, skeys[tile * TILE]);
-                s_lo = c == 0 ? 0 : (K <= MERGE_SAMPLES ? c - 1 : (int)((long long)(c - 1) * K / MERGE_SAMPLES)) + 1;
+            if (threadIdx.x == 0) {  // (holds the tile's first key)
+                // the last table entry <= the first key STAYS in the range: it may be the resident point of that voxel
+                const int c = lds_count_le(s_old, npa, key);
+                s_lo = c == 0 ? 0 : (K <= MERGE_TABLE ? c - 1 : (int)((long long)(c - 1) * K / MERGE_TABLE));
             }
-            if (threadIdx.x == 64) {
-                const int c = lds_count_le(s_samp, npa, skeys[min(tile * TILE + TILE, nf) - 1]);
-                s_hi = c == npa ? K : (K <= MERGE_SAMPLES ? c : (int)((long long)c * K / MERGE_SAMPLES));
+            if (j == jlast) {  // the thread that holds the tile's last key
+                const int c = lds_count_le(s_old, npa, key);
+                s_hi = c == npa ? K : (K <= MERGE_TABLE ? c : (int)((long long)c * K / MERGE_TABLE));
             }
             __syncthreads();
             const int lo = s_lo, hi = max(s_hi, s_lo), len = hi - lo;
-            // level B: the tile's range, whole or sampled
-            const bool exact = len <= MERGE_SAMPLES;
-            const int npb = exact ? len : MERGE_SAMPLES;
-            for (int s = threadIdx.x; s < npb; s += 256) {
-                const int pos = exact ? lo + s : lo + (int)((long long)s * len / MERGE_SAMPLES);
-                s_samp[s] = vox_key(old[pos], inv, min_b, mul);
-            }
-            __syncthreads();
-            // the four runs of a thread are searched in lockstep so that their dependent probes overlap
-            int lo4[4], hi4[4];
-            bool ex4[4];
+            int r = 0;           // resident points with index <= key
+            bool exists = false;  // ... the last of them has this index
+            if (len <= cap) {
+                // the range itself: indices of old[lo, hi) to LDS
+                // (MN_LOADS requests per thread go out before the first index is formed: a round of them costs one memory
+                // latency, ~2.5 us here, however many there are -- 8 per round made a 6 k range 7.6 us)
+                for (int s0 = 0; s0 < len; s0 += 256 * MN_LOADS) {
+                    Point pt[MN_LOADS];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                lo4[k] = hi4[k] = 0;
-                ex4[k] = false;
-                if (!head[k])
-                    continue;
-                const int c = lds_count_le(s_samp, npb, key[k]);
-                if (exact) {
-                    lo4[k] = hi4[k] = lo + c;
-                    ex4[k] = c > 0 && s_samp[c - 1] == key[k];
-                } else {
-                    lo4[k] = c == 0 ? lo : lo + (int)((long long)(c - 1) * len / MERGE_SAMPLES) + 1;
-                    hi4[k] = max(lo4[k], c == npb ? hi : lo + (int)((long long)c * len / MERGE_SAMPLES));
-                }
-            }
-            for (;;) {  // first index in [lo, hi) whose key is > key (hi if none)
-                bool any = false;
-                int mid[4];
-                uint32_t km[4];
+                    for (int u = 0; u < MN_LOADS; u++) {
+                        const int sidx = s0 + u * 256 + (int)threadIdx.x;
+                        if (sidx < len)
+                            pt[u] = old[lo + sidx];
+                    }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    mid[k] = (lo4[k] + hi4[k]) >> 1;
-                    if (lo4[k] < hi4[k]) {
-                        km[k] = vox_key(old[mid[k]], inv, min_b, mul);
-                        any = true;
+                    for (int u = 0; u < MN_LOADS; u++) {
+                        const int sidx = s0 + u * 256 + (int)threadIdx.x;
+                        if (sidx < len)
+                            s_old[sidx] = vox_key(pt[u], inv, min_b, mul);
                     }
                 }
-                if (!any)
-                    break;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (lo4[k] < hi4[k]) {
-                        if (km[k] <= key[k])
-                            lo4[k] = mid[k] + 1;
+                __syncthreads();
+                if (head) {
+                    const int c = lds_count_le(s_old, len, key);
+                    r = lo + c;  // (every point below lo is smaller than the tile's first key)
+                    exists = c > 0 && s_old[c - 1] == key;
+                }
+            } else {
+                // a long range: MN_SAMPLES samples of it, then the last levels in global memory
+                for (int s = threadIdx.x; s < MN_SAMPLES; s += 256)
+                    s_old[s] = vox_key(old[lo + (int)((long long)s * len / MN_SAMPLES)], inv, min_b, mul);
+                __syncthreads();
+                if (head) {
+                    const int c = lds_count_le(s_old, MN_SAMPLES, key);
+                    int l = c == 0 ? lo : lo + (int)((long long)(c - 1) * len / MN_SAMPLES) + 1;
+                    int h = max(l, c == MN_SAMPLES ? hi : lo + (int)((long long)c * len / MN_SAMPLES));
+                    while (l < h) {  // first index in [l, h) whose key is > key (h if none)
+                        const int mid = (l + h) >> 1;
+                        if (vox_key(old[mid], inv, min_b, mul) <= key)
+                            l = mid + 1;
                         else
-                            hi4[k] = mid[k];
+                            h = mid;
                     }
+                    r = l;
+                    exists = l > 0 && vox_key(old[l - 1], inv, min_b, mul) == key;
                 }
             }
-            uint32_t kprev[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++)  // (exact with c == 0: the candidate is the point just below the staged range)
-                kprev[k] = (head[k] && !ex4[k] && lo4[k] > 0) ? vox_key(old[lo4[k] - 1], inv, min_b, mul) : 0xFFFFFFFEu;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (!head[k])
-                    continue;
-                const bool exists = ex4[k] || kprev[k] == key[k];
-                opens[k] = !exists;
-                rnk[k] = exists ? -lo4[k] : lo4[k];  // negative: merges into resident point r-1
+            if (head) {
+                opens = !exists;
+                rnk = exists ? -r : r;
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                opens[k] = head[k];
-        }
-        const unsigned tot = tile_flag_scan(opens, excl, s_cnt);
-        const unsigned base = lb_tile_base(status, tile, epoch, tot, &s_base);
+        } else
+            opens = head;
+        // value index, first new point, seed: nothing here depends on the look-back
         Box bx;
         box_init(bx);
-        Point first[4], seed[4];
-        uint32_t v0[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {  // three phases of independent loads: value index, first new point, seed
-            const int j = tile * TILE + k * 256 + threadIdx.x;
-            v0[k] = head[k] ? svals[j] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (head[k]) {
-                first[k] = newp[v0[k]];
-                if (rnk[k] < 0)
-                    seed[k] = old[-rnk[k] - 1];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = tile * TILE + k * 256 + threadIdx.x;
-            if (j < nf)
-                cexcl[j] = base + excl[k];
-            if (!head[k])
-                continue;
-            Point o;
-            int pos;
-            if (rnk[k] < 0) {
-                o = vox_centroid_from(first[k], newp, skeys, svals, j, nf, key[k], &seed[k]);
-                pos = (-rnk[k] - 1) + (int)(base + excl[k]);
-            } else {
-                o = vox_centroid_from(first[k], newp, skeys, svals, j, nf, key[k], nullptr);
-                pos = rnk[k] + (int)(base + excl[k]);
-            }
-            out[pos] = o;
+        Point o;
+        if (head) {
+            const Point first = newp[svals[j]];
+            Point seed;
+            if (rnk < 0)
+                seed = old[-rnk - 1];
+            o = vox_centroid_from(first, newp, skeys, svals, j, nf, key, rnk < 0 ? &seed : nullptr);
             box_add(bx, o);
         }
+        // new voxels opened before j: in the wave, in the tile, in the earlier tiles
+        const unsigned long long bal = __ballot(opens);
+        unsigned excl = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        unsigned tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w == wave)
+                excl += tot;
+            tot += s_cnt[w];
+        }
+        const unsigned base = lb_tile_base(status, tile, epoch, tot, &s_base);
+        if (j < nf)
+            cexcl[j] = base + excl;
+        if (head)
+            out[(rnk < 0 ? -rnk - 1 : rnk) + (int)(base + excl)] = o;
         box_block_reduce(bx, s_box);
         if (threadIdx.x == 0) {
-            box_atomic(outbox, bx);
+            box_slots_atomic(outbox, bx);
             if (tile == ntiles - 1) {
                 cexcl[nf] = base + tot;
                 st->nout = K + (int)(base + tot);
             }
         }
-    }
-    // side job, after this tile's prefix is published (off the look-back chain): the bracket of every map tile
-    // (an LDS-sampled variant of this search measured no faster: 37.8 vs 34.9 us for the kernel)
-    if (!st->overflow) {
-        const int ntk = (K + TILE - 1) / TILE;
-        for (int b = (int)threadIdx.x * (int)gridDim.x + tile; b < ntk; b += gridDim.x * 256)
+    } else if (!overflow) {
+        // side job (the workgroups behind the tiles): the bracket of every map tile
+        const int ntk = (K + TILE - 1) / TILE, nside = (int)gridDim.x - ntiles;
+        for (int b = (tile - ntiles) * 256 + (int)threadIdx.x; b < ntk; b += nside * 256)
             tile_lb[b] = key_lower_bound(skeys, 0, nf, vox_key(old[(size_t)b * TILE], inv, min_b, mul));
     }
     lb_leave(ctl);
 }
+
+// workgroups k_merge_new is launched with beyond the tiles of new points: one bracket search per thread up to 16 k map
+// tiles (a 16 M point map), more per thread beyond
+static inline int merge_side_groups(long long K) { return (int)std::min<long long>(std::max<long long>((tiles_of_ll(K) + 255) / 256, 1), 64); }
 
 constexpr int MERGE_OLD_LDS = 2048;
 
@@ -968,6 +1041,14 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
     }
     const int ntk = (K + TILE - 1) / TILE;
     const int i0 = blockIdx.x * TILE;
+    // the tile's points are requested first: their latency covers the bracket / staging chain below
+    Point p4[4] = {};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = i0 + k * 256 + threadIdx.x;
+        if (i < K)
+            p4[k] = old[i];
+    }
     const int lo = min(max(tile_lb[blockIdx.x], 0), nf);
     const int hi = min(max((int)blockIdx.x + 1 < ntk ? tile_lb[blockIdx.x + 1] : nf, lo), nf);
     const int len = hi - lo;
@@ -983,12 +1064,10 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int i = i0 + k * 256 + threadIdx.x;
-        Point p;
+        const Point p = p4[k];
         uint32_t key = 0;
-        if (i < K) {
-            p = old[i];
+        if (i < K)
             key = vox_key(p, inv, min_b, mul);
-        }
         uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
         if (i >= K)
             continue;
@@ -1015,7 +1094,7 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
         st->unsorted = 1;
     box_block_reduce(bx, s_box);
     if (threadIdx.x == 0)
-        box_atomic(outbox, bx);
+        box_slots_atomic(outbox, bx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1242,7 +1321,7 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float4 *__restrict__ sort
 // host side
 // ------------------------------------------------------------------------------------------
 struct VoxelWorkspace {
-    DevBuf keys[2], vals[2], status, part, cexcl, tile_lb, ctl, state, ghist;
+    DevBuf keys[2], vals[2], status, part, cexcl, tile_lb, ctl, state, ghist, table;
     unsigned epoch = 0;
     bool armed = false;
     int reserve(long long n_sort, int nparts)
@@ -1268,7 +1347,8 @@ struct VoxelWorkspace {
             return rc;
         if ((rc = cexcl.reserve(sizeof(unsigned) * (size_t)(n_sort + 1))) != ORBGPU_OK)
             return rc;
-        if ((rc = state.reserve(sizeof(CloudState))) != ORBGPU_OK || (rc = ghist.reserve(sizeof(unsigned) * 4 * 256)) != ORBGPU_OK)
+        if ((rc = state.reserve(sizeof(CloudState))) != ORBGPU_OK || (rc = ghist.reserve(sizeof(unsigned) * 4 * 256)) != ORBGPU_OK ||
+            (rc = table.reserve(sizeof(uint32_t) * MERGE_TABLE)) != ORBGPU_OK)
             return rc;
         if (!armed) {
             if ((rc = ctl.reserve(sizeof(LbCtl))) != ORBGPU_OK)
@@ -1293,7 +1373,7 @@ struct VoxelWorkspace {
             keys[k].release();
             vals[k].release();
         }
-        status.release(), part.release(), cexcl.release(), tile_lb.release(), ctl.release(), state.release(), ghist.release();
+        status.release(), part.release(), cexcl.release(), tile_lb.release(), ctl.release(), state.release(), ghist.release(), table.release();
         armed = false;
     }
 };
@@ -1315,7 +1395,7 @@ static void radix_sort_device(VoxelWorkspace &ws, int grid_tiles, hipStream_t st
 }
 
 // General path: in[0..n) -> out (capacity >= n): 7 launches.  The output count lands in ws.state->nout, the
-// bounding box of the output in outbox[6].
+// bounding box of the output in the slots of outbox (BOX_WORDS words).
 static int voxel_filter_device(VoxelWorkspace &ws, const Point *in, long long n, float leaf, Point *out,
                                unsigned *outbox, hipStream_t st)
 {
@@ -1335,7 +1415,7 @@ static int voxel_filter_device(VoxelWorkspace &ws, const Point *in, long long n,
                        outbox);
     hipLaunchKernelGGL(k_vox_keys, dim3(nt), dim3(256), 0, st, in, &S->n_sort, ws.part.as<Box>(), nb,
                        (const unsigned *)nullptr, inv, S, ws.keys[0].as<uint32_t>(), ws.vals[0].as<uint32_t>(),
-                       ws.ghist.as<unsigned>());
+                       ws.ghist.as<unsigned>(), (const Point *)nullptr, 0, (uint32_t *)nullptr);
     radix_sort_device(ws, nt, st);
     hipLaunchKernelGGL(k_vox_reduce, dim3(nt), dim3(256), 0, st, in, (int)n, ws.keys[0].as<uint32_t>(),
                        ws.vals[0].as<uint32_t>(), S, out, ws.ctl.as<LbCtl>(), ws.status.as<unsigned long long>(),
@@ -1645,6 +1725,7 @@ struct orbgpu_cloud {
     bool profiling = false;  // HIP events on the handle's stream around the kernels of an insert
     hipEvent_t ev[2] = {nullptr, nullptr};
     float last_ms = -1.f;
+    int merge_cap = 0;    // resident indices k_merge_new stages per workgroup (MN_CAP; ORBGPU_DEBUG_MERGE_CAP lowers it for tests)
 };
 
 namespace orbgpu {
@@ -1688,7 +1769,7 @@ static int cloud_filter(orbgpu_cloud *c, long long k)
     if (rc != ORBGPU_OK)
         return rc;
     rc = voxel_filter_device(c->ws, c->map[c->cur].as<Point>(), k, c->leaf, c->map[c->cur ^ 1].as<Point>(),
-                             c->box.as<unsigned>() + 6 * (c->cur ^ 1), c->stream);
+                             c->box.as<unsigned>() + BOX_WORDS * (c->cur ^ 1), c->stream);
     if (rc != ORBGPU_OK)
         return rc;
     CloudState hs;
@@ -1716,13 +1797,13 @@ static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dst
         return rc;
     if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK)
         return rc;
-    if ((rc = c->box.reserve(sizeof(unsigned) * 12)) != ORBGPU_OK ||
+    if ((rc = c->box.reserve(sizeof(unsigned) * 2 * BOX_WORDS)) != ORBGPU_OK ||
         (rc = c->ws.tile_lb.reserve(sizeof(int) * (size_t)(tiles_of(K) + 1) * 2)) != ORBGPU_OK)
         return rc;
     VoxelWorkspace &ws = c->ws;
     CloudState *S = ws.state.as<CloudState>();
     Point *old = c->map[c->cur].as<Point>(), *newp = old + K, *out = c->map[c->cur ^ 1].as<Point>();
-    unsigned *box_in = c->box.as<unsigned>() + 6 * c->cur, *box_out = c->box.as<unsigned>() + 6 * (c->cur ^ 1);
+    unsigned *box_in = c->box.as<unsigned>() + BOX_WORDS * c->cur, *box_out = c->box.as<unsigned>() + BOX_WORDS * (c->cur ^ 1);
     const float inv = 1.0f / c->leaf;
     const bool merge = K == 0 || c->sorted_map;
     c->last_ms = -1.f;
@@ -1737,11 +1818,14 @@ static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dst
         const int ntn = tiles_of(maxnew);
         hipLaunchKernelGGL(k_vox_keys, dim3(ntn), dim3(256), 0, c->stream, newp, &S->n_sort, c->fs.part.as<Box>(),
                            bp_tiles(w, h), K > 0 ? box_in : (const unsigned *)nullptr, inv, S, ws.keys[0].as<uint32_t>(),
-                           ws.vals[0].as<uint32_t>(), ws.ghist.as<unsigned>());
+                           ws.vals[0].as<uint32_t>(), ws.ghist.as<unsigned>(), (const Point *)old, (int)K,
+                           ws.table.as<uint32_t>());
         radix_sort_device(ws, ntn, c->stream);
-        hipLaunchKernelGGL(k_merge_new, dim3(ntn), dim3(256), 0, c->stream, old, (int)K, newp, ws.keys[0].as<uint32_t>(),
-                           ws.vals[0].as<uint32_t>(), inv, S, ws.cexcl.as<unsigned>(), ws.tile_lb.as<int>(), out,
-                           ws.ctl.as<LbCtl>(),
+        const int mn_tiles = (int)((maxnew + MN_TILE - 1) / MN_TILE);
+        hipLaunchKernelGGL(k_merge_new, dim3(mn_tiles + merge_side_groups(K)), dim3(256),
+                           sizeof(uint32_t) * (size_t)std::max(c->merge_cap, MERGE_TABLE), c->stream, old, (int)K, newp,
+                           ws.keys[0].as<uint32_t>(), ws.vals[0].as<uint32_t>(), inv, S, ws.table.as<uint32_t>(), c->merge_cap,
+                           ws.cexcl.as<unsigned>(), ws.tile_lb.as<int>(), out, ws.ctl.as<LbCtl>(),
                            ws.status.as<unsigned long long>(), ws.next_epoch(), box_out);
         if (K > 0)
             hipLaunchKernelGGL(k_merge_old, dim3(tiles_of(K)), dim3(256), 0, c->stream, old, (int)K,
@@ -1799,6 +1883,18 @@ int orbgpu_cloud_create(double resolution, int32_t device_id, orbgpu_cloud **out
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate: %s", hipGetErrorString(e));
+        delete c;
+        return ORBGPU_EHIP;
+    }
+    // k_merge_new stages up to MN_CAP resident indices (96 KB of dynamic LDS)
+    c->merge_cap = orbgpu::MN_CAP;
+    if (const char *dbg = getenv("ORBGPU_DEBUG_MERGE_CAP"))  // tests: a small cap sends tiles down the sampled fall-back
+        c->merge_cap = std::min(std::max(atoi(dbg), 0), orbgpu::MN_CAP);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(orbgpu::k_merge_new), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(uint32_t) * orbgpu::MN_CAP));
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(k_merge_new): %s", hipGetErrorString(e));
+        (void)hipStreamDestroy(c->stream);
         delete c;
         return ORBGPU_EHIP;
     }
@@ -1879,7 +1975,7 @@ int orbgpu_cloud_rebuild(orbgpu_cloud *c, int32_t n, const float *const *depth, 
     ORBGPU_REQUIRE(maxnew * n < (1ll << 30), "too many points for one rebuild");
     if ((rc = cloud_grow(c, c->cur, maxnew * n, 0)) != ORBGPU_OK)
         return rc;
-    if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK || (rc = c->box.reserve(sizeof(unsigned) * 12)) != ORBGPU_OK)
+    if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK || (rc = c->box.reserve(sizeof(unsigned) * 2 * BOX_WORDS)) != ORBGPU_OK)
         return rc;
     CloudState *S = c->ws.state.as<CloudState>();
     long long total = 0;
@@ -1923,7 +2019,7 @@ static int cloud_append_filtered_device(orbgpu_cloud *c, const float *d_depth, s
     ORBGPU_REQUIRE(K + maxnew < (1ll << 30), "dense map too large (%lld points)", K + maxnew);
     if ((rc = cloud_grow(c, c->cur, K + maxnew, K)) != ORBGPU_OK || (rc = cloud_grow(c, c->cur ^ 1, maxnew, 0)) != ORBGPU_OK)
         return rc;
-    if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK || (rc = c->box.reserve(sizeof(unsigned) * 12)) != ORBGPU_OK)
+    if ((rc = c->ws.reserve(maxnew, bp_tiles(w, h))) != ORBGPU_OK || (rc = c->box.reserve(sizeof(unsigned) * 2 * BOX_WORDS)) != ORBGPU_OK)
         return rc;
     CloudState *S = c->ws.state.as<CloudState>();
     Point *scratch = c->map[c->cur ^ 1].as<Point>();
@@ -1934,7 +2030,7 @@ static int cloud_append_filtered_device(orbgpu_cloud *c, const float *d_depth, s
     if ((rc = read_state(c, hs)) != ORBGPU_OK)
         return rc;
     rc = voxel_filter_device(c->ws, scratch, hs.n_sort, c->leaf, c->map[c->cur].as<Point>() + K,
-                             c->box.as<unsigned>() + 6 * (c->cur ^ 1), c->stream);
+                             c->box.as<unsigned>() + BOX_WORDS * (c->cur ^ 1), c->stream);
     if (rc != ORBGPU_OK || (rc = read_state(c, hs)) != ORBGPU_OK)
         return rc;
     c->size = K + hs.nout;
@@ -2189,7 +2285,7 @@ int orbgpu_voxel_filter(const orbgpu_point_xyzrgba *in, int64_t n, double resolu
         dbox.release();
     };
     if ((rc = din.reserve(sizeof(Point) * (size_t)n)) != ORBGPU_OK || (rc = dout.reserve(sizeof(Point) * (size_t)n)) != ORBGPU_OK ||
-        (rc = dbox.reserve(sizeof(unsigned) * 6)) != ORBGPU_OK) {
+        (rc = dbox.reserve(sizeof(unsigned) * BOX_WORDS)) != ORBGPU_OK) {
         cleanup();
         return rc;
     }

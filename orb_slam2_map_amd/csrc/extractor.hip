@@ -438,8 +438,12 @@ __device__ __forceinline__ pk16 fast_score_pk(pk16 c, const pk16 p[16])
     for (int i = 0; i < 8; i++)
         t[i] = hmin3(m4[i], m4[(i + 2) & 7], __builtin_elementwise_maximum(v[2 * i], v[(2 * i + 9) & 15]));
     const pkh B = __builtin_elementwise_maximum(hmax3(hmax3(t[0], t[1], t[2]), hmax3(t[3], t[4], t[5]), t[6]), t[7]);
-    const pk16 zero = {0, 0};
-    return pkmax(pkmax(c - h_as_pk(A), h_as_pk(B) - c), zero);  // values are in [0,255]
+    // max(c - A, B - c, 0) with saturating unsigned subtractions (v_pk_sub_u16 clamp): 3 operations instead of 4
+    typedef unsigned short pku16 __attribute__((ext_vector_type(2)));
+    const pku16 cu = __builtin_bit_cast(pku16, c);
+    const pku16 dk = __builtin_elementwise_sub_sat(cu, __builtin_bit_cast(pku16, A));
+    const pku16 br = __builtin_elementwise_sub_sat(__builtin_bit_cast(pku16, B), cu);
+    return __builtin_bit_cast(pk16, __builtin_elementwise_max(dk, br));  // values are in [0,255]
 }
 
 // v_perm selectors that zero-extend bytes (o, o+2) resp. (o+1, o+3) of the 8-byte pair {lo,hi}

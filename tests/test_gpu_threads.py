@@ -62,7 +62,15 @@ def test_concurrent_threads_own_handles_and_stateless_matchers(gpu, oracle, stre
             for r in range(rounds):
                 k, d = ext(frames[i][0] if r % 2 == 0 else frames[i + 1][0])
                 want = ref_ext[i] if r % 2 == 0 else ref_ext[i + 1]
-                assert k.tobytes() == want[0].tobytes() and np.array_equal(d, want[1]), "extraction differs (thread %d round %d)" % (i, r)
+                if not (k.tobytes() == want[0].tobytes() and np.array_equal(d, want[1])):
+                    # what differs, and whether the same handle gets it right when asked again (a transfer or a kernel?)
+                    k2_, d2_ = ext(frames[i][0] if r % 2 == 0 else frames[i + 1][0])
+                    rows = np.nonzero((d != want[1]).any(1))[0] if d.shape == want[1].shape else np.zeros(0, np.int64)
+                    raise AssertionError("extraction differs (thread %d round %d): key points equal %s, %d of %d descriptor rows differ "
+                                         "(first %s, octaves %s); a second call on the same handle is %s"
+                                         % (i, r, k.tobytes() == want[0].tobytes(), len(rows), len(d), rows[:8].tolist(),
+                                            want[0]["octave"][rows[:8]].tolist() if len(rows) else [],
+                                            "right" if k2_.tobytes() == want[0].tobytes() and np.array_equal(d2_, want[1]) else "wrong too"))
                 (ka, da), (kb, db) = ref_ext[i], ref_ext[i + 1]
                 n, mb = mine.MatchBruteForce(da, ka["angle"], db, kb["angle"])
                 assert n == ref_bf[i][0] and np.array_equal(mb, ref_bf[i][1]), "BF match differs (thread %d round %d)" % (i, r)
