@@ -492,10 +492,37 @@ __global__ __launch_bounds__(256) void k_vox_keys(const Point *__restrict__ pts,
                                                   const unsigned *__restrict__ oldbox, float inv, CloudState *st,
                                                   uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                   unsigned *__restrict__ ghist, const Point *__restrict__ old, int K,
-                                                  uint32_t *__restrict__ samp)
+                                                  uint32_t *__restrict__ samp, int pts_cap,
+                                                  uint32_t *__restrict__ okeys, int okey_groups)
 {
     __shared__ Box s_box[4];
     __shared__ unsigned s_h[4 * 256];
+    // what does not depend on the set-up is requested first: the tile's points (the buffer holds pts_cap of them, all
+    // readable whether or not they are part of this call's input) and this workgroup's share of the sample table
+    Point own[4] = {}, smp = {};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long long i = (long long)blockIdx.x * TILE + k * 256 + threadIdx.x;
+        if (i < pts_cap)
+            own[k] = pts[i];
+    }
+    const int np = samp ? min(K, MERGE_TABLE) : 0;
+    const int sidx = blockIdx.x * 256 + threadIdx.x;  // (the launch has more than MERGE_TABLE threads, or loops below)
+    if (sidx < np)
+        smp = old[K <= MERGE_TABLE ? sidx : (int)((long long)sidx * K / MERGE_TABLE)];
+    // ... and, in the workgroups that index the resident map (below), the first 4096 points of their chunk
+    const int og = (int)blockIdx.x - ((int)gridDim.x - okey_groups);
+    const int og_chunk = og >= 0 ? ((K + okey_groups - 1) / okey_groups + 255) & ~255 : 0;
+    const int og_i0 = og * og_chunk, og_i1 = min(og_i0 + og_chunk, K);
+    Point ogp[16];
+    if (og >= 0) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int i = og_i0 + u * 256 + (int)threadIdx.x;
+            if (i < og_i1)
+                ogp[u] = old[i];
+        }
+    }
     const int n = *n_dev;
     if ((long long)blockIdx.x * TILE >= n && blockIdx.x != 0 && !samp)
         return;
@@ -522,9 +549,37 @@ __global__ __launch_bounds__(256) void k_vox_keys(const Point *__restrict__ pts,
     // merge path: the indices of MERGE_TABLE evenly spaced resident points (all of them if the map is smaller), the
     // table k_merge_new brackets its tile with -- one scattered load per thread here, beside this kernel's own loads,
     // instead of the same 1024 scattered loads at the head of every workgroup's chain there (4 us of its 35)
+    // merge path, the last okey_groups workgroups of the launch: the index of EVERY resident point under this call's
+    // set-up, 4 bytes per point for k_merge_new to rank against (it staged the points themselves until this was added:
+    // 16 bytes per point at the ~12 GB/s one workgroup draws, 9 of its 18 us).  These workgroups run beside the ones that
+    // index the new points, on compute units the launch would leave idle.
+    if (og >= 0) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int i = og_i0 + u * 256 + (int)threadIdx.x;
+            if (i < og_i1)
+                okeys[i] = vox_key(ogp[u], inv, vs.min_b, vs.mul);
+        }
+        for (int b = og_i0 + 4096; b < og_i1; b += 256 * 8) {  // (maps beyond ~900 k points: chunks longer than 4096)
+            Point pt[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = b + u * 256 + (int)threadIdx.x;
+                if (i < og_i1)
+                    pt[u] = old[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = b + u * 256 + (int)threadIdx.x;
+                if (i < og_i1)
+                    okeys[i] = vox_key(pt[u], inv, vs.min_b, vs.mul);
+            }
+        }
+    }
     if (samp) {
-        const int np = min(K, MERGE_TABLE);
-        for (int s = blockIdx.x * 256 + threadIdx.x; s < np; s += gridDim.x * 256)
+        if (sidx < np)
+            samp[sidx] = vox_key(smp, inv, vs.min_b, vs.mul);
+        for (int s = sidx + gridDim.x * 256; s < np; s += gridDim.x * 256)  // (small frames: fewer threads than samples)
             samp[s] = vox_key(old[K <= MERGE_TABLE ? s : (int)((long long)s * K / MERGE_TABLE)], inv, vs.min_b, vs.mul);
         if ((long long)blockIdx.x * TILE >= n && blockIdx.x != 0)
             return;
@@ -536,7 +591,7 @@ __global__ __launch_bounds__(256) void k_vox_keys(const Point *__restrict__ pts,
     for (int k = 0; k < 4; k++) {
         const long long i = (long long)blockIdx.x * TILE + k * 256 + threadIdx.x;
         if (i < n) {
-            const uint32_t key = vox_key(pts[i], inv, vs.min_b, vs.mul);
+            const uint32_t key = vox_key(own[k], inv, vs.min_b, vs.mul);
             keys[i] = key;
             vals[i] = (uint32_t)i;
 #pragma unroll
@@ -844,7 +899,7 @@ __device__ __forceinline__ int lds_count_le(const uint32_t *a, int n, uint32_t k
 constexpr int MN_TILE = 256;     // sorted new keys per workgroup (one per thread)
 constexpr int MN_CAP = 24576;    // resident indices a workgroup stages in LDS (96 KB)
 constexpr int MN_SAMPLES = 1024; // fall-back when a tile's range is longer than that: samples of the range
-constexpr int MN_LOADS = 32;     // 16-byte loads a thread has in flight while it stages a range (128 VGPRs; one wave per SIMD anyway)
+constexpr int MN_LOADS = 16;     // loads a thread has in flight while it stages a range
 
 // new-point side: every run of equal keys among the sorted new points becomes one output voxel -- merged with the
 // resident map's point of that voxel if there is one (it comes first in PCL's input order), a new voxel otherwise.
@@ -863,9 +918,9 @@ constexpr int MN_LOADS = 32;     // 16-byte loads a thread has in flight while i
 // Side job: tile_lb[b] = first sorted new key >= the index of resident point b*1024, which brackets the new keys
 // k_merge_old's workgroup b has to look at.  It is the work of the workgroups BEHIND the tiles of new points (the
 // launch adds merge_side_groups(K) of them): a 15-deep chain of its own that runs beside the tiles' chain.
-__global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old, int K,
+__global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old, const uint32_t *__restrict__ okeys, int K,
                                                    const Point *__restrict__ newp, const uint32_t *__restrict__ skeys,
-                                                   const uint32_t *__restrict__ svals, float inv, CloudState *st,
+                                                   const uint32_t *__restrict__ svals, CloudState *st,
                                                    const uint32_t *__restrict__ table, int cap,
                                                    unsigned *__restrict__ cexcl, int *__restrict__ tile_lb,
                                                    Point *__restrict__ out, LbCtl *ctl, unsigned long long *status,
@@ -879,11 +934,6 @@ __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old
     const int nf = st->nfinite;
     const int ntiles = max((nf + MN_TILE - 1) / MN_TILE, 1);
     const bool overflow = st->overflow != 0;
-    int min_b[3], mul[3];
-    for (int a = 0; a < 3; a++) {
-        min_b[a] = st->min_b[a];
-        mul[a] = st->mul[a];
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (tile < ntiles && !overflow) {
         const int j = tile * MN_TILE + (int)threadIdx.x;
@@ -915,22 +965,20 @@ __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old
             int r = 0;           // resident points with index <= key
             bool exists = false;  // ... the last of them has this index
             if (len <= cap) {
-                // the range itself: indices of old[lo, hi) to LDS
-                // (MN_LOADS requests per thread go out before the first index is formed: a round of them costs one memory
-                // latency, ~2.5 us here, however many there are -- 8 per round made a 6 k range 7.6 us)
+                // the range itself: the indices of old[lo, hi) (k_vox_keys) to LDS
                 for (int s0 = 0; s0 < len; s0 += 256 * MN_LOADS) {
-                    Point pt[MN_LOADS];
+                    uint32_t kk[MN_LOADS];
 #pragma unroll
                     for (int u = 0; u < MN_LOADS; u++) {
                         const int sidx = s0 + u * 256 + (int)threadIdx.x;
                         if (sidx < len)
-                            pt[u] = old[lo + sidx];
+                            kk[u] = okeys[lo + sidx];
                     }
 #pragma unroll
                     for (int u = 0; u < MN_LOADS; u++) {
                         const int sidx = s0 + u * 256 + (int)threadIdx.x;
                         if (sidx < len)
-                            s_old[sidx] = vox_key(pt[u], inv, min_b, mul);
+                            s_old[sidx] = kk[u];
                     }
                 }
                 __syncthreads();
@@ -942,7 +990,7 @@ __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old
             } else {
                 // a long range: MN_SAMPLES samples of it, then the last levels in global memory
                 for (int s = threadIdx.x; s < MN_SAMPLES; s += 256)
-                    s_old[s] = vox_key(old[lo + (int)((long long)s * len / MN_SAMPLES)], inv, min_b, mul);
+                    s_old[s] = okeys[lo + (int)((long long)s * len / MN_SAMPLES)];
                 __syncthreads();
                 if (head) {
                     const int c = lds_count_le(s_old, MN_SAMPLES, key);
@@ -950,13 +998,13 @@ __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old
                     int h = max(l, c == MN_SAMPLES ? hi : lo + (int)((long long)c * len / MN_SAMPLES));
                     while (l < h) {  // first index in [l, h) whose key is > key (h if none)
                         const int mid = (l + h) >> 1;
-                        if (vox_key(old[mid], inv, min_b, mul) <= key)
+                        if (okeys[mid] <= key)
                             l = mid + 1;
                         else
                             h = mid;
                     }
                     r = l;
-                    exists = l > 0 && vox_key(old[l - 1], inv, min_b, mul) == key;
+                    exists = l > 0 && okeys[l - 1] == key;
                 }
             }
             if (head) {
@@ -1007,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_merge_new(const Point *__restrict__ old
         // side job (the workgroups behind the tiles): the bracket of every map tile
         const int ntk = (K + TILE - 1) / TILE, nside = (int)gridDim.x - ntiles;
         for (int b = (tile - ntiles) * 256 + (int)threadIdx.x; b < ntk; b += nside * 256)
-            tile_lb[b] = key_lower_bound(skeys, 0, nf, vox_key(old[(size_t)b * TILE], inv, min_b, mul));
+            tile_lb[b] = key_lower_bound(skeys, 0, nf, okeys[(size_t)b * TILE]);
     }
     lb_leave(ctl);
 }
@@ -1031,6 +1079,7 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
 {
     __shared__ Box s_box[4];
     __shared__ uint32_t s_keys[MERGE_OLD_LDS];
+    __shared__ unsigned s_cex[MERGE_OLD_LDS + 1];
     if (st->overflow)
         return;
     const int nf = st->nfinite;
@@ -1041,26 +1090,32 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
     }
     const int ntk = (K + TILE - 1) / TILE;
     const int i0 = blockIdx.x * TILE;
-    // the tile's points are requested first: their latency covers the bracket / staging chain below
-    Point p4[4] = {};
+    // the tile's points are requested first -- and, by the first lane of every wave, the point in front of the wave's
+    // first one, for the ordering check --: their latency covers the bracket / staging chain below
+    const int lane = threadIdx.x & 63;
+    Point p4[4] = {}, pv4[4] = {};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int i = i0 + k * 256 + threadIdx.x;
         if (i < K)
             p4[k] = old[i];
+        if (lane == 0 && i > 0 && i < K)
+            pv4[k] = old[i - 1];
     }
     const int lo = min(max(tile_lb[blockIdx.x], 0), nf);
     const int hi = min(max((int)blockIdx.x + 1 < ntk ? tile_lb[blockIdx.x + 1] : nf, lo), nf);
     const int len = hi - lo;
     const bool staged = len <= MERGE_OLD_LDS;
-    if (staged)
+    if (staged) {  // the new keys the tile can meet and the new-voxel counts in front of them (one more: lb may be hi)
         for (int s = threadIdx.x; s < len; s += 256)
             s_keys[s] = skeys[lo + s];
+        for (int s = threadIdx.x; s <= len; s += 256)
+            s_cex[s] = cexcl[lo + s];
+    }
     __syncthreads();
     Box bx;
     box_init(bx);
     bool bad = false;
-    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int i = i0 + k * 256 + threadIdx.x;
@@ -1072,22 +1127,25 @@ __global__ __launch_bounds__(256) void k_merge_old(const Point *__restrict__ old
         if (i >= K)
             continue;
         if (lane == 0 && i > 0)
-            prev = vox_key(old[i - 1], inv, min_b, mul);
+            prev = vox_key(pv4[k], inv, min_b, mul);
         if (i > 0 && prev >= key)
             bad = true;
         int lb;
         bool touched;
+        unsigned opened;  // new voxels in front of this point
         if (staged) {
             const int c = key_lower_bound(s_keys, 0, len, key);
             lb = lo + c;
             touched = c < len ? s_keys[c] == key : (lb < nf && skeys[lb] == key);
+            opened = s_cex[c];
         } else {
             lb = key_lower_bound(skeys, lo, hi, key);
             touched = lb < nf && skeys[lb] == key;
+            opened = touched ? 0u : cexcl[lb];
         }
         if (touched)
             continue;  // merged by k_merge_new
-        out[i + (int)cexcl[lb]] = p;
+        out[i + (int)opened] = p;
         box_add(bx, p);
     }
     if (__any(bad) && lane == 0)
@@ -1321,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_sor_knn(const float4 *__restrict__ sort
 // host side
 // ------------------------------------------------------------------------------------------
 struct VoxelWorkspace {
-    DevBuf keys[2], vals[2], status, part, cexcl, tile_lb, ctl, state, ghist, table;
+    DevBuf keys[2], vals[2], status, part, cexcl, tile_lb, ctl, state, ghist, table, okeys;
     unsigned epoch = 0;
     bool armed = false;
     int reserve(long long n_sort, int nparts)
@@ -1373,7 +1431,7 @@ struct VoxelWorkspace {
             keys[k].release();
             vals[k].release();
         }
-        status.release(), part.release(), cexcl.release(), tile_lb.release(), ctl.release(), state.release(), ghist.release(), table.release();
+        status.release(), part.release(), cexcl.release(), tile_lb.release(), ctl.release(), state.release(), ghist.release(), table.release(), okeys.release();
         armed = false;
     }
 };
@@ -1415,7 +1473,7 @@ static int voxel_filter_device(VoxelWorkspace &ws, const Point *in, long long n,
                        outbox);
     hipLaunchKernelGGL(k_vox_keys, dim3(nt), dim3(256), 0, st, in, &S->n_sort, ws.part.as<Box>(), nb,
                        (const unsigned *)nullptr, inv, S, ws.keys[0].as<uint32_t>(), ws.vals[0].as<uint32_t>(),
-                       ws.ghist.as<unsigned>(), (const Point *)nullptr, 0, (uint32_t *)nullptr);
+                       ws.ghist.as<unsigned>(), (const Point *)nullptr, 0, (uint32_t *)nullptr, (int)n, (uint32_t *)nullptr, 0);
     radix_sort_device(ws, nt, st);
     hipLaunchKernelGGL(k_vox_reduce, dim3(nt), dim3(256), 0, st, in, (int)n, ws.keys[0].as<uint32_t>(),
                        ws.vals[0].as<uint32_t>(), S, out, ws.ctl.as<LbCtl>(), ws.status.as<unsigned long long>(),
@@ -1800,6 +1858,9 @@ static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dst
     if ((rc = c->box.reserve(sizeof(unsigned) * 2 * BOX_WORDS)) != ORBGPU_OK ||
         (rc = c->ws.tile_lb.reserve(sizeof(int) * (size_t)(tiles_of(K) + 1) * 2)) != ORBGPU_OK)
         return rc;
+    if (sizeof(uint32_t) * (size_t)K > c->ws.okeys.bytes &&  // (grows with the map: with slack, not at every key frame)
+        (rc = c->ws.okeys.reserve(sizeof(uint32_t) * (size_t)(K + K / 2 + 4 * maxnew))) != ORBGPU_OK)
+        return rc;
     VoxelWorkspace &ws = c->ws;
     CloudState *S = ws.state.as<CloudState>();
     Point *old = c->map[c->cur].as<Point>(), *newp = old + K, *out = c->map[c->cur ^ 1].as<Point>();
@@ -1816,15 +1877,18 @@ static int cloud_insert_device(orbgpu_cloud *c, const float *d_depth, size_t dst
     CloudState hs;
     if (merge) {
         const int ntn = tiles_of(maxnew);
-        hipLaunchKernelGGL(k_vox_keys, dim3(ntn), dim3(256), 0, c->stream, newp, &S->n_sort, c->fs.part.as<Box>(),
+        // + the workgroups that index the resident map: ~4 k points each, at most as many as fill the device with the others
+        const int okg = K > 0 ? (int)std::min<long long>((K + 4095) / 4096, std::max(256 - ntn, 64)) : 0;
+        hipLaunchKernelGGL(k_vox_keys, dim3(ntn + okg), dim3(256), 0, c->stream, newp, &S->n_sort, c->fs.part.as<Box>(),
                            bp_tiles(w, h), K > 0 ? box_in : (const unsigned *)nullptr, inv, S, ws.keys[0].as<uint32_t>(),
                            ws.vals[0].as<uint32_t>(), ws.ghist.as<unsigned>(), (const Point *)old, (int)K,
-                           ws.table.as<uint32_t>());
+                           ws.table.as<uint32_t>(), (int)maxnew, ws.okeys.as<uint32_t>(), okg);
         radix_sort_device(ws, ntn, c->stream);
         const int mn_tiles = (int)((maxnew + MN_TILE - 1) / MN_TILE);
         hipLaunchKernelGGL(k_merge_new, dim3(mn_tiles + merge_side_groups(K)), dim3(256),
-                           sizeof(uint32_t) * (size_t)std::max(c->merge_cap, MERGE_TABLE), c->stream, old, (int)K, newp,
-                           ws.keys[0].as<uint32_t>(), ws.vals[0].as<uint32_t>(), inv, S, ws.table.as<uint32_t>(), c->merge_cap,
+                           sizeof(uint32_t) * (size_t)std::max(c->merge_cap, MERGE_TABLE), c->stream, old,
+                           ws.okeys.as<uint32_t>(), (int)K, newp,
+                           ws.keys[0].as<uint32_t>(), ws.vals[0].as<uint32_t>(), S, ws.table.as<uint32_t>(), c->merge_cap,
                            ws.cexcl.as<unsigned>(), ws.tile_lb.as<int>(), out, ws.ctl.as<LbCtl>(),
                            ws.status.as<unsigned long long>(), ws.next_epoch(), box_out);
         if (K > 0)
