@@ -10,10 +10,13 @@
 // The old map is itself such an output -- sorted, one point per voxel, and that order (z-major
 // lexicographic on the lattice coordinates) does not depend on the bounding box -- so a key frame is a MERGE:
 //   k_bp         back-project + transform + compact the <= 34 k new points (one launch, look-back offsets)
-//   k_vox_keys   PCL's set-up from (box of the map, box of the new points), voxel indices of the new points
+//   k_vox_keys   PCL's set-up from (box of the map, box of the new points), voxel indices of the new points; further
+//                workgroups of the same launch index EVERY resident point under that set-up (4 bytes per point) and
+//                sample 4096 of those indices into a table
 //   k_sort_pass  x4: stable LSD radix sort of the new points only (one launch per digit, look-back)
-//   k_merge_new  runs of new points -> centroid (seeded with the map's point of that voxel if any) at its
-//                merged position
+//   k_merge_new  256 sorted new keys per workgroup: the table brackets the resident range they can fall into, its
+//                indices are staged in LDS and every run of equal keys is ranked there -> centroid (seeded with the
+//                map's point of that voxel if any) at its merged position
 //   k_merge_old  untouched map points shift up by the number of new voxels before them (the map is read and
 //                written once: K*16 B in, V*16 B out = the algorithmic bytes of SURVEY.md 8d)
 // 8 launches per key frame instead of 35, no full-map sort.  What the merge assumes is checked on the fly
@@ -21,6 +24,12 @@
 // the general path = the same sort over all points + a fused head-flag / scan / reduce kernel (7 launches),
 // which also serves orbgpu_voxel_filter and the loop-closure rebuild.  Equal indices keep input order in both
 // paths, so the per-voxel float sums are reproducible.  HBM-bound integer/float streaming; no MFMA.
+//
+// What bounds a key frame is latency, not bytes (s_memrealtime stamps inside the kernels): a
+// dependent load inside a kernel is a 1 - 1.5 us round trip whichever cache answers it, a publish -> read hop between
+// workgroups (look-back) ~3 us, a kernel boundary ~2.2 us, and ONE workgroup draws ~12 - 15 GB/s.  Hence: loads are
+// requested before the chain that does not need them, data a workgroup searches is staged in LDS with one coalesced
+// request, work that is wide (indexing 700 k resident points) rides in launches that are narrow (34 tiles of new points).
 #include "common.h"
 
 #include <cstdlib>
@@ -47,8 +56,9 @@ struct Pose {
 // Decoupled look-back (single-pass device-wide prefix sums over tiles).
 //
 // Every kernel that needs an ordered prefix over its workgroups (compaction offsets, radix-sort digit
-// offsets, voxel output positions) takes a dynamic tile id from a ticket counter -- so a tile only ever
-// waits for tiles that have already started -- publishes its aggregate, sums the published values of its
+// offsets, voxel output positions) takes a tile id -- blockIdx.x in launches small enough to be resident as a whole,
+// else a dynamic one from a ticket counter, so that a tile only ever waits for tiles that have already started
+// (lb_take_tile) -- publishes its aggregate, sums the published values of its
 // predecessors until it meets an inclusive prefix, and publishes its own inclusive prefix.
 // Status word: [63:32] launch epoch (stale words of earlier launches never match, nothing is cleared
 // between launches), [31:30] 1 = aggregate / 2 = inclusive prefix, [29:0] value.  The last workgroup to

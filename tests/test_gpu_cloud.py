@@ -199,6 +199,31 @@ def test_cloud_merge_path_sequence(gpu, oracle, stream640, leaf):
     cloud.close()
 
 
+@pytest.mark.parametrize("cap", ["0", "300", "5000"])
+def test_cloud_merge_path_with_long_resident_ranges(gpu, oracle, stream640, monkeypatch, cap):
+    """k_merge_new ranks a tile of new keys against the resident indices of the range they can fall into: staged in
+    LDS when the range has at most `cap` points (24576 in production), sampled + searched in global memory otherwise.
+    ORBGPU_DEBUG_MERGE_CAP (read when the handle is created) makes ordinary key frames exercise the long-range path (0:
+    every tile) and the mix of both (300, 5000); a dense map seen again through a sparse frame (3 of 4 depth samples
+    invalid) stretches the ranges on top of that."""
+    monkeypatch.setenv("ORBGPU_DEBUG_MERGE_CAP", cap)
+    camv = cam(stream640)
+    cloud = gpu.PointCloudMapping(0.02)
+    omap = np.zeros(0, oracle.POINT_DTYPE)
+    rng = np.random.default_rng(5)
+    for i in range(6):
+        _, rgb, depth = stream640.frame(7 * i)
+        if i >= 4:
+            depth = depth.copy()
+            depth[rng.random(depth.shape) < 0.75] = 0.0
+        T = scenario.rigid(0.004 * i, -0.006 * i, 0.002 * i, (0.05 * i, 0.01 * i, -0.02 * i))
+        cloud.insertKeyFrame(depth, rgb, *camv, T)
+        omap, ov = _oracle_step(oracle, omap, depth, rgb, camv, T, 0.02)
+        assert not ov and cloud.last_path() == 1, "key frame %d took path %d" % (i, cloud.last_path())
+        assert cloud.download().tobytes() == omap.tobytes(), "key frame %d cap %s" % (i, cap)
+    cloud.close()
+
+
 def test_cloud_same_view_twice_merges_into_existing_voxels(gpu, oracle, stream640):
     """The same key frame inserted twice: every new point falls into an occupied voxel (no new voxels, map size
     unchanged), then a third insert from elsewhere opens new ones before / between / after the resident ones."""

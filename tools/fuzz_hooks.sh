@@ -10,3 +10,9 @@ for h in "ORBGPU_DEBUG_QT_KEYS=500" "ORBGPU_DEBUG_QT_KEYS=500 ORBGPU_DEBUG_QT_NO
   echo "fuzz_extract [$h]: $line" | tee -a $OUT
   case "$line" in "fuzz ok"*) ;; *) echo "stopped: fuzz_extract under $h did not finish clean" | tee -a $OUT; exit 1;; esac
 done
+# the dense map's merge with the sampled long-range path forced on every tile / on most tiles
+for h in "ORBGPU_DEBUG_MERGE_CAP=0" "ORBGPU_DEBUG_MERGE_CAP=700"; do
+  line=$(env $h timeout -k 10 $((SECS + 120)) python tools/fuzz_cloud.py $SECS $SEED 2>&1 | tail -1)
+  echo "fuzz_cloud [$h]: $line" | tee -a $OUT
+  case "$line" in "fuzz ok"*) ;; *) echo "stopped: fuzz_cloud under $h did not finish clean" | tee -a $OUT; exit 1;; esac
+done
