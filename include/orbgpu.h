@@ -186,6 +186,7 @@ int orbgpu_extractor_set_concurrent_blur(orbgpu_extractor *h, int32_t enable);
  * are textured everywhere, like the synthetic benchmark stream -- hence off by default.  Environment variable
  * ORBGPU_FAST_EARLY_OUT=1 turns it on for handles created afterwards. */
 int orbgpu_extractor_set_fast_early_out(orbgpu_extractor *h, int32_t enable);
+
 /* Pipelining aid for callers that run other work next to an extraction (bench.py starts the matcher of the previous
  * batch there): `hip_event` (a hipEvent_t, or NULL to clear) is recorded on the launch stream of every later
  * orbgpu_extract_batch_device call right after stage `stage` (index as in orbgpu_extractor_stage_name). */

@@ -6,6 +6,13 @@
 // OpenCV 2.4 calls it makes.  Integer stages are bit-exact by
 // construction; float stages are written without contraction (see common.h).
 #include "common.h"
+
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 #include "trig_base.h"
 
 #include <algorithm>
@@ -2688,21 +2695,26 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     RSV(e->d_ncand, sizeof(int) * nl * B);
     RSV(e->d_qtaux, sizeof(int) * QT_AUX_FRAME * QT_BATCH_MIN);
 #undef RSV
-    ORBGPU_HIP_TRY(hipMemcpy(e->d_geom.p, geom.data(), sizeof(LevelGeom) * nl, hipMemcpyHostToDevice));
-    ORBGPU_HIP_TRY(hipMemcpy(e->d_cells.p, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice));
-    ORBGPU_HIP_TRY(hipMemcpy(e->d_ctab.p, ctab.data(), sizeof(ColumnInfo) * ctab.size(), hipMemcpyHostToDevice));
+    // Tables and initial values go through the handle's OWN stream and are waited for below.  The synchronous forms are
+    // not a substitute: hipMemset (like cudaMemset) is asynchronous with respect to the host and runs on the null stream,
+    // which the handle's non-blocking stream is not ordered with -- under load (several host threads making their first
+    // calls at once) the zeroing of the blurred planes and of the cell counters arrived AFTER k_blur / k_fast_detect had
+    // written them: descriptors of zeros, wrong key points, once a memory fault (round 4, tools/stress_first_calls.py).
+    ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_geom.p, geom.data(), sizeof(LevelGeom) * nl, hipMemcpyHostToDevice, e->stream));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_cells.p, cells.data(), sizeof(CellDesc) * cells.size(), hipMemcpyHostToDevice, e->stream));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_ctab.p, ctab.data(), sizeof(ColumnInfo) * ctab.size(), hipMemcpyHostToDevice, e->stream));
     if (!bcol.empty())
-        ORBGPU_HIP_TRY(hipMemcpy(e->d_bcol.p, bcol.data(), sizeof(BorderCol) * bcol.size(), hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_bcol.p, bcol.data(), sizeof(BorderCol) * bcol.size(), hipMemcpyHostToDevice, e->stream));
     e->border_fast = !bcol.empty();
     if (!xtab.empty()) {
-        ORBGPU_HIP_TRY(hipMemcpy(e->d_xtab.p, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice));
-        ORBGPU_HIP_TRY(hipMemcpy(e->d_ytab.p, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice));
-        ORBGPU_HIP_TRY(hipMemcpy(e->d_yrow.p, yrow.data(), sizeof(YRow) * yrow.size(), hipMemcpyHostToDevice));
-        ORBGPU_HIP_TRY(hipMemcpy(e->d_rstrip.p, rstrip.data(), sizeof(ResizeStrip) * rstrip.size(), hipMemcpyHostToDevice));
-        ORBGPU_HIP_TRY(hipMemcpy(e->d_rsel.p, rsel.data(), sizeof(uint4) * rsel.size(), hipMemcpyHostToDevice));
-        ORBGPU_HIP_TRY(hipMemcpy(e->d_rwt.p, rwt.data(), sizeof(uint4) * rwt.size(), hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_xtab.p, xtab.data(), sizeof(XTab) * xtab.size(), hipMemcpyHostToDevice, e->stream));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_ytab.p, ytab.data(), sizeof(YTab) * ytab.size(), hipMemcpyHostToDevice, e->stream));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_yrow.p, yrow.data(), sizeof(YRow) * yrow.size(), hipMemcpyHostToDevice, e->stream));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_rstrip.p, rstrip.data(), sizeof(ResizeStrip) * rstrip.size(), hipMemcpyHostToDevice, e->stream));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_rsel.p, rsel.data(), sizeof(uint4) * rsel.size(), hipMemcpyHostToDevice, e->stream));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_rwt.p, rwt.data(), sizeof(uint4) * rwt.size(), hipMemcpyHostToDevice, e->stream));
     }
-    ORBGPU_HIP_TRY(hipMemcpy(e->d_pattern.p, k_pattern_host, 1024, hipMemcpyHostToDevice));
+    ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_pattern.p, k_pattern_host, 1024, hipMemcpyHostToDevice, e->stream));
     {
         // k_orient's byte-weight tables per (alignment a of the disc's first column, |v|, dword j of the 9-dword row):
         // W10 holds u + 16 inside the disc (0 outside), M01 holds 1 inside the disc
@@ -2717,13 +2729,15 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
                 }
             }
         }
-        ORBGPU_HIP_TRY(hipMemcpy(e->d_pattern.as<uint8_t>() + 1024, orw.data(), orw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipMemcpyAsync(e->d_pattern.as<uint8_t>() + 1024, orw.data(), orw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        ORBGPU_HIP_TRY(hipStreamSynchronize(e->stream));  // (orw leaves scope)
     }
     // the blurred planes are only written inside the image; define the rest once
-    ORBGPU_HIP_TRY(hipMemset(e->d_blur.p, 0, e->frame_pyr * B));
+    ORBGPU_HIP_TRY(hipMemsetAsync(e->d_blur.p, 0, e->frame_pyr * B, e->stream));
     // cell counters start at zero; k_quadtree re-arms them after reading
-    ORBGPU_HIP_TRY(hipMemset(e->d_cellcnt.p, 0, sizeof(int) * (cells.size() + ORBGPU_MAX_LEVELS) * B));
-    ORBGPU_HIP_TRY(hipMemset(e->d_qtaux.p, 0, e->d_qtaux.bytes));  // likewise (k_quadtree<true> re-arms what it reads)
+    ORBGPU_HIP_TRY(hipMemsetAsync(e->d_cellcnt.p, 0, sizeof(int) * (cells.size() + ORBGPU_MAX_LEVELS) * B, e->stream));
+    ORBGPU_HIP_TRY(hipMemsetAsync(e->d_qtaux.p, 0, e->d_qtaux.bytes, e->stream));  // likewise (k_quadtree<true> re-arms what it reads)
+    ORBGPU_HIP_TRY(hipStreamSynchronize(e->stream));  // ... before any stream (the caller's, for the device entry points) reads them
     // The attribute belongs to the function (per device), not to this handle: another handle with a larger geometry may
     // have raised it and still launch, so it is set once to the most the kernel can ever be launched with here
     // (qt_lds <= 159 KB and qt_lds + 6 qt_kcap <= 150 KB are enforced above; the static part is < 200 B).
@@ -2737,9 +2751,75 @@ static int configure(orbgpu_extractor *e, int w, int h, int batch)
     return ORBGPU_OK;
 }
 
+// Where the kernels of a call go: onto a stream, or -- host entry points, from the second call of a configuration on --
+// into a hipGraph as a chain of kernel nodes.  The graph is BUILT (hipGraphAddKernelNode), not captured: a stream
+// capture is process-wide state on this runtime -- another thread's hipFree / hipMalloc / synchronous copy invalidated
+// captures in flight (in every capture mode), and launches of other threads then failed with "operation failed due to a
+// previous error during capture" (round 4, tools/stress_first_calls.py).  Nothing here touches global state.
+struct Launcher {
+    hipStream_t st = nullptr;
+    hipGraph_t graph = nullptr;      // non-null: record instead of launching
+    hipGraphNode_t last = nullptr;   // tail of the chain
+    hipError_t err = hipSuccess;     // first error while recording
+
+    Launcher() = default;
+    explicit Launcher(hipStream_t s) : st(s) {}
+
+    template <typename... P, typename... A> void launch(void (*kern)(P...), dim3 grid, dim3 block, size_t lds, A &&...a)
+    {
+        static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+        if (!graph) {
+            hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<P>(a)...);
+            return;
+        }
+        std::tuple<std::remove_cv_t<P>...> vals(static_cast<P>(a)...);  // the node copies the values when it is added
+        void *ptrs[sizeof...(P) + 1];
+        fill(ptrs, vals, std::index_sequence_for<P...>{});
+        hipKernelNodeParams kp = {};
+        kp.func = reinterpret_cast<void *>(kern);
+        kp.gridDim = grid;
+        kp.blockDim = block;
+        kp.sharedMemBytes = (unsigned)lds;
+        kp.kernelParams = ptrs;
+        kp.extra = nullptr;
+        add([&](hipGraphNode_t *n, const hipGraphNode_t *dep, size_t ndep) { return hipGraphAddKernelNode(n, graph, dep, ndep, &kp); });
+    }
+    int memset32(void *dst, size_t bytes)  // zero `bytes` (a multiple of 4) at dst
+    {
+        if (!graph) {
+            ORBGPU_HIP_TRY(hipMemsetAsync(dst, 0, bytes, st));
+            return ORBGPU_OK;
+        }
+        hipMemsetParams mp = {};
+        mp.dst = dst;
+        mp.elementSize = 4;
+        mp.width = bytes / 4;
+        mp.height = 1;
+        mp.pitch = bytes;
+        mp.value = 0;
+        add([&](hipGraphNode_t *n, const hipGraphNode_t *dep, size_t ndep) { return hipGraphAddMemsetNode(n, graph, dep, ndep, &mp); });
+        return ORBGPU_OK;
+    }
+
+private:
+    template <typename T, size_t... I> static void fill(void **ptrs, T &vals, std::index_sequence<I...>)
+    {
+        ((ptrs[I] = const_cast<void *>(static_cast<const void *>(&std::get<I>(vals)))), ...);
+    }
+    template <typename F> void add(F f)
+    {
+        hipGraphNode_t n = nullptr;
+        const hipError_t e = f(&n, last ? &last : nullptr, last ? 1 : 0);
+        if (e != hipSuccess && err == hipSuccess)
+            err = e;
+        if (e == hipSuccess)
+            last = n;
+    }
+};
+
 // Level 0 as a padded plane: copyMakeBorder(image, REFLECT_101) (ORBextractor.cc:1125-1129).  Every call when the input is
 // not aligned for direct mode; otherwise only when mvImagePyramid[0] is asked for (the getters below).
-static int materialize_level0(orbgpu_extractor *e, const Src0 &s0, int batch, hipStream_t st)
+static int materialize_level0(orbgpu_extractor *e, const Src0 &s0, int batch, Launcher &L)
 {
     const LevelGeom &g = e->geom[0];
     const LevelGeom *dg = e->d_geom.as<LevelGeom>();
@@ -2747,19 +2827,20 @@ static int materialize_level0(orbgpu_extractor *e, const Src0 &s0, int batch, hi
     const size_t stride = s0.pitch;
     if (e->border_fast && stride % 4 == 0 && s0.frame_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(s0.p) & 3) == 0) {
         dim3 gridf(((g.pitch / 16) * ((g.h + 2 * EDGE + BORDER_ROWS - 1) / BORDER_ROWS) + 255) / 256, batch);
-        hipLaunchKernelGGL(k_border0_fast, gridf, dim3(256), 0, st, s0.p, stride, s0.frame_stride, pyr, e->frame_pyr, dg,
+        L.launch(k_border0_fast, gridf, dim3(256), 0, s0.p, stride, s0.frame_stride, pyr, e->frame_pyr, dg,
                            e->d_bcol.as<BorderCol>());
     } else {
         dim3 grid(((g.pitch / 4) * ((g.h + 2 * EDGE + PYR_ROWS - 1) / PYR_ROWS) + 255) / 256, batch);
-        hipLaunchKernelGGL(k_border0, grid, dim3(256), 0, st, s0.p, stride, s0.frame_stride, pyr, e->frame_pyr, dg);
+        L.launch(k_border0, grid, dim3(256), 0, s0.p, stride, s0.frame_stride, pyr, e->frame_pyr, dg);
     }
-    ORBGPU_HIP_TRY(hipGetLastError());
+    if (!L.graph)
+        ORBGPU_HIP_TRY(hipGetLastError());
     return ORBGPU_OK;
 }
 
 // the blur of all levels: one launch, or -- direct mode -- level 0 from the image (k_blur0_direct) + the other levels
 // (which: 0 = everything, 1 = only the direct-mode level 0, which needs nothing but the image, 2 = only the rest)
-static void launch_blur(orbgpu_extractor *e, const Src0 &s0, int batch, hipStream_t st, int which = 0)
+static void launch_blur(orbgpu_extractor *e, const Src0 &s0, int batch, Launcher &L, int which = 0)
 {
     const int nl = e->nlevels;
     const LevelGeom *dg = e->d_geom.as<LevelGeom>();
@@ -2769,20 +2850,21 @@ static void launch_blur(orbgpu_extractor *e, const Src0 &s0, int batch, hipStrea
         const LevelGeom &g = e->geom[0];
         const int nstrips = (g.w / 8) * ((g.h + BLUR_ROWS - 1) / BLUR_ROWS);
         if (which != 2)
-            hipLaunchKernelGGL(k_blur0_direct, dim3((nstrips + 255) / 256, batch), dim3(256), 0, st, s0, blur, e->frame_pyr, dg);
+            L.launch(k_blur0_direct, dim3((nstrips + 255) / 256, batch), dim3(256), 0, s0, blur, e->frame_pyr, dg);
         strip0 = e->blur_geom.first[1];
     }
     if (which == 1)
         return;
     if (e->blur_geom.first[nl] > strip0)
-        hipLaunchKernelGGL(k_blur, dim3((e->blur_geom.first[nl] - strip0 + 255) / 256, batch), dim3(256), 0, st, pyr, blur,
+        L.launch(k_blur, dim3((e->blur_geom.first[nl] - strip0 + 255) / 256, batch), dim3(256), 0, pyr, blur,
                            e->frame_pyr, dg, e->blur_geom, strip0);
 }
 
 static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch, int w, int h, size_t stride,
                            size_t frame_stride, orbgpu_keypoint *d_kps, uint8_t *d_desc, int cap, int *d_n_out,
-                           hipStream_t st)
+                           Launcher &L)
 {
+    hipStream_t st = L.st;  // (events and the side stream below: plain launches only)
     const int nl = e->nlevels;
     const LevelGeom *dg = e->d_geom.as<LevelGeom>();
     uint8_t *pyr = e->d_pyr.as<uint8_t>();
@@ -2790,7 +2872,8 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     int rc = e->d_aux.reserve(sizeof(KpAux) * (size_t)cap * batch);
     if (rc != ORBGPU_OK)
         return rc;
-    const bool prof = e->profiling && e->prof_calls < orbgpu_extractor::PROF_SLOTS;
+    const bool rec = L.graph != nullptr;  // recording a graph: no events, no side stream
+    const bool prof = !rec && e->profiling && e->prof_calls < orbgpu_extractor::PROF_SLOTS;
     if (prof && e->ev.empty()) {
         e->ev.resize((size_t)orbgpu_extractor::PROF_SLOTS * 2 * ST_COUNT, nullptr);
         for (auto &x : e->ev)
@@ -2804,9 +2887,9 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     {                                                                          \
         if (prof)                                                              \
             ORBGPU_HIP_TRY(hipEventRecord(evs[1 + (stage)], s));               \
-        if (e->stage_signal[stage])                                            \
+        if (!rec && e->stage_signal[stage])                                    \
             ORBGPU_HIP_TRY(hipEventRecord(e->stage_signal[stage], s));         \
-        if (e->pipe_signal[stage])                                             \
+        if (!rec && e->pipe_signal[stage])                                     \
             ORBGPU_HIP_TRY(hipEventRecord(e->pipe_signal[stage], s));          \
     }
     // direct mode: aligned rows, and strides the 24-bit row-offset multiplies cover (checked by the callers: stride < 2^24)
@@ -2821,17 +2904,19 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     BEGIN(ST_PYRAMID, st);
     // concurrent blur in direct mode: level 0's blur depends on the image only -- it starts on the side stream now, next
     // to the resize chain (seven dependent launches whose small levels leave most of the device idle)
-    const bool early_blur0 = e->concurrent_blur && direct && !e->no_early_blur0;
+    const bool side_blur = e->concurrent_blur && !rec;  // (a recorded graph is a chain)
+    Launcher Ls(e->side);
+    const bool early_blur0 = side_blur && direct && !e->no_early_blur0;
     if (early_blur0) {
         ORBGPU_HIP_TRY(hipEventRecord(e->ev_fork0, st));
         ORBGPU_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork0, 0));
         if (prof)
             ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 1], e->side));
-        launch_blur(e, s0, batch, e->side, 1);
+        launch_blur(e, s0, batch, Ls, 1);
     }
     {
         if (!direct) {
-            int rcb = materialize_level0(e, s0, batch, st);
+            int rcb = materialize_level0(e, s0, batch, L);
             if (rcb != ORBGPU_OK)
                 return rcb;
         }
@@ -2846,12 +2931,12 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
                 const bool dir1 = direct && l == 1;  // level 1 straight from the image
                 auto kern = dir1 ? (rows == PYR_ROWS ? k_resize_fast<true, true> : k_resize_fast<false, true>)
                                  : (rows == PYR_ROWS ? k_resize_fast<true, false> : k_resize_fast<false, false>);
-                hipLaunchKernelGGL(kern, grf, dim3(256), 0, st, pyr, e->frame_pyr, dg, l, e->d_rstrip.as<ResizeStrip>(),
+                L.launch(kern, grf, dim3(256), 0, pyr, e->frame_pyr, dg, l, e->d_rstrip.as<ResizeStrip>(),
                                    e->d_rsel.as<uint4>(), e->d_rwt.as<uint4>(), e->d_yrow.as<YRow>(),
                                    dir1 ? e->rs_off_direct : gl.rs_off, rows, s0);
             }
             else
-                hipLaunchKernelGGL(k_resize_level, gr, dim3(256), 0, st, pyr, e->frame_pyr, dg, l,
+                L.launch(k_resize_level, gr, dim3(256), 0, pyr, e->frame_pyr, dg, l,
                                    e->d_xtab.as<XTab>(), e->d_ytab.as<YTab>());
         }
     }
@@ -2860,30 +2945,33 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     // follows it pays for the write-back of the blurred planes (k_describe 105 instead of 87 us behind it, k_orient 119
     // instead of 93), and FAST has bandwidth to spare.  (On a side stream next to the quadtree both were slower.)
     BEGIN(ST_BLUR, st);
-    if (e->concurrent_blur) {
+    if (side_blur) {
         // fork: the side stream waits for the pyramid, blurs, and is joined in front of the descriptor stage
         ORBGPU_HIP_TRY(hipEventRecord(e->ev_fork, st));
         ORBGPU_HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
         if (prof && !early_blur0)
             ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 1], e->side));
-        launch_blur(e, s0, batch, e->side, early_blur0 ? 2 : 0);
+        launch_blur(e, s0, batch, Ls, early_blur0 ? 2 : 0);
         if (prof)
             ORBGPU_HIP_TRY(hipEventRecord(evs[ST_COUNT + 2], e->side));
         ORBGPU_HIP_TRY(hipEventRecord(e->ev_join, e->side));
     } else
-        launch_blur(e, s0, batch, st);
+        launch_blur(e, s0, batch, L);
     END(ST_BLUR, st);
     BEGIN(ST_FAST, st);
     if (e->counters_dirty) {  // a previous call enqueued the FAST pass but not the quadtree that re-arms the counters
-        ORBGPU_HIP_TRY(hipMemsetAsync(e->d_cellcnt.p, 0, e->d_cellcnt.bytes, st));
-        ORBGPU_HIP_TRY(hipMemsetAsync(e->d_qtaux.p, 0, e->d_qtaux.bytes, st));
+        int rcm = L.memset32(e->d_cellcnt.p, e->d_cellcnt.bytes & ~(size_t)3);
+        if (rcm == ORBGPU_OK)
+            rcm = L.memset32(e->d_qtaux.p, e->d_qtaux.bytes & ~(size_t)3);
+        if (rcm != ORBGPU_OK)
+            return rcm;
     }
     e->counters_dirty = true;
     {
         const int t_ini = std::max(e->prm.ini_th_fast, 1), t_min = std::max(e->prm.min_th_fast, 1);
         const DetectGeom &dgeo = direct ? e->det_geom_direct : e->det_geom;
         const int nwaves = (dgeo.first[nl] + FD_OWN - 1) / FD_OWN;
-        hipLaunchKernelGGL(e->fast_early_out ? k_fast_detect<true> : k_fast_detect<false>, dim3((nwaves + 3) / 4, batch), dim3(256), 0, st, pyr, e->frame_pyr, dg,
+        L.launch(e->fast_early_out ? k_fast_detect<true> : k_fast_detect<false>, dim3((nwaves + 3) / 4, batch), dim3(256), 0, pyr, e->frame_pyr, dg,
                            dgeo, e->d_ctab.as<ColumnInfo>(), e->d_cells.as<CellDesc>(), (int)e->cells.size(),
                            e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(), std::min(t_ini, t_min),
                            t_ini, e->fast_queue_cap, s0);
@@ -2891,7 +2979,7 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     END(ST_FAST, st);
     BEGIN(ST_QUADTREE, st);
     if (batch >= QT_BATCH_MIN || e->force_batch_quadtree)
-        hipLaunchKernelGGL(k_quadtree<false>, dim3(batch, nl), dim3(QT_THREADS_BATCH), e->qt_lds, st, dg,
+        L.launch(k_quadtree<false>, dim3(batch, nl), dim3(QT_THREADS_BATCH), e->qt_lds, dg,
                            e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
@@ -2899,37 +2987,42 @@ static int launch_pipeline(orbgpu_extractor *e, const uint8_t *d_gray, int batch
     else {
         // the filtering / counting sweep over the stored keys of every level first, spread over the device
         if (e->qt_prefilter)
-            hipLaunchKernelGGL(k_qt_prefilter, dim3(std::min((e->max_slots_level + QT_PRE_KEYS - 1) / QT_PRE_KEYS, QT_PRE_GRID), nl, batch), dim3(256), 0,
-                               st, dg, (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
+            L.launch(k_qt_prefilter, dim3(std::min((e->max_slots_level + QT_PRE_KEYS - 1) / QT_PRE_KEYS, QT_PRE_GRID), nl, batch), dim3(256), 0, dg, (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots, e->d_cellcnt.as<int>(),
                                e->d_dkey.as<uint32_t>(), e->d_qtaux.as<int>(), std::max(e->prm.ini_th_fast, 1));
-        hipLaunchKernelGGL(k_quadtree<true>, dim3(batch, nl), dim3(w * h >= QT_LARGE_PIXELS ? QT_THREADS : QT_THREADS_SMALL), e->qt_lds + (size_t)e->qt_kcap * 6, st, dg,
+        L.launch(k_quadtree<true>, dim3(batch, nl), dim3(w * h >= QT_LARGE_PIXELS ? QT_THREADS : QT_THREADS_SMALL), e->qt_lds + (size_t)e->qt_kcap * 6, dg,
                            e->d_cells.as<CellDesc>(), (int)e->cells.size(), e->d_slots.as<uint32_t>(), e->frame_slots,
                            e->d_cellcnt.as<int>(), e->d_dkey.as<uint32_t>(), e->d_dnode.as<uint16_t>(),
                            e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(), e->d_ncand.as<int>(), nl,
                            e->ncap, std::max(e->prm.ini_th_fast, 1), e->qt_kcap, qt_dbg(),
                            e->qt_prefilter ? e->d_qtaux.as<int>() : (int *)nullptr);
     }
-    ORBGPU_HIP_TRY(hipGetLastError());
+    if (!rec)
+        ORBGPU_HIP_TRY(hipGetLastError());
     e->counters_dirty = false;
     END(ST_QUADTREE, st);
     BEGIN(ST_ORIENT, st);
     const int or_iters = batch >= OR_BATCH_MIN ? OR_ITERS : 1;
-    hipLaunchKernelGGL(k_orient, dim3((e->sel_cap_total + 8 * or_iters - 1) / (8 * or_iters), batch), dim3(256), 0, st, pyr, e->frame_pyr, dg, nl,
+    L.launch(k_orient, dim3((e->sel_cap_total + 8 * or_iters - 1) / (8 * or_iters), batch), dim3(256), 0, pyr, e->frame_pyr, dg, nl,
                        e->d_sel.as<uint32_t>(), e->sel_cap_total, e->d_nsel.as<int>(),
                        reinterpret_cast<const uint32_t *>(e->d_pattern.as<uint8_t>() + 1024), d_kps,
                        e->d_aux.as<KpAux>(), cap, d_n_out, or_iters, s0);
-    hipLaunchKernelGGL(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0, st,
+    L.launch(k_trig, dim3((std::min(cap, e->max_kp) + 255) / 256, batch), dim3(256), 0,
                        e->d_aux.as<KpAux>(), d_n_out, cap, e->trig);
     END(ST_ORIENT, st);
     BEGIN(ST_DESCRIBE, st);
-    if (e->concurrent_blur)
+    if (side_blur)
         ORBGPU_HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));  // join: the descriptors read the blurred planes
-    hipLaunchKernelGGL(k_describe, dim3((std::min(cap, e->max_kp) + 7) / 8, batch), dim3(256), 0, st, blur,
+    L.launch(k_describe, dim3((std::min(cap, e->max_kp) + 7) / 8, batch), dim3(256), 0, blur,
                        e->frame_pyr, dg, e->d_aux.as<KpAux>(), d_n_out, cap, e->d_pattern.as<int8_t>(), d_desc);
     END(ST_DESCRIBE, st);
 #undef BEGIN
 #undef END
-    ORBGPU_HIP_TRY(hipGetLastError());
+    if (!rec)
+        ORBGPU_HIP_TRY(hipGetLastError());
+    else if (L.err != hipSuccess) {
+        set_error("recording the extraction graph: %s", hipGetErrorString(L.err));
+        return ORBGPU_EHIP;
+    }
     if (prof)
         e->prof_calls++;
     e->last_batch = batch;
@@ -2975,6 +3068,8 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
         e->direct0_min_batch = std::max(atoi(q), 1);
     if (const char *q = getenv("ORBGPU_FAST_EARLY_OUT"))  // default of the option for handles created from now on (fuzzing, A/B)
         e->fast_early_out = atoi(q) != 0;
+    if (getenv("ORBGPU_DEBUG_NO_GRAPH"))  // test hook / A-B: the host entry points always launch plainly
+        e->graph_state = -1;
     if (const char *q = getenv("ORBGPU_DEBUG_FAST_QUEUE"))  // test hook: forces k_fast_detect's queue-full path
         e->fast_queue_cap = std::min(std::max(atoi(q), 0), FD_QCAP);
     e->nlevels = p->nlevels;
@@ -3085,8 +3180,8 @@ int orbgpu_extract_batch_device(orbgpu_extractor *e, const uint8_t *d_gray, int3
     rc = configure(e, w, h, std::max(batch, e->prm.max_batch));
     if (rc != ORBGPU_OK)
         return rc;
-    return launch_pipeline(e, d_gray, batch, w, h, stride, frame_stride, d_kps, d_desc, cap, d_n_out,
-                           (hipStream_t)hip_stream);
+    Launcher L((hipStream_t)hip_stream);
+    return launch_pipeline(e, d_gray, batch, w, h, stride, frame_stride, d_kps, d_desc, cap, d_n_out, L);
 }
 
 int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch, int32_t w, int32_t h,
@@ -3114,17 +3209,19 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch
         return rc;
     if ((rc = e->d_nout.reserve(sizeof(int) * batch)) != ORBGPU_OK)
         return rc;
+    // Everything that allocates or uploads tables comes first (a first call of a configuration), while the stream is
+    // empty; only then is work enqueued.
+    if ((rc = configure(e, w, h, std::max(batch, e->prm.max_batch))) != ORBGPU_OK)
+        return rc;
+    if ((rc = e->d_aux.reserve(sizeof(KpAux) * (size_t)cap * batch)) != ORBGPU_OK)
+        return rc;
     for (int f = 0; f < batch; f++)
         ORBGPU_HIP_TRY(hipMemcpy2DAsync(e->d_in.as<uint8_t>() + img * f, (size_t)w, gray + frame_stride * f, stride,
                                         (size_t)w, (size_t)h, hipMemcpyHostToDevice, e->stream));
     // Single frames are launch bound (17 dependent launches for 0.3 MB): replay them as one hipGraph.  The graph bakes
     // in the handle-owned buffers, so it is keyed on them and on the geometry; a first call of a configuration runs
-    // plain (it may allocate), the second captures.  Profiling (events between stages) and capture failures fall
+    // plain, the second captures.  Profiling (events between stages) and capture failures fall
     // back to plain launches.
-    if ((rc = configure(e, w, h, std::max(batch, e->prm.max_batch))) != ORBGPU_OK)
-        return rc;
-    if ((rc = e->d_aux.reserve(sizeof(KpAux) * (size_t)cap * batch)) != ORBGPU_OK)
-        return rc;
     uint64_t key = 1469598103934665603ull;
     for (uint64_t v : {(uint64_t)w, (uint64_t)h, (uint64_t)batch, (uint64_t)cap, (uint64_t)(uintptr_t)e->d_in.p,
                        (uint64_t)(uintptr_t)e->d_kps.p, (uint64_t)(uintptr_t)e->d_desc.p, (uint64_t)(uintptr_t)e->d_nout.p,
@@ -3138,15 +3235,17 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch
                 e->level0_materialized = !e->last_src.direct;  // the replay did what launch_pipeline recorded: no padded level 0 in direct mode
             } else
                 e->graph_state = -1;
-        } else if (e->graph_key == key) {  // second call of this configuration: capture
+        } else if (e->graph_key == key) {  // second call of this configuration: record the graph
             hipGraph_t g = nullptr;
             hipGraphExec_t ge = nullptr;
-            bool ok = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            bool ok = hipGraphCreate(&g, 0) == hipSuccess;
             if (ok) {
+                Launcher L;
+                L.graph = g;
                 const int lrc = launch_pipeline(e, e->d_in.as<uint8_t>(), batch, w, h, (size_t)w, img,
                                                 e->d_kps.as<orbgpu_keypoint>(), e->d_desc.as<uint8_t>(), cap,
-                                                e->d_nout.as<int32_t>(), e->stream);
-                ok = hipStreamEndCapture(e->stream, &g) == hipSuccess && lrc == ORBGPU_OK && g;
+                                                e->d_nout.as<int32_t>(), L);
+                ok = lrc == ORBGPU_OK && L.err == hipSuccess;
             }
             if (ok)
                 ok = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
@@ -3164,12 +3263,14 @@ int orbgpu_extract_batch(orbgpu_extractor *e, const uint8_t *gray, int32_t batch
             }
             if (!ok) {
                 (void)hipGetLastError();
+                if (ge && ge != e->graph_exec)
+                    (void)hipGraphExecDestroy(ge);
                 if (g && g != e->graph)
                     (void)hipGraphDestroy(g);
                 e->graph_state = -1;
             }
         } else {
-            e->graph_key = key;  // first call of a new configuration: plain launches, capture next time
+            e->graph_key = key;  // first call of a new configuration: plain launches, the graph next time
             if (e->graph_exec) {
                 (void)hipGraphExecDestroy(e->graph_exec);
                 e->graph_exec = nullptr;
@@ -3217,7 +3318,8 @@ static int ensure_level0(orbgpu_extractor *e)
     if (e->level0_materialized)
         return ORBGPU_OK;
     ORBGPU_HIP_TRY(hipDeviceSynchronize());
-    int rc = materialize_level0(e, e->last_src, e->last_batch, nullptr);
+    Launcher L0(nullptr);
+    int rc = materialize_level0(e, e->last_src, e->last_batch, L0);
     if (rc != ORBGPU_OK)
         return rc;
     ORBGPU_HIP_TRY(hipDeviceSynchronize());
