@@ -158,6 +158,7 @@ int orbgpu_vocabulary_create(int32_t k, int32_t L, int32_t n_nodes, const int32_
         if (r != ORBGPU_OK)
             return r;
         ORBGPU_HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        ORBGPU_HIP_TRY(hipStreamSynchronize(nullptr));  // (the kernels that read this run on non-blocking streams)
         return ORBGPU_OK;
     };
     if ((rc = up(v->child_first, first.data(), sizeof(int) * (size_t)n_nodes)) != ORBGPU_OK ||

@@ -2163,6 +2163,8 @@ int orbgpu_cloud_remove_outliers(orbgpu_cloud *c, int32_t mean_k, double stddev_
                     pts[(size_t)o++] = pts[(size_t)i];
             if (kept > 0)
                 e = hipMemcpy(c->map[c->cur].p, pts.data(), sizeof(Point) * (size_t)kept, hipMemcpyHostToDevice);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(nullptr);  // null-stream work is not ordered with the handle's non-blocking stream
             if (e == hipSuccess) {
                 c->size = kept;
                 c->sorted_map = false;  // the next insert re-derives order and bounding box from the points

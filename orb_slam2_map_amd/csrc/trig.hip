@@ -155,6 +155,8 @@ int trig_table_for_device(int device_id, TrigTable *out)
             if (he == hipSuccess)
                 he = hipMemcpy(n->val.p, g_host.val.data(), g_host.val.size() * 8, hipMemcpyHostToDevice);
         }
+        if (rc == ORBGPU_OK && he == hipSuccess)
+            he = hipStreamSynchronize(nullptr);  // (the kernels that read the table run on non-blocking streams)
         if (rc != ORBGPU_OK || he != hipSuccess) {
             if (rc == ORBGPU_OK) {
                 set_error("trig table upload: %s", hipGetErrorString(he));
