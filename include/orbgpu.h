@@ -165,7 +165,8 @@ int orbgpu_extractor_debug_read(orbgpu_extractor *h, int32_t what, int32_t frame
  * disabling keeps the window, so a caller may profile a sample of its calls).
  * Names are returned by orbgpu_extractor_stage_name(i); count by orbgpu_extractor_stage_count(). */
 /* The host entry points (orbgpu_extract, orbgpu_extract_batch) replay their launch sequence as a hipGraph from the
- * third call of a configuration on: *state = 1 graph in use, 0 not captured yet, -1 capture failed (plain launches). */
+ * third call of a configuration on: *state = 1 graph in use, 0 not recorded yet, -1 recording failed (plain launches).
+ * The graph is built node by node (hipGraphAddKernelNode), never by stream capture: nothing process-wide is touched. */
 int orbgpu_extractor_graph_state(const orbgpu_extractor *h, int32_t *state);
 /* How DistributeOctTree (ORBextractor.cc:539-763) is launched for a call of `batch` frames at the configured image size:
  * keys of a level the workgroup keeps in LDS (0 = the batch variant, all keys in memory), threads per workgroup and the
