@@ -148,15 +148,16 @@ while time.time() - t0 < budget:
         th, mono, ori = float(rng.choice([7.0, 15.0, 30.0])), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         no, ko = O.search_by_projection_last(ocur, Tcw, fx, fy, cx, cy, bf, bf / fx, last, th, mono, ori, k0)
         dl, dc = G.DeviceFrame().upload(gframe(olast)), G.DeviceFrame().upload(gframe(ocur))
+        with_outliers = bool(rng.integers(0, 2))
         ng, kg = G.search_by_projection_last_table(dc, Tcw, dl, Tl, tbl, np.where(has, lids[:nl], -1), fx, fy, cx, cy, bf, bf / fx, th,
-                                                   mono, ori, last_outlier=last["outlier"] if rng.integers(0, 2) else None,
+                                                   mono, ori, last_outlier=last["outlier"] if with_outliers else None,
                                                    cur_kp_ids=cur_ids)
-        if last["outlier"].any() and ng != no:  # (the outlier array is optional: without it the oracle must be asked again)
+        if not with_outliers:  # the outlier array is optional: without it the oracle is asked for the same thing
+            # (until round 4 this branch was only taken when the COUNTS differed: a call without the array whose count
+            # happened to equal the with-outliers count -- seed 7, 202 vs 202 -- was then compared with the wrong answer)
             last2 = dict(last)
             last2["outlier"] = np.zeros(nl, np.uint8)
-            no2, ko2 = O.search_by_projection_last(ocur, Tcw, fx, fy, cx, cy, bf, bf / fx, last2, th, mono, ori, k0)
-            if ng == no2 and np.array_equal(kg, ko2):
-                no, ko = no2, ko2
+            no, ko = O.search_by_projection_last(ocur, Tcw, fx, fy, cx, cy, bf, bf / fx, last2, th, mono, ori, k0)
         if ng != no or not np.array_equal(kg, ko):
             fail("last", dict(cfg, th=th, mono=mono, ori=ori), ng, no)
         n_last += 1
