@@ -614,12 +614,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 {
     __shared__ uint2 s_q[4][FD_QCAP];
     __shared__ DetectLane s_lane[4][64];
-    __shared__ int s_qn[4], s_cc[4][FD_CELLS], s_cid[4][FD_CELLS];
+    __shared__ int s_cc[4][FD_CELLS], s_cid[4][FD_CELLS];
     int bx, f;
     xcd_frame_block(bx, f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0)
-        s_qn[wave] = 0;
     if (lane < FD_CELLS)
         s_cc[wave][lane] = 0;
     const int q = (bx * 4 + wave) * FD_OWN + lane - 1;
@@ -639,11 +637,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // boundary sits out (rows = 0): the neighbour it would deliver is outside every cell and masked anyway.
     const bool wave_dir0 = s0.direct != 0 && __builtin_amdgcn_readlane(level, 1) == 0;
     const bool dir0 = s0.direct != 0 && level == 0;
-    const int rows = in_range && dir0 == wave_dir0 ? min(g.hcell, g.h - EDGE - y0) : 0;  // (<= 0 for the padding strips)
+    const int rows = max(in_range && dir0 == wave_dir0 ? min(g.hcell, g.h - EDGE - y0) : 0, 0);  // (0 for the padding strips)
+    // The row loop is WAVE-uniform: every lane runs as many steps as the wave's tallest band (a wave can straddle bands and
+    // levels of different height).  A lane past the end of its own band keeps scoring -- on the last row it may fetch
+    // (fetch_max; a lane without rows reads the first rows of the plane) -- and its scores are masked to zero, which is what
+    // "rows outside the band count as 0" asks for anyway.  Uniform control flow costs no copies at branch joins and lets
+    // the record queue count in a scalar register.
+    int wrows = rows;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        wrows = max(wrows, __shfl_xor(wrows, off, 64));
+    wrows = __builtin_amdgcn_readfirstlane(wrows);
+    const int fetch_max = rows + 5;  // the last input row the lane's band needs
     const uint8_t *fsrc = wave_dir0 ? s0.p + (size_t)f * s0.frame_stride : pyr + (size_t)f * frame_pyr;
     const int lpitch = dir0 ? (int)s0.pitch : g.pitch;
-    const uint32_t src0 = dir0 ? (uint32_t)(y0 - 3) * (uint32_t)lpitch + (uint32_t)(xs - 4)
-                               : (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE - 3) * (uint32_t)lpitch + (uint32_t)(xs + EDGE - 4);
+    const uint32_t src0 = rows == 0 ? 0u
+                          : dir0    ? (uint32_t)(y0 - 3) * (uint32_t)lpitch + (uint32_t)(xs - 4)
+                                    : (uint32_t)g.plane_off + (uint32_t)(y0 + EDGE - 3) * (uint32_t)lpitch + (uint32_t)(xs + EDGE - 4);
     uint32_t *fslots = slots + (size_t)f * frame_slots;
     int *fcnt = cell_cnt + (size_t)f * (ncells_total + ORBGPU_MAX_LEVELS);  // per-cell counters ...
     int *lcnt = fcnt + ncells_total;                                         // ... then the stored keys of every level
@@ -676,17 +686,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // NMS state, one row behind the scores: T of rows k-2 and k-1; H of row k-1 with the threshold folded in
     // (H = max(left, right, t)); S of row k-1 (packed pairs)
     uint32_t TpE = 0u, TpO = 0u, TcE = 0u, TcO = 0u, HcE = 0u, HcO = 0u, ScE = 0u, ScO = 0u;
+    int qn = 0;  // records the wave has queued: wave-uniform, the row loop's control flow is
     auto finish_row = [&](uint32_t TnE, uint32_t TnO, int row) {
         const pkh nbE = hmax3(__builtin_bit_cast(pkh, HcE), __builtin_bit_cast(pkh, TpE), __builtin_bit_cast(pkh, TnE));
         const pkh nbO = hmax3(__builtin_bit_cast(pkh, HcO), __builtin_bit_cast(pkh, TpO), __builtin_bit_cast(pkh, TnO));
         // x > y  <=>  sign(y - x) for values in [0,255]: survivor <=> s > max(every neighbour, t)
         const uint32_t sE = as_u32(h_as_pk(nbE) - as_pk(ScE)) & vE;
         const uint32_t sO = as_u32(h_as_pk(nbO) - as_pk(ScO)) & vO;
+        // a lane's slot in the wave's queue: the fill count + the survivor lanes below it (the compare that feeds the branch
+        // is the ballot; until round 4 an LDS atomic with return that nearly every row of this stream waited for)
+        const unsigned long long srv = __ballot((sE | sO) != 0u);
         if (sE | sO) {
             const uint32_t sg = (sE >> 15) | (sO >> 7);  // flag bytes in pixel order: px0 bit 0, px1 bit 8, px2 bit 16, px3 bit 24
             const uint32_t sc4 = __builtin_amdgcn_perm(ScO, ScE, 0x06020400u);
             const uint32_t rec = sg | ((uint32_t)row << 1) | lane_tag;
-            const int slot = atomicAdd(&s_qn[wave], 1);
+            const int slot = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(srv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)srv, 0u));
             if (slot < qcap)
                 s_q[wave][slot] = make_uint2(sc4, rec);
             else
@@ -696,6 +710,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     fslots[geom[level].slot_off + atomicAdd(&lcnt[level], 1)] = pack_key(dl.xrel + p, dl.yrel + row, sc - 1);
                 });
         }
+        qn += (int)__popcll(srv);
     };
     auto nms_row = [&](uint32_t se, uint32_t so, int k) {
         // wave-wide lane shifts (DPP wave_shr:1 / wave_shl:1): an inactive or missing source lane yields 0
@@ -721,7 +736,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     RowU r0, r1, r2, r3, r4, r5, r6;
 #define FD_FETCH(row)                                                                                        \
     {                                                                                                        \
-        const uint32_t *qq = reinterpret_cast<const uint32_t *>(fsrc + (src0 + rowoff((row), lpitch)));     \
+        const uint32_t *qq = reinterpret_cast<const uint32_t *>(fsrc + (src0 + rowoff(min((int)(row), fetch_max), lpitch))); \
         nx.d[0] = qq[0];                                                                                     \
         nx.d[1] = qq[1];                                                                                     \
         nx.d[2] = qq[2];                                                                                     \
@@ -732,16 +747,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         unpack_row(nx, R);                                                                                   \
     }
 #define FD_STEP(A, B, C, D, E, F, G, k)                                                                      \
-    if ((k) < rows) {                                                                                        \
+    if ((k) < wrows) {                                                                                       \
         unpack_row(nx, G);                                                                                   \
-        if ((k) + 1 < rows)                                                                                  \
-            FD_FETCH((k) + 7)                                                                                \
+        FD_FETCH((k) + 7)                                                                                    \
+        const uint32_t lm = (uint32_t)(((k) - rows) >> 31);  /* all ones while the lane's own band lasts */   \
         pk16 se = {0, 0}, so = {0, 0};                                                                       \
         bool runE = true, runO = true;                                                                       \
         if (EARLY) {                                                                                         \
             if (hold == 0) {                                                                                 \
-                runE = __builtin_amdgcn_ballot_w64(fast_maybe_half<0>(A, D, G, tpk) != 0u) != 0ull;          \
-                runO = __builtin_amdgcn_ballot_w64(fast_maybe_half<1>(A, D, G, tpk) != 0u) != 0ull;          \
+                runE = __builtin_amdgcn_ballot_w64((fast_maybe_half<0>(A, D, G, tpk) & lm) != 0u) != 0ull;   \
+                runO = __builtin_amdgcn_ballot_w64((fast_maybe_half<1>(A, D, G, tpk) & lm) != 0u) != 0ull;   \
                 hold = (runE && runO) ? FD_EARLY_HOLD : 0;                                                   \
             } else                                                                                           \
                 hold--;                                                                                      \
@@ -752,7 +767,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (runO)                                                                                            \
             so = fast_score_half<1>(A, B, C, D, E, F, G);                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
-        nms_row(as_u32(se), as_u32(so), (k));                                                                \
+        nms_row(as_u32(se) & lm, as_u32(so) & lm, (k));                                                      \
     }
     // EARLY: rows to go before the bound is evaluated again -- after a row whose segment was NOT clear the next
     // FD_EARLY_HOLD rows run the network untested (textured regions pay a quarter of the test), after a clear one every row is
@@ -763,12 +778,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int o = 0; o < 8; o++)
         r0.f[o] = r1.f[o] = r2.f[o] = r3.f[o] = r4.f[o] = r5.f[o] = r6.f[o] = 0u;
-    if (rows > 0) {
+    if (wrows > 0) {
         FD_LOAD(r0, 0) FD_LOAD(r1, 1) FD_LOAD(r2, 2) FD_LOAD(r3, 3) FD_LOAD(r4, 4) FD_LOAD(r5, 5)
         FD_FETCH(6)
     }
 #pragma unroll 1
-    for (int k = 0; k < rows; k += 7) {
+    for (int k = 0; k < wrows; k += 7) {
         FD_STEP(r0, r1, r2, r3, r4, r5, r6, k)
         FD_STEP(r1, r2, r3, r4, r5, r6, r0, k + 1)
         FD_STEP(r2, r3, r4, r5, r6, r0, r1, k + 2)
@@ -780,8 +795,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef FD_STEP
 #undef FD_LOAD
 #undef FD_FETCH
-    if (rows > 0)
-        finish_row(0u, 0u, rows - 1);  // the row below the band counts as 0
+    if (wrows > 0)
+        finish_row(0u, 0u, wrows - 1);  // the row below the band counts as 0 (a shorter band was finished inside the loop)
 
     // ---- the wave's records become keys.  The cells a wave touches are a contiguous range of at most FD_CELLS ids
     //      (host-checked), so id mod FD_CELLS addresses per-wave counters in LDS.  Per (wave, cell): one global atomic
@@ -791,7 +806,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nrec = min(s_qn[wave], qcap);
+    const int nrec = min(qn, qcap);
     for (int e = lane; e < nrec; e += 64) {
         const uint2 r = s_q[wave][e];
         detect_record(r.x, r.y, s_lane[wave][(r.y >> 9) & 63u], [&](int, int sc, int cell) {
