@@ -714,8 +714,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     auto nms_row = [&](uint32_t se, uint32_t so, int k) {
         // wave-wide lane shifts (DPP wave_shr:1 / wave_shl:1): an inactive or missing source lane yields 0
-        const uint32_t oL = __builtin_amdgcn_update_dpp(0u, so, 0x138, 0xf, 0xf, false);  // left column's (px1, px3)
-        const uint32_t eR = __builtin_amdgcn_update_dpp(0u, se, 0x130, 0xf, 0xf, false);  // right column's (px0, px2)
+        const uint32_t oL = __builtin_amdgcn_update_dpp(0u, so, 0x138, 0xf, 0xf, true);  // left column's (px1, px3)
+        const uint32_t eR = __builtin_amdgcn_update_dpp(0u, se, 0x130, 0xf, 0xf, true);  // right column's (px0, px2)
         const uint32_t le = __builtin_amdgcn_perm(so, oL, selLE);                    // (px-1, px1)
         const uint32_t re = so & kRE;                                                 // (px1, px3)
         const uint32_t lo = se & kLO;                                                 // (px0, px2)
