@@ -84,7 +84,7 @@ def pmc_traffic(stage, frames_per_launch):
 
 def valu_issue(stage, frames_per_launch, ms_per_launch):
     """Second bound of the dominant kernel (it is VALU-issue bound, not HBM bound): VALU wave-instructions per launch from
-    the committed SQ counter pass (profiles/r03_pmc_sq.json, rocprofv3 --pmc SQ_INSTS_VALU ... at B = 256), scaled to
+    the committed SQ counter pass (profiles/r04_pmc_sq.json, rocprofv3 --pmc SQ_INSTS_VALU ... at B = 256), scaled to
     this launch, against the live launch duration; the ceiling is tools/ubench/valu_rate (profiles/r02_valu_rate.txt)."""
     try:
         sq = [n for n in ("r04_pmc_sq.json", "r03_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", n))][0]
@@ -114,7 +114,7 @@ def valu_issue_step(frames_per_step, ms_per_step):
     for name in ("r04_pmc_sq.json", "r03_pmc_sq.json"):
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", name)))
-            nsteps = j["kernels"]["k_fast_detect"]["launches"]  # one launch per step
+            nsteps = max(v["launches"] for kn, v in j["kernels"].items() if kn.split("<")[0] == "k_fast_detect")  # one launch per step
             per = {kn: v["valu_insts_per_launch"] * v["launches"] / nsteps / 256.0 * frames_per_step
                    for kn, v in j["kernels"].items()}
             insts = sum(per.values())
