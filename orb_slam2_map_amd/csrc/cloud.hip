@@ -403,19 +403,23 @@ __global__ __launch_bounds__(256) void k_bp(const float *__restrict__ depth, siz
     bool ok[4];
     int mm[4], nn[4];
     unsigned rank[4];
+    uint32_t col[4];  // the sample's colour, requested with its depth (one round trip instead of two; unused if the depth is invalid)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int s = tile * TILE + k * 256 + threadIdx.x;
         ok[k] = false;
         d[k] = 0.f;
         mm[k] = nn[k] = 0;
+        col[k] = 0u;
         if (s < ns) {
             const int r = s / gw;
             mm[k] = r * 3;
             nn[k] = (s - r * gw) * 3;
             d[k] = depth[(size_t)mm[k] * dstride + (size_t)nn[k]];
-            ok[k] = depth_valid(d[k]);
+            const uint8_t *px = rgb + (size_t)mm[k] * cstride + (size_t)nn[k] * 3;
+            col[k] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
         }
+        ok[k] = s < ns && depth_valid(d[k]);
         const unsigned long long bal = __ballot(ok[k]);
         rank[k] = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0)
@@ -441,8 +445,7 @@ __global__ __launch_bounds__(256) void k_bp(const float *__restrict__ depth, siz
         p.z = d[k];
         p.x = ((float)nn[k] - cx) * p.z / fx;  // :124-125, this exact operation order
         p.y = ((float)mm[k] - cy) * p.z / fy;
-        const uint8_t *px = rgb + (size_t)mm[k] * cstride + (size_t)nn[k] * 3;
-        p.rgba = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+        p.rgba = col[k];
         if (pose.apply && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
             // pcl::transformPointCloud with a double matrix (A8)
             const double x = p.x, y = p.y, z = p.z;
