@@ -182,6 +182,7 @@ int orbgpu_vocabulary_create(int32_t k, int32_t L, int32_t n_nodes, const int32_
 
 int orbgpu_vocabulary_destroy(orbgpu_vocabulary *v)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     if (!v)
         return ORBGPU_OK;
     (void)hipSetDevice(v->device_id);

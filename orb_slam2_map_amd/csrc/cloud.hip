@@ -1945,6 +1945,7 @@ extern "C" {
 
 int orbgpu_cloud_create(double resolution, int32_t device_id, orbgpu_cloud **out)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     ORBGPU_REQUIRE(out, "null argument");
     ORBGPU_REQUIRE(resolution > 0 && std::isfinite(resolution), "resolution must be positive");
     int rc = select_device(device_id);
@@ -1981,6 +1982,7 @@ int orbgpu_cloud_create(double resolution, int32_t device_id, orbgpu_cloud **out
 
 int orbgpu_cloud_destroy(orbgpu_cloud *c)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     if (!c)
         return ORBGPU_OK;
     (void)hipSetDevice(c->device_id);

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 
 #include "orbgpu.h"
 
@@ -93,6 +94,11 @@ struct DevBuf {
 };
 
 int select_device(int device_id);
+
+// Creation and destruction of handles take this lock: they are the calls that allocate / free device and pinned memory,
+// create / destroy streams, events and graphs, and synchronise the device -- the runtime has aborted once (1 of ~9 runs of
+// the GPU suite) with two threads inside orbgpu_extractor_destroy at the same moment.  Nothing on a per-frame path takes it.
+std::mutex &lifecycle_mutex();
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ int wave_reduce_add(int v)

@@ -3059,6 +3059,7 @@ extern "C" {
 
 int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor **out)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     ORBGPU_REQUIRE(p && out, "null argument");
     ORBGPU_REQUIRE(p->nlevels >= 1 && p->nlevels <= ORBGPU_MAX_LEVELS, "nlevels must be in [1,%d]", ORBGPU_MAX_LEVELS);
     ORBGPU_REQUIRE(p->nfeatures >= 1, "nfeatures must be positive");
@@ -3111,6 +3112,7 @@ int orbgpu_extractor_create(const orbgpu_extractor_params *p, orbgpu_extractor *
 
 int orbgpu_extractor_destroy(orbgpu_extractor *e)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     if (!e)
         return ORBGPU_OK;
     (void)hipSetDevice(e->prm.device_id);

@@ -423,6 +423,7 @@ int orbgpu_mappoint_table_last_unknown(const orbgpu_mappoint_table *t, int32_t *
 // ---------------------------------------------------------------------------------------------------------------------
 int orbgpu_mappoint_table_create(int32_t device_id, int32_t initial_rows, orbgpu_mappoint_table **out)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     ORBGPU_REQUIRE(out && initial_rows >= 0 && initial_rows <= (1 << 26), "bad argument");
     int rc = select_device(device_id);
     if (rc != ORBGPU_OK)
@@ -455,6 +456,7 @@ int orbgpu_mappoint_table_create(int32_t device_id, int32_t initial_rows, orbgpu
 
 int orbgpu_mappoint_table_destroy(orbgpu_mappoint_table *t)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     if (!t)
         return ORBGPU_OK;
     (void)hipSetDevice(t->device_id);
@@ -762,6 +764,7 @@ int orbgpu_mappoint_table_read(orbgpu_mappoint_table *t, int64_t id, float *worl
 // ---------------------------------------------------------------------------------------------------------------------
 int orbgpu_frame_create(int32_t device_id, orbgpu_frame **out)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     ORBGPU_REQUIRE(out, "null argument");
     int rc = select_device(device_id);
     if (rc != ORBGPU_OK)
@@ -784,6 +787,7 @@ int orbgpu_frame_create(int32_t device_id, orbgpu_frame **out)
 
 int orbgpu_frame_destroy(orbgpu_frame *fr)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     if (!fr)
         return ORBGPU_OK;
     (void)hipSetDevice(fr->device_id);

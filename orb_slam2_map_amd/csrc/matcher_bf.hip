@@ -609,6 +609,7 @@ extern "C" {
 
 int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orbgpu_matcher **out)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     ORBGPU_REQUIRE(out, "null argument");
     ORBGPU_REQUIRE(max_pairs >= 1 && cap >= 1 && cap <= 4096, "max_pairs must be >= 1 and cap in [1,4096]");
     int rc = select_device(device_id);
@@ -646,6 +647,7 @@ int orbgpu_matcher_create(int32_t device_id, int32_t max_pairs, int32_t cap, orb
 
 int orbgpu_matcher_destroy(orbgpu_matcher *m)
 {
+    std::lock_guard<std::mutex> lifecycle(orbgpu::lifecycle_mutex());
     if (!m)
         return ORBGPU_OK;
     (void)hipSetDevice(m->device_id);

@@ -24,6 +24,12 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+std::mutex &lifecycle_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+
 int select_device(int device_id)
 {
     int n = 0;
