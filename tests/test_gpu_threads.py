@@ -123,9 +123,12 @@ def test_first_calls_on_fresh_handles_from_fresh_threads(gpu, stream640):
     ref = [ge(f) for f in frames]
     bad = []
 
+    keep = []  # the handles are closed by the main thread, after the join: this test is about first calls, not teardown
+
     def worker(i, barrier, it):
         try:
             ext = gpu.ORBextractor(1000)
+            keep.append(ext)
             barrier.wait()
             for r in range(3):  # plain launches, the graph is recorded, the graph is replayed
                 k, d = ext(frames[i + (r & 1)])
@@ -147,6 +150,8 @@ def test_first_calls_on_fresh_handles_from_fresh_threads(gpu, stream640):
         for t in ts:
             t.join(120)
         assert all(not t.is_alive() for t in ts)
+        while keep:
+            keep.pop().close()
     assert not bad, bad[:8]
 
 
